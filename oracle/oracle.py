@@ -1,0 +1,222 @@
+"""ctypes front-end of the CPU oracle (oracle/fgs_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED (see fgs_oracle.c header): the reference has no golden vectors and cannot run here.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package never does.
+
+The functions chain the oracle stages in the order of the reference's host code:
+  forward   = rasterization/src/forward.cu:11-259   (K1 .. K10)
+  inference = rasterization/src/inference.cu:11-226
+  backward  = rasterization/src/backward.cu:8-125 + rasterization_api.cu:127-134 (zero-filled grads)
+  adam_step = adam/src/adam.cu:36-71
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+TILE_W, TILE_H, BLOCK_BLEND = 16, 12, 192
+
+
+class _Settings(C.Structure):
+    _fields_ = [
+        ('w2c', C.c_float * 12), ('cam_pos', C.c_float * 3), ('bg', C.c_float * 3),
+        ('active_sh_bases', C.c_int), ('total_sh_rest', C.c_int), ('width', C.c_int), ('height', C.c_int),
+        ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+        ('near_plane', C.c_float), ('far_plane', C.c_float), ('proper_aa', C.c_int),
+    ]
+
+
+@dataclass
+class Settings:
+    """Numpy mirror of RasterizerSettings (torch_bindings/rasterization.py:8-38)."""
+    w2c: np.ndarray            # [>=3, 4] row-major world-to-camera
+    cam_position: np.ndarray   # [3]
+    bg_color: np.ndarray       # [3]
+    active_sh_bases: int
+    width: int
+    height: int
+    focal_x: float
+    focal_y: float
+    center_x: float
+    center_y: float
+    near_plane: float
+    far_plane: float
+    proper_antialiasing: bool = False
+
+    def to_c(self, total_sh_rest: int) -> _Settings:
+        s = _Settings()
+        w = np.ascontiguousarray(self.w2c, dtype=np.float32).reshape(-1)[:12]
+        s.w2c[:] = w.tolist()
+        s.cam_pos[:] = np.asarray(self.cam_position, dtype=np.float32).reshape(-1).tolist()
+        s.bg[:] = np.asarray(self.bg_color, dtype=np.float32).reshape(-1).tolist()
+        s.active_sh_bases, s.total_sh_rest = int(self.active_sh_bases), int(total_sh_rest)
+        s.width, s.height = int(self.width), int(self.height)
+        s.fx, s.fy, s.cx, s.cy = self.focal_x, self.focal_y, self.center_x, self.center_y
+        s.near_plane, s.far_plane = self.near_plane, self.far_plane
+        s.proper_aa = int(bool(self.proper_antialiasing))
+        return s
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / 'libfgs_oracle.so'
+    src = _HERE / 'fgs_oracle.c'
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(['make', '-C', str(_HERE), '-B', 'libfgs_oracle.so'], check=True, capture_output=True)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.orc_preprocess.restype = C.c_int
+        _LIB.orc_ranges_and_buckets.restype = C.c_uint
+        _LIB.orc_extract_end_bit.restype = C.c_int
+        _LIB.orc_num_threads.restype = C.c_int
+    return _LIB
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def grid_of(width: int, height: int):
+    gw, gh = (width + TILE_W - 1) // TILE_W, (height + TILE_H - 1) // TILE_H
+    return gw, gh, gw * gh
+
+
+def end_bit_of(n_tiles: int) -> int:
+    return int(lib().orc_extract_end_bit(C.c_uint(n_tiles - 1)))
+
+
+def forward(means, scales, rotations, opacities, sh0, sh_rest, settings: Settings, *, bucket_size: int = 32,
+            inference: bool = False, to_chw: bool = True, clamp_output: bool = True) -> dict:
+    """Runs K1..K10 and returns every intermediate (names follow buffer_utils.h:45-163)."""
+    L = lib()
+    means, scales, rotations = _f32(means).reshape(-1, 3), _f32(scales).reshape(-1, 3), _f32(rotations).reshape(-1, 4)
+    opacities, sh0 = _f32(opacities).reshape(-1), _f32(sh0).reshape(-1, 3)
+    N = means.shape[0]
+    sh_rest = _f32(sh_rest).reshape(N, -1, 3)
+    total_rest = sh_rest.shape[1]
+    S = settings.to_c(total_rest)
+    W, H = settings.width, settings.height
+    gw, gh, T = grid_of(W, H)
+    out = {'N': N, 'grid': (gw, gh), 'T': T, 'end_bit': end_bit_of(T), 'bucket_size': bucket_size}
+
+    n_touched = np.zeros(N, np.uint32)
+    screen_bounds = np.zeros((N, 4), np.uint16)
+    mean2d = np.zeros((N, 2), np.float32)
+    conic_opacity = np.zeros((N, 4), np.float32)
+    color = np.zeros((N, 3), np.float32)
+    depth_keys = np.zeros(max(N, 1), np.uint32)
+    prim_idx = np.zeros(max(N, 1), np.uint32)
+    n_inst = C.c_uint(0)
+    V = L.orc_preprocess(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh0), _p(sh_rest), C.byref(S),
+                         int(inference), _p(n_touched), _p(screen_bounds), _p(mean2d), _p(conic_opacity), _p(color),
+                         _p(depth_keys), _p(prim_idx), C.byref(n_inst))
+    I = int(n_inst.value)
+    depth_keys, prim_idx = depth_keys[:V].copy(), prim_idx[:V].copy()
+    out.update(V=V, I=I, n_touched=n_touched, screen_bounds=screen_bounds, mean2d=mean2d, conic_opacity=conic_opacity,
+               color=color, depth_keys_unsorted=depth_keys.copy(), prim_idx_unsorted=prim_idx.copy())
+    L.orc_sort_pairs(V, _p(depth_keys), _p(prim_idx), 32)
+    out.update(depth_keys=depth_keys, prim_idx=prim_idx)
+
+    offsets = np.zeros(max(V, 1), np.uint32)
+    inst_keys = np.zeros(max(I, 1), np.uint32)
+    inst_prims = np.zeros(max(I, 1), np.uint32)
+    L.orc_create_instances(V, _p(prim_idx), _p(n_touched), _p(screen_bounds), _p(mean2d), _p(conic_opacity), gw,
+                           _p(offsets), _p(inst_keys), _p(inst_prims))
+    out.update(offsets=offsets[:V], inst_keys_unsorted=inst_keys[:I].copy(), inst_prims_unsorted=inst_prims[:I].copy())
+    L.orc_sort_pairs(I, _p(inst_keys), _p(inst_prims), out['end_bit'])
+    inst_keys, inst_prims = inst_keys[:I], inst_prims[:I]
+    out.update(inst_keys=inst_keys, inst_prims=inst_prims)
+
+    ranges = np.zeros((T, 2), np.uint32)
+    n_buckets = np.zeros(T, np.uint32)
+    bucket_offsets = np.zeros(T, np.uint32)
+    B = int(L.orc_ranges_and_buckets(I, _p(np.ascontiguousarray(inst_keys)), T, bucket_size, _p(ranges), _p(n_buckets),
+                                     _p(bucket_offsets)))
+    out.update(ranges=ranges, n_buckets=n_buckets, bucket_offsets=bucket_offsets, B=B)
+
+    P = W * H
+    inst_prims_c = np.ascontiguousarray(inst_prims) if I > 0 else np.zeros(1, np.uint32)
+    if inference:
+        image = np.zeros((3, H, W) if to_chw else (H, W, 3), np.float32)
+        L.orc_blend_forward(1, int(to_chw), int(clamp_output), bucket_size, _p(ranges), _p(bucket_offsets), _p(inst_prims_c),
+                            _p(screen_bounds), _p(mean2d), _p(conic_opacity), _p(color), C.byref(S), _p(image),
+                            None, None, None, None, None)
+        out['image'] = image
+        return out
+    image = np.zeros((3, H, W), np.float32)
+    final_T = np.ones(P, np.float32)
+    n_processed = np.zeros(P, np.uint32)
+    max_n_processed = np.zeros(T, np.uint32)
+    bucket_tile_index = np.zeros(max(B, 1), np.uint32)
+    bucket_ckpt = np.zeros((max(B, 1), BLOCK_BLEND, 4), np.float32)
+    L.orc_blend_forward(0, 1, 0, bucket_size, _p(ranges), _p(bucket_offsets), _p(inst_prims_c), _p(screen_bounds), _p(mean2d),
+                        _p(conic_opacity), _p(color), C.byref(S), _p(image), _p(final_T), _p(n_processed),
+                        _p(max_n_processed), _p(bucket_tile_index), _p(bucket_ckpt))
+    out.update(image=image, final_T=final_T, n_processed=n_processed, max_n_processed=max_n_processed,
+               bucket_tile_index=bucket_tile_index[:B], bucket_ckpt=bucket_ckpt[:B], _S=S,
+               _inputs=(means, scales, rotations, opacities, sh0, sh_rest))
+    return out
+
+
+def backward(fwd: dict, settings: Settings, grad_image, densification_info: np.ndarray | None = None) -> dict:
+    """K11 + K12 on the state returned by forward(); grads are zero-initialised as in rasterization_api.cu:127-134."""
+    L = lib()
+    means, scales, rotations, opacities, sh0, sh_rest = fwd['_inputs']
+    N, B, S = fwd['N'], fwd['B'], fwd['_S']
+    grad_image = _f32(grad_image).reshape(3, settings.height, settings.width)
+    g = {
+        'means': np.zeros((N, 3), np.float32), 'scales': np.zeros((N, 3), np.float32),
+        'rotations': np.zeros((N, 4), np.float32), 'opacities': np.zeros((N, 1), np.float32),
+        'sh0': np.zeros((N, 1, 3), np.float32), 'sh_rest': np.zeros(sh_rest.shape, np.float32),
+    }
+    grad_mean2d = np.zeros((N, 2), np.float32)
+    grad_conic = np.zeros((3, N), np.float32)
+    inst_prims = np.ascontiguousarray(fwd['inst_prims']) if fwd['I'] > 0 else np.zeros(1, np.uint32)
+    bti = np.ascontiguousarray(fwd['bucket_tile_index']) if B > 0 else np.zeros(1, np.uint32)
+    ckpt = np.ascontiguousarray(fwd['bucket_ckpt']) if B > 0 else np.zeros((1, BLOCK_BLEND, 4), np.float32)
+    L.orc_blend_backward(N, B, fwd['bucket_size'], _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims),
+                         _p(fwd['mean2d']), _p(fwd['conic_opacity']), _p(fwd['color']), C.byref(S), _p(grad_image),
+                         _p(fwd['image']), _p(fwd['final_T']), _p(fwd['max_n_processed']), _p(fwd['n_processed']),
+                         _p(bti), _p(ckpt), _p(grad_mean2d), _p(grad_conic), _p(g['opacities']), _p(g['sh0']))
+    g['_grad_mean2d'] = grad_mean2d.copy()
+    g['_grad_conic'] = grad_conic.copy()
+    g['_grad_opacity_acc'] = g['opacities'].copy()
+    g['_grad_color_acc'] = g['sh0'].copy()
+    dens = None
+    if densification_info is not None and densification_info.size > 0:
+        assert densification_info.dtype == np.float32 and densification_info.flags['C_CONTIGUOUS']
+        dens = _p(densification_info)
+    L.orc_preprocess_backward(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh_rest), C.byref(S),
+                              _p(fwd['n_touched']), _p(grad_mean2d), _p(grad_conic), _p(g['means']), _p(g['scales']),
+                              _p(g['rotations']), _p(g['opacities']), _p(g['sh0']), _p(g['sh_rest']), dens)
+    return g
+
+
+def adam_step(grad: np.ndarray, param: np.ndarray, exp_avg: np.ndarray, exp_avg_sq: np.ndarray, step: int, lr: float,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15) -> None:
+    """In-place Adam update (adam.cu:10-71)."""
+    for a in (grad, param, exp_avg, exp_avg_sq):
+        assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    lib().orc_adam_step(_p(grad), _p(param), _p(exp_avg), _p(exp_avg_sq), C.c_longlong(param.size), int(step),
+                        C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps))
