@@ -1,0 +1,205 @@
+"""torch <-> C-ABI glue: turns tensors into raw pointers, owns the resize callback, checks status codes.
+
+One `Backend` wraps one loaded library handle. The product uses `default_backend()` (libfgs_hip.so); the test-suite also
+builds one around the CPU simulation library to exercise this exact code path without a GPU.
+Mirrors what the reference does in C++ in rasterization_api.cu:13-247 and utils/torch_utils.h:6-12.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Sequence
+
+import torch
+
+from . import _lib
+
+
+class RasterizerSettings(NamedTuple):
+    """Same 13 fields, order and meaning as the reference (torch_bindings/rasterization.py:8-38)."""
+    w2c: torch.Tensor            # affine transformation from model/world space to view space (row-major, >= 3 rows)
+    cam_position: torch.Tensor   # camera position in world space
+    bg_color: torch.Tensor       # background colour (RGB)
+    active_sh_bases: int         # number of SH bases used for colour
+    width: int                   # image width in pixels
+    height: int                  # image height in pixels
+    focal_x: float               # focal length in pixels
+    focal_y: float
+    center_x: float              # principal point in pixels, +x right
+    center_y: float              # +y down
+    near_plane: float
+    far_plane: float
+    proper_antialiasing: bool
+
+    def as_tuple(self) -> tuple:
+        return tuple(self)
+
+
+class ForwardResult(NamedTuple):
+    image: torch.Tensor
+    buffers: tuple          # (primitive, tile, instance, bucket) uint8 tensors, opaque
+    state: tuple            # (n_visible, n_instances, n_buckets, selector), opaque
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream_of(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+
+
+class Backend:
+    def __init__(self, lib: C.CDLL):
+        self.lib = lib
+
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _check(self, status: int, what: str) -> None:
+        if status != 0:
+            raise RuntimeError(f'{what} failed (status {status}): {self.lib.fgs_last_error().decode()}')
+
+    @staticmethod
+    def _settings(s: RasterizerSettings, total_sh_rest: int, device: torch.device, keep: list) -> _lib.Settings:
+        w2c = s.w2c.to(device=device, dtype=torch.float32).contiguous()
+        cam = s.cam_position.to(device=device, dtype=torch.float32).contiguous()
+        bg = s.bg_color.to(device=device, dtype=torch.float32).contiguous()
+        if w2c.numel() < 12 or cam.numel() < 3 or bg.numel() < 3:
+            raise ValueError('w2c needs >= 3x4, cam_position and bg_color 3 entries')
+        keep += [w2c, cam, bg]
+        return _lib.Settings(w2c.data_ptr(), cam.data_ptr(), bg.data_ptr(), int(s.active_sh_bases), int(total_sh_rest),
+                             int(s.width), int(s.height), float(s.focal_x), float(s.focal_y), float(s.center_x),
+                             float(s.center_y), float(s.near_plane), float(s.far_plane), int(bool(s.proper_antialiasing)))
+
+    @staticmethod
+    def _check_params(tensors: Sequence[torch.Tensor], names: Sequence[str]) -> torch.device:
+        device = tensors[0].device
+        for t, n in zip(tensors, names):   # utils/torch_utils.h:14-19 (CHECK_INPUT)
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+                raise RuntimeError(f"Input tensor '{n}' must be a contiguous float32 tensor on {device}.")
+        return device
+
+    @staticmethod
+    def _make_resizer(device: torch.device, n_buffers: int):
+        buffers = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+
+        def resize(_user, which, nbytes):          # utils/torch_utils.h:6-12
+            try:
+                buffers[which].resize_(int(nbytes))
+                return buffers[which].data_ptr() if nbytes else 0
+            except Exception:                       # never let an exception cross the C boundary
+                return 0
+        return buffers, _lib.RESIZE_FN(resize)
+
+    # -- entry points -----------------------------------------------------------------------------------------------
+    def forward(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings) -> ForwardResult:
+        device = self._check_params((means, scales, rotations, opacities, sh0, sh_rest),
+                                    ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest'))
+        keep: list = []
+        S = self._settings(settings, sh_rest.shape[1] if sh_rest.dim() == 3 else 0, device, keep)
+        image = torch.empty((3, settings.height, settings.width), dtype=torch.float32, device=device)
+        buffers, cb = self._make_resizer(device, 4)
+        st = _lib.ForwardState()
+        self._check(self.lib.fgs_forward(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest),
+                                         means.shape[0], C.byref(S), image.data_ptr(), cb, None, C.byref(st), _stream_of(device)),
+                    'fgs_forward')
+        return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
+
+    def inference(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings, to_chw: bool,
+                  clamp_output: bool, return_state: bool = False):
+        device = self._check_params((means, scales, rotations, opacities, sh0, sh_rest),
+                                    ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest'))
+        keep: list = []
+        S = self._settings(settings, sh_rest.shape[1] if sh_rest.dim() == 3 else 0, device, keep)
+        shape = (3, settings.height, settings.width) if to_chw else (settings.height, settings.width, 3)
+        image = torch.empty(shape, dtype=torch.float32, device=device)
+        buffers, cb = self._make_resizer(device, 4)
+        st = _lib.ForwardState()
+        self._check(self.lib.fgs_inference(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest),
+                                           means.shape[0], C.byref(S), image.data_ptr(), int(to_chw), int(clamp_output), cb, None,
+                                           C.byref(st), _stream_of(device)), 'fgs_inference')
+        if return_state:
+            return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
+        return image
+
+    def _scratch(self, n: int, settings: RasterizerSettings, device: torch.device) -> torch.Tensor:
+        nbytes = int(self.lib.fgs_backward_scratch_bytes(n, int(settings.width), int(settings.height)))
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+
+    def backward(self, densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest, buffers, settings,
+                 state) -> tuple:
+        device = self._check_params((means, scales, rotations, opacities, sh_rest), ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_rest'))
+        keep: list = []
+        n = means.shape[0]
+        total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
+        S = self._settings(settings, total_rest, device, keep)
+        grad_image = grad_image.to(dtype=torch.float32).contiguous()
+        grads = (torch.empty((n, 3), dtype=torch.float32, device=device), torch.empty((n, 3), dtype=torch.float32, device=device),
+                 torch.empty((n, 4), dtype=torch.float32, device=device), torch.empty((n, 1), dtype=torch.float32, device=device),
+                 torch.empty((n, 1, 3), dtype=torch.float32, device=device), torch.empty((n, total_rest, 3), dtype=torch.float32, device=device))
+        dens = densification_info if densification_info is not None and densification_info.numel() > 0 else None   # api:136
+        if dens is not None and (dens.dtype != torch.float32 or not dens.is_contiguous() or dens.device != device or dens.numel() != 2 * n):
+            raise RuntimeError('densification_info must be a contiguous float32 [2, N] tensor on the parameters\' device')
+        scratch = self._scratch(n, settings, device)
+        st = _lib.ForwardState(*state)
+        self._check(self.lib.fgs_backward(_ptr(grad_image), _ptr(image), _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                          _ptr(sh_rest), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]), _ptr(buffers[3]),
+                                          _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), _ptr(grads[3]), _ptr(grads[4]), _ptr(grads[5]),
+                                          _ptr(dens), scratch.data_ptr(), n, C.byref(S), C.byref(st), _stream_of(device)), 'fgs_backward')
+        return grads
+
+    def backward_adam_fused(self, densification_info, grad_image, image, params: Sequence[torch.Tensor], exp_avgs, exp_avg_sqs,
+                            buffers, settings, state, step: int, lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15) -> None:
+        """params / moments / lrs in optimizer-group order: means, sh0, sh_rest, opacities, scales, rotations (Model.py:238-245)."""
+        device = self._check_params(tuple(params) + tuple(exp_avgs) + tuple(exp_avg_sqs), ['param/moment'] * 18)
+        keep: list = []
+        n = params[0].shape[0]
+        total_rest = params[2].shape[1] if params[2].dim() == 3 else 0
+        S = self._settings(settings, total_rest, device, keep)
+        grad_image = grad_image.to(dtype=torch.float32).contiguous()
+        dens = densification_info if densification_info is not None and densification_info.numel() > 0 else None
+        scratch = self._scratch(n, settings, device)
+        st = _lib.ForwardState(*state)
+        arr = lambda ts: (C.c_void_p * 6)(*[_ptr(t) for t in ts])
+        lr_arr = (C.c_double * 6)(*[float(x) for x in lrs])
+        self._check(self.lib.fgs_backward_adam_fused(_ptr(grad_image), _ptr(image), arr(params), arr(exp_avgs), arr(exp_avg_sqs),
+                                                     _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]), _ptr(buffers[3]), _ptr(dens),
+                                                     scratch.data_ptr(), n, C.byref(S), C.byref(st), int(step), lr_arr,
+                                                     float(betas[0]), float(betas[1]), float(eps), _stream_of(device)),
+                    'fgs_backward_adam_fused')
+
+    def adam_step(self, grad, param, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float, beta2: float, eps: float) -> None:
+        device = self._check_params((grad, param, exp_avg, exp_avg_sq), ('param_grad', 'param', 'exp_avg', 'exp_avg_sq'))
+        self._check(self.lib.fgs_adam_step(_ptr(grad), _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step),
+                                           float(lr), float(beta1), float(beta2), float(eps), _stream_of(device)), 'fgs_adam_step')
+
+    def adam_step_multi(self, grads, params, exp_avgs, exp_avg_sqs, steps, lrs, beta1: float, beta2: float, eps: float) -> None:
+        k = len(params)
+        if k == 0:
+            return
+        device = self._check_params(tuple(grads) + tuple(params) + tuple(exp_avgs) + tuple(exp_avg_sqs), ['adam tensor'] * (4 * k))
+        arr = lambda ts: (C.c_void_p * k)(*[_ptr(t) for t in ts])
+        self._check(self.lib.fgs_adam_step_multi(k, arr(grads), arr(params), arr(exp_avgs), arr(exp_avg_sqs),
+                                                 (C.c_int64 * k)(*[p.numel() for p in params]), (C.c_int32 * k)(*[int(s) for s in steps]),
+                                                 (C.c_double * k)(*[float(x) for x in lrs]), float(beta1), float(beta2), float(eps),
+                                                 _stream_of(device)), 'fgs_adam_step_multi')
+
+    # -- introspection (tests / bench only) ------------------------------------------------------------------------------
+    def blob_layout(self, which: int, n: int, width: int, height: int, n_instances: int, n_buckets: int) -> dict:
+        entries = (_lib.BlobEntry * 16)()
+        k = self.lib.fgs_blob_layout(which, n, width, height, n_instances, n_buckets, entries, 16)
+        if k < 0:
+            raise RuntimeError(self.lib.fgs_last_error().decode())
+        return {entries[i].name.decode(): (entries[i].offset, entries[i].bytes) for i in range(k)}
+
+    def view(self, blob: torch.Tensor, layout: dict, name: str, dtype: torch.dtype) -> torch.Tensor:
+        off, nbytes = layout[name]
+        return blob[off:off + nbytes].view(dtype)
+
+
+_DEFAULT: Backend | None = None
+
+
+def default_backend() -> Backend:
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Backend(_lib.library())
+    return _DEFAULT

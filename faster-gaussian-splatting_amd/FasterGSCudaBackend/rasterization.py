@@ -1,0 +1,60 @@
+"""Operator surface of the rasterizer: diff_rasterize / rasterize / RasterizerSettings.
+
+Names, argument order and semantics follow the reference's torch_bindings/rasterization.py:41-156 so that
+Renderer.py:72-123 runs unmodified against this package; the implementation underneath is libfgs_hip.so through ctypes.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from ._backend import RasterizerSettings, default_backend
+
+
+def _require_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        # Renderer.py:58-59 raises in CPU mode as well; there is no CPU implementation behind this package
+        raise RuntimeError('FasterGS rasterizer: tensors must live on a ROCm/HIP device (no CPU implementation)')
+
+
+class _Rasterize(torch.autograd.Function):
+    """Differentiable w.r.t. the six parameter tensors (rasterization.py:41-110 of the reference)."""
+
+    @staticmethod
+    def forward(ctx: Any, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, densification_info,
+                rasterizer_settings: RasterizerSettings) -> torch.Tensor:
+        _require_gpu(means)
+        res = default_backend().forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings)
+        ctx.rasterizer_settings = rasterizer_settings
+        ctx.buffer_state = res.state
+        ctx.save_for_backward(res.image, means, scales, rotations, opacities, sh_coefficients_rest, *res.buffers)
+        ctx.densification_info = densification_info
+        ctx.mark_non_differentiable(densification_info)
+        return res.image
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx: Any, grad_image: torch.Tensor):
+        image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
+        grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
+                                           buffers, ctx.rasterizer_settings, ctx.buffer_state)
+        return (*grads, None, None)   # densification_info, rasterizer_settings
+
+
+def diff_rasterize(means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor, opacities: torch.Tensor,
+                   sh_coefficients_0: torch.Tensor, sh_coefficients_rest: torch.Tensor, densification_info: torch.Tensor,
+                   rasterizer_settings: RasterizerSettings) -> torch.Tensor:
+    """Training render: image [3,H,W]; densification_info [2,N] is updated in backward, or pass torch.empty(0)."""
+    return _Rasterize.apply(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, densification_info,
+                            rasterizer_settings)
+
+
+def rasterize(means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor, opacities: torch.Tensor,
+              sh_coefficients_0: torch.Tensor, sh_coefficients_rest: torch.Tensor, rasterizer_settings: RasterizerSettings,
+              to_chw: bool, clamp_output: bool = True) -> torch.Tensor:
+    """Forward-only render (the reference's benchmark path, Renderer.py:107-123): [3,H,W] or [H,W,3]."""
+    _require_gpu(means)
+    return default_backend().inference(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest,
+                                       rasterizer_settings, to_chw, clamp_output)

@@ -1,0 +1,455 @@
+// C-ABI entry points of libfgs_hip.so (declared in include/fgs_hip.h) and the host-side orchestration of the pipeline.
+// Replaces the reference's C++ wrappers + host code: rasterization_api.cu:13-247, rasterization/src/forward.cu:11-259,
+// backward.cu:8-125, inference.cu:11-226, adam/src/adam.cu:36-71.
+//
+// Host-side differences that are deliberate (MI355X-first), not omissions:
+//  * every launch goes to the caller's hipStream_t (the reference uses the legacy default stream + a static side stream);
+//  * ONE device->host read per forward (n_visible, n_instances through pinned memory) instead of three blocking copies:
+//    the bucket buffer is sized by the bound B <= I/64 + min(T, I) and kernels read the exact bucket count on the device;
+//  * no zero-fill of the 59-float gradients (the backward kernels write every element), only the 9-float atomic
+//    accumulators are cleared.
+#include <fgs_hip.h>
+#include "fgs_kernels.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+
+using namespace fgs;
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define FGS_HIP(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(FGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+// bu:10-18
+int extract_end_bit(uint32_t n) {
+    if (n == 0) return 1;             // the reference's bit-twiddling version yields 1 for a single tile
+    int bits = 0;
+    while (n != 0) { ++bits; n >>= 1; }
+    return bits;
+}
+
+struct Carver {                       // 256-byte aligned bump allocation inside a caller-owned byte buffer (cf. bu:30-36)
+    char* base; size_t off = 0;
+    fgs_blob_entry* entries; int max_entries; int n = 0;
+    explicit Carver(void* b, fgs_blob_entry* e = nullptr, int m = 0) : base(static_cast<char*>(b)), entries(e), max_entries(m) {}
+    template <typename T> T* take(const char* name, size_t count) {
+        off = (off + 255) & ~static_cast<size_t>(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        if (entries && n < max_entries) { entries[n].name = name; entries[n].offset = off; entries[n].bytes = count * sizeof(T); }
+        ++n;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return (off + 255) & ~static_cast<size_t>(255); }
+};
+
+struct Geometry { uint32_t grid_w, grid_h, n_tiles; int end_bit, key_bytes; };
+Geometry geometry_of(int width, int height) {
+    Geometry g;
+    g.grid_w = (width + kTileW - 1) / kTileW;
+    g.grid_h = (height + kTileH - 1) / kTileH;
+    g.n_tiles = g.grid_w * g.grid_h;
+    g.end_bit = extract_end_bit(g.n_tiles - 1);          // fwd:42
+    g.key_bytes = g.end_bit <= 16 ? 2 : 4;                // fwd:152-153
+    return g;
+}
+
+struct PrimitiveBuffers {             // cf. bu:45-94
+    PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters;
+    char* temp; size_t temp_bytes;
+    static PrimitiveBuffers carve(Carver& c, uint32_t n) {
+        PrimitiveBuffers b;
+        b.rec = c.take<PrimRec>("rec", n);
+        b.n_touched = c.take<uint32_t>("n_touched", n);
+        b.keys[0] = c.take<uint32_t>("depth_keys0", n); b.keys[1] = c.take<uint32_t>("depth_keys1", n);
+        b.prims[0] = c.take<uint32_t>("prim_idx0", n); b.prims[1] = c.take<uint32_t>("prim_idx1", n);
+        b.offsets = c.take<uint32_t>("offsets", n);
+        b.counters = c.take<uint32_t>("counters", 4);
+        b.temp_bytes = depth_sort_temp_bytes(n);
+        b.temp = c.take<char>("sort_temp", b.temp_bytes);
+        return b;
+    }
+};
+struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed are tile-major here
+    uint2* ranges; uint32_t* bucket_offsets; uint32_t* max_n_processed; float* final_T; uint32_t* n_processed;
+    char* temp; size_t temp_bytes;
+    static TileBuffers carve(Carver& c, uint32_t t, bool training) {
+        TileBuffers b{};
+        b.ranges = c.take<uint2>("ranges", t);
+        if (training) {
+            b.bucket_offsets = c.take<uint32_t>("bucket_offsets", t);
+            b.max_n_processed = c.take<uint32_t>("max_n_processed", t);
+            b.final_T = c.take<float>("final_T", (size_t)t * kTilePixels);
+            b.n_processed = c.take<uint32_t>("n_processed", (size_t)t * kTilePixels);
+            b.temp_bytes = bucket_scan_temp_bytes(t);
+            b.temp = c.take<char>("scan_temp", b.temp_bytes);
+        }
+        return b;
+    }
+};
+struct InstanceBuffers {              // cf. bu:96-124
+    void* keys[2]; uint32_t* prims[2]; char* temp; size_t temp_bytes;
+    static InstanceBuffers carve(Carver& c, uint32_t n, int key_bytes, int end_bit) {
+        InstanceBuffers b;
+        b.keys[0] = c.take<char>("keys0", (size_t)n * key_bytes); b.keys[1] = c.take<char>("keys1", (size_t)n * key_bytes);
+        b.prims[0] = c.take<uint32_t>("prims0", n); b.prims[1] = c.take<uint32_t>("prims1", n);
+        b.temp_bytes = tile_sort_temp_bytes(n, key_bytes, end_bit);
+        b.temp = c.take<char>("sort_temp", b.temp_bytes);
+        return b;
+    }
+};
+struct BucketBuffers {                // cf. bu:154-163
+    uint32_t* tile_index; float4* ckpt;
+    static BucketBuffers carve(Carver& c, uint32_t n) {
+        BucketBuffers b;
+        b.tile_index = c.take<uint32_t>("tile_index", n);
+        b.ckpt = c.take<float4>("ckpt", (size_t)n * kTilePixels);
+        return b;
+    }
+};
+struct BackwardScratch {
+    float* acc; float* view_dir; float4* pixrec;
+    static BackwardScratch carve(Carver& c, uint32_t n, uint32_t t) {
+        BackwardScratch b;
+        b.acc = c.take<float>("acc", (size_t)n * 9);
+        b.view_dir = c.take<float>("view_dir", (size_t)n * 3);
+        b.pixrec = c.take<float4>("pixrec", (size_t)t * kTilePixels * 2);
+        return b;
+    }
+};
+
+uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
+    return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
+}
+
+CameraArgs camera_of(const fgs_settings& s, const Geometry& g) {
+    CameraArgs c;
+    c.w2c = s.w2c; c.cam_pos = s.cam_position;
+    c.width = static_cast<float>(s.width); c.height = static_cast<float>(s.height);   // fwd:82-83
+    c.fx = s.focal_x; c.fy = s.focal_y; c.cx = s.center_x; c.cy = s.center_y;
+    c.near_plane = s.near_plane; c.far_plane = s.far_plane; c.proper_aa = s.proper_antialiasing ? 1 : 0;
+    c.active_sh_bases = s.active_sh_bases; c.total_sh_rest = s.total_sh_bases_rest;
+    c.grid_w = g.grid_w; c.grid_h = g.grid_h;
+    return c;
+}
+
+int check_settings(const fgs_settings* s) {
+    if (!s) return fail(FGS_ERR_INVALID_ARGUMENT, "settings is NULL");
+    if (!s->w2c || !s->cam_position || !s->bg_color) return fail(FGS_ERR_INVALID_ARGUMENT, "w2c / cam_position / bg_color must be device pointers");
+    if (s->width <= 0 || s->height <= 0) return fail(FGS_ERR_INVALID_ARGUMENT, "image size %dx%d", s->width, s->height);
+    if (s->active_sh_bases < 1 || s->active_sh_bases > 16) return fail(FGS_ERR_INVALID_ARGUMENT, "active_sh_bases %d", s->active_sh_bases);
+    if (s->total_sh_bases_rest < 0 || (s->active_sh_bases > 1 && s->total_sh_bases_rest < s->active_sh_bases - 1))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "sh_coefficients_rest has %d bases, active_sh_bases %d", s->total_sh_bases_rest, s->active_sh_bases);
+    return FGS_OK;
+}
+
+uint32_t* pinned_counters() {          // 16 bytes of pinned host memory per host thread for the one D2H read
+    thread_local uint32_t* p = nullptr;
+    if (!p && hipHostMalloc(reinterpret_cast<void**>(&p), 16, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    return p;
+}
+
+AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps) {   // adam.cu:52-54
+    const double bc1_rcp = 1.0 / (1.0 - std::pow(beta1, step));
+    const double bc2_sqrt_rcp = 1.0 / std::sqrt(1.0 - std::pow(beta2, step));
+    AdamHyper h;
+    h.step_size = static_cast<float>(lr * bc1_rcp);
+    h.beta1 = static_cast<float>(beta1); h.beta2 = static_cast<float>(beta2); h.eps = static_cast<float>(eps);
+    h.bc2_sqrt_rcp = static_cast<float>(bc2_sqrt_rcp);
+    return h;
+}
+
+// shared by fgs_forward (training) and fgs_inference
+int run_forward(bool training, const float* means, const float* scales, const float* rotations, const float* opacities,
+                const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
+                int to_chw, int clamp_output, fgs_resize_fn resize, void* user, fgs_forward_state* state_out, void* stream_) {
+    if (int rc = check_settings(settings)) return rc;
+    if (n_primitives < 0 || !image || !resize || !state_out) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_primitives=%d)", n_primitives);
+    if (n_primitives > 0 && (!means || !scales || !rotations || !opacities || !sh0 || (settings->total_sh_bases_rest > 0 && !sh_rest)))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint32_t n = static_cast<uint32_t>(n_primitives);
+    const Geometry geo = geometry_of(settings->width, settings->height);
+
+    // tile buffers + K0 (fwd:44-55)
+    Carver tile_size(nullptr);
+    TileBuffers::carve(tile_size, geo.n_tiles, training);
+    void* tile_blob = resize(user, FGS_BUF_TILE, tile_size.total());
+    if (!tile_blob && tile_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(tile, %zu) returned NULL", tile_size.total());
+    Carver tile_c(tile_blob);
+    TileBuffers tb = TileBuffers::carve(tile_c, geo.n_tiles, training);
+    FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));
+
+    // primitive buffers + K1 (fwd:58-98)
+    Carver prim_size(nullptr);
+    PrimitiveBuffers::carve(prim_size, n);
+    void* prim_blob = resize(user, FGS_BUF_PRIMITIVE, prim_size.total());
+    if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
+    Carver prim_c(prim_blob);
+    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
+    FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
+    PreprocessArgs pa;
+    pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
+    pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters;
+    pa.n = n; pa.cam = camera_of(*settings, geo);
+    FGS_HIP(launch_preprocess(!training, pa, stream));
+
+    // the one host read of the pass: V and I (fwd:99-102)
+    uint32_t* host = pinned_counters();
+    if (!host) return fail(FGS_ERR_HIP, "hipHostMalloc for the counter read-back failed");
+    FGS_HIP(hipMemcpyAsync(host, pb.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FGS_HIP(hipStreamSynchronize(stream));
+    const uint32_t n_visible = host[0], n_instances = host[1];
+
+    // K2-K4 (fwd:104-127)
+    int depth_sel = 0;
+    FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream));
+    const uint32_t* sorted_prims = pb.prims[depth_sel];
+    FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.rec, pb.offsets, n_visible, stream));
+
+    // K5-K7 (fwd:179-216)
+    Carver inst_size(nullptr);
+    InstanceBuffers::carve(inst_size, n_instances, geo.key_bytes, geo.end_bit);
+    void* inst_blob = resize(user, FGS_BUF_INSTANCE, inst_size.total());
+    if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
+    Carver inst_c(inst_blob);
+    InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
+    FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible, stream));
+    int tile_sel = 0;
+    FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, geo.end_bit, stream));
+    // the key double buffer flips together with the value double buffer
+    FGS_HIP(launch_extract_ranges(geo.key_bytes, ib.keys[tile_sel], tb.ranges, n_instances, stream));
+
+    BlendArgs ba{};
+    ba.ranges = tb.ranges; ba.inst_prims = ib.prims[tile_sel]; ba.rec = pb.rec; ba.bg = settings->bg_color; ba.image = image;
+    ba.width = settings->width; ba.height = settings->height; ba.grid_w = geo.grid_w; ba.n_tiles = geo.n_tiles;
+    ba.to_chw = to_chw; ba.clamp_output = clamp_output;
+    uint32_t n_buckets_cap = 0;
+    if (training) {
+        // K8+K9 (fwd:218-231) and the bucket buffer sized by its bound (no read-back of n_buckets, fwd:234)
+        FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));
+        n_buckets_cap = bucket_capacity(n_instances, geo.n_tiles);
+        Carver bucket_size(nullptr);
+        BucketBuffers::carve(bucket_size, n_buckets_cap);
+        void* bucket_blob = resize(user, FGS_BUF_BUCKET, bucket_size.total());
+        if (!bucket_blob && bucket_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(bucket, %zu) returned NULL", bucket_size.total());
+        Carver bucket_c(bucket_blob);
+        BucketBuffers bb = BucketBuffers::carve(bucket_c, n_buckets_cap);
+        ba.bucket_offsets = tb.bucket_offsets; ba.final_T = tb.final_T; ba.n_processed = tb.n_processed;
+        ba.max_n_processed = tb.max_n_processed; ba.bucket_tile = bb.tile_index; ba.ckpt = bb.ckpt;
+    }
+    FGS_HIP(launch_blend(training, ba, stream));                                          // K10 (fwd:239)
+
+    state_out->n_visible = static_cast<int32_t>(n_visible);
+    state_out->n_instances = static_cast<int32_t>(n_instances);
+    state_out->n_buckets = static_cast<int32_t>(n_buckets_cap);
+    state_out->selector = tile_sel;
+    return FGS_OK;
+}
+
+struct BackwardPlan {
+    Geometry geo; PrimitiveBuffers pb; TileBuffers tb; InstanceBuffers ib; BucketBuffers bb; BackwardScratch sc;
+};
+
+int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_blob, void* bucket_blob, void* scratch,
+                  int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state) {
+    if (int rc = check_settings(settings)) return rc;
+    if (!state || n_primitives < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad state / n_primitives");
+    if (!prim_blob || !tile_blob || !scratch || (state->n_instances > 0 && !inst_blob) || (state->n_buckets > 0 && !bucket_blob))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL scratch buffer");
+    P.geo = geometry_of(settings->width, settings->height);
+    Carver pc(prim_blob), tc(tile_blob), ic(inst_blob), bc(bucket_blob), sc(scratch);   // same carve order as the forward pass (bwd:46-52)
+    P.pb = PrimitiveBuffers::carve(pc, static_cast<uint32_t>(n_primitives));
+    P.tb = TileBuffers::carve(tc, P.geo.n_tiles, true);
+    P.ib = InstanceBuffers::carve(ic, static_cast<uint32_t>(state->n_instances), P.geo.key_bytes, P.geo.end_bit);
+    P.bb = BucketBuffers::carve(bc, static_cast<uint32_t>(state->n_buckets));
+    P.sc = BackwardScratch::carve(sc, static_cast<uint32_t>(n_primitives), P.geo.n_tiles);
+    return FGS_OK;
+}
+
+int run_blend_backward(const BackwardPlan& P, const float* grad_image, const float* image, int32_t n_primitives,
+                       const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream) {
+    if (n_primitives > 0) FGS_HIP(hipMemsetAsync(P.sc.acc, 0, sizeof(float) * 9 * (size_t)n_primitives, stream));   // replaces api:127-134
+    BlendBackwardArgs a{};
+    a.ranges = P.tb.ranges; a.bucket_offsets = P.tb.bucket_offsets; a.inst_prims = P.ib.prims[state->selector]; a.rec = P.pb.rec;
+    a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
+    a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
+    a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
+    a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
+    a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
+    a.proper_aa = settings->proper_antialiasing ? 1 : 0;
+    FGS_HIP(launch_blend_backward(a, stream));                                                 // K11 (bwd:56)
+    return FGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int32_t fgs_abi_version(void) { return FGS_ABI_VERSION; }
+const char* fgs_last_error(void) { return g_error; }
+const char* fgs_build_info(void) { return "libfgs_hip gfx950 wave64 tile16x12 bucket64 rocprim-sort"; }
+
+int32_t fgs_forward(const float* means, const float* scales, const float* rotations, const float* opacities,
+                    const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                    const fgs_settings* settings, float* image, fgs_resize_fn resize, void* resize_user,
+                    fgs_forward_state* state_out, void* stream) {
+    return run_forward(true, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+                       image, 1, 0, resize, resize_user, state_out, stream);
+}
+
+int32_t fgs_inference(const float* means, const float* scales, const float* rotations, const float* opacities,
+                      const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                      const fgs_settings* settings, float* image, int32_t to_chw, int32_t clamp_output,
+                      fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream) {
+    return run_forward(false, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+                       image, to_chw, clamp_output, resize, resize_user, state_out, stream);
+}
+
+size_t fgs_backward_scratch_bytes(int32_t n_primitives, int32_t width, int32_t height) {
+    if (n_primitives < 0 || width <= 0 || height <= 0) return 0;
+    Carver c(nullptr);
+    BackwardScratch::carve(c, static_cast<uint32_t>(n_primitives), geometry_of(width, height).n_tiles);
+    return c.total();
+}
+
+int32_t fgs_backward(const float* grad_image, const float* image,
+                     const float* means, const float* scales, const float* rotations, const float* opacities,
+                     const float* sh_coefficients_rest,
+                     void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                     float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                     float* densification_info, void* scratch,
+                     int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
+    BackwardPlan P;
+    if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_primitives, settings, state)) return rc;
+    if (!grad_image || !image) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL image / grad_image");
+    if (n_primitives == 0) return FGS_OK;
+    if (!means || !scales || !rotations || !opacities || !grad_means || !grad_scales || !grad_rotations || !grad_opacities || !grad_sh_coefficients_0)
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter / gradient tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = run_blend_backward(P, grad_image, image, n_primitives, settings, state, stream)) return rc;
+
+    PreprocessBackwardArgs a{};
+    a.means = means; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.sh_rest = sh_coefficients_rest;
+    a.n_touched = P.pb.n_touched; a.acc = P.sc.acc; a.view_dir = P.sc.view_dir;
+    a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
+    a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
+    a.n = static_cast<uint32_t>(n_primitives); a.cam = camera_of(*settings, P.geo);
+    FGS_HIP(launch_preprocess_backward(false, a, stream));                                     // K12 (bwd:94)
+    if (settings->total_sh_bases_rest > 0) {
+        if (!grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
+        ShRestArgs s{};
+        s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc; s.grad_sh_rest = grad_sh_coefficients_rest;
+        s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
+        FGS_HIP(launch_sh_rest_backward(false, s, stream));
+    }
+    return FGS_OK;
+}
+
+int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
+                                float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                float* densification_info, void* scratch,
+                                int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state,
+                                int32_t step, const double* lrs, double beta1, double beta2, double eps, void* stream_) {
+    BackwardPlan P;
+    if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_primitives, settings, state)) return rc;
+    if (!grad_image || !image || !params || !exp_avgs || !exp_avg_sqs || !lrs || step < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n_primitives == 0) return FGS_OK;
+    for (int k = 0; k < 6; ++k)
+        if (!params[k] || !exp_avgs[k] || !exp_avg_sqs[k]) {
+            if (k == 2 && settings->total_sh_bases_rest == 0) continue;
+            return fail(FGS_ERR_INVALID_ARGUMENT, "NULL tensor in group %d", k);
+        }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = run_blend_backward(P, grad_image, image, n_primitives, settings, state, stream)) return rc;
+
+    // API group order (Model.py:238-245): 0 means, 1 sh0, 2 sh_rest, 3 opacities, 4 scales, 5 rotations
+    PreprocessBackwardArgs a{};
+    a.means = params[0]; a.scales = params[4]; a.rotations = params[5]; a.opacities = params[3]; a.sh_rest = params[2];
+    a.n_touched = P.pb.n_touched; a.acc = P.sc.acc; a.view_dir = P.sc.view_dir; a.densification_info = densification_info;
+    a.n = static_cast<uint32_t>(n_primitives); a.cam = camera_of(*settings, P.geo);
+    const int map[5] = {0, 1, 3, 4, 5};     // kernel group order: means, sh0, opacities, scales, rotations
+    for (int k = 0; k < 5; ++k) {
+        a.p[k] = params[map[k]]; a.m[k] = exp_avgs[map[k]]; a.v[k] = exp_avg_sqs[map[k]];
+        a.h[k] = adam_hyper(step, lrs[map[k]], beta1, beta2, eps);
+    }
+    // The geometry kernel reads sh_rest (pre-update) and leaves the view direction for the SH-rest pass, which then
+    // updates sh_rest in place; means are updated by the geometry kernel after it has taken the direction.
+    FGS_HIP(launch_preprocess_backward(true, a, stream));
+    if (settings->total_sh_bases_rest > 0) {
+        ShRestArgs s{};
+        s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc;
+        s.p = params[2]; s.m = exp_avgs[2]; s.v = exp_avg_sqs[2]; s.h = adam_hyper(step, lrs[2], beta1, beta2, eps);
+        s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
+        FGS_HIP(launch_sh_rest_backward(true, s, stream));
+    }
+    return FGS_OK;
+}
+
+int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
+                            double beta1, double beta2, double eps, void* stream) {
+    if (n_groups < 0 || n_groups > 8) return fail(FGS_ERR_INVALID_ARGUMENT, "n_groups %d (max 8)", n_groups);
+    AdamArgs a{};
+    uint32_t blocks = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (n_elements[k] < 0 || steps[k] < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "group %d: n_elements / step", k);
+        if (n_elements[k] == 0) continue;
+        if (!grads[k] || !params[k] || !exp_avgs[k] || !exp_avg_sqs[k]) return fail(FGS_ERR_INVALID_ARGUMENT, "group %d: NULL tensor", k);
+        AdamGroup& g = a.g[a.n_groups++];
+        g.grad = grads[k]; g.param = params[k]; g.exp_avg = exp_avgs[k]; g.exp_avg_sq = exp_avg_sqs[k]; g.n = n_elements[k];
+        g.h = adam_hyper(steps[k], lrs[k], beta1, beta2, eps);
+        g.first_block = blocks;
+        blocks += static_cast<uint32_t>((n_elements[k] + 1023) / 1024);
+    }
+    a.total_blocks = blocks;
+    FGS_HIP(launch_adam(a, static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
+int32_t fgs_adam_step(const float* grad, float* param, float* exp_avg, float* exp_avg_sq, int64_t n_elements,
+                      int32_t step, double lr, double beta1, double beta2, double eps, void* stream) {
+    return fgs_adam_step_multi(1, &grad, &param, &exp_avg, &exp_avg_sq, &n_elements, &step, &lr, beta1, beta2, eps, stream);
+}
+
+int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int32_t height, int32_t n_instances,
+                        int32_t n_buckets, fgs_blob_entry* entries, int32_t max_entries) {
+    if (width <= 0 || height <= 0 || n_primitives < 0 || n_instances < 0 || n_buckets < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad sizes");
+    const Geometry geo = geometry_of(width, height);
+    Carver c(nullptr, entries, max_entries);
+    switch (which) {
+        case FGS_BUF_PRIMITIVE: PrimitiveBuffers::carve(c, n_primitives); break;
+        case FGS_BUF_TILE: TileBuffers::carve(c, geo.n_tiles, true); break;
+        case FGS_BUF_INSTANCE: InstanceBuffers::carve(c, n_instances, geo.key_bytes, geo.end_bit); break;
+        case FGS_BUF_BUCKET: BucketBuffers::carve(c, n_buckets); break;
+        case FGS_BUF_COUNT: BackwardScratch::carve(c, n_primitives, geo.n_tiles); break;   // the backward scratch buffer
+        default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown buffer %d", which);
+    }
+    return c.n < max_entries ? c.n : max_entries;
+}
+
+int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {
+    if (!out_device_256) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL output");
+    FGS_HIP(launch_wave_selftest(out_device_256, static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,137 @@
+// K10: per-tile front-to-back alpha blending for gfx950 (training variant with per-bucket checkpoints, and the
+// forward-only inference variant). Semantics: reference kernels_forward.cuh:362-498 / kernels_inference.cuh:348-463.
+//
+// CDNA4 shape (not a translation of the 6-warp CUDA block):
+//  * a 16x12 tile is 3 wave64; each wave owns a 16x4 strip = the two 8x4 sub-tiles of the reference side by side
+//    (lanes 0-31 left, 32-63 right). The reference's per-sub-tile bounding-box cull is kept exactly: each lane tests one
+//    of 64 staged Gaussians against BOTH sub-tiles, two 64-bit ballots give the per-half masks, the wave walks the union
+//    with scalar bit ops and each half predicates on its own mask.
+//  * Gaussians are staged 192 at a time through LDS from ONE 48-byte record per primitive (3 x 16-B loads from one line).
+//  * checkpoints are written every kBucket=64 Gaussians (one backward wavefront) -- half the reference's checkpoint
+//    traffic -- 1 KiB contiguous per wave; T_final / n_processed are tile-major so backward reads them coalesced.
+//  * workgroup -> tile mapping keeps contiguous image bands on one XCD (workgroup b runs on XCD b % 8), so the
+//    records gathered by neighbouring tiles stay in that XCD's 4 MiB L2.
+#include "fgs_kernels.h"
+#include <fgs_wave.h>
+
+namespace fgs {
+
+template <bool TRAINING>
+__global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
+    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
+    const unsigned tile = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (tile >= a.n_tiles) return;
+    const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
+    const unsigned lx = half * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
+    const unsigned px = tile_x * kTileW + lx, py = tile_y * kTileH + ly;
+    const bool inside = px < a.width && py < a.height;
+    const unsigned local = ly * kTileW + lx;
+    const float pxf = static_cast<float>(px) + 0.5f, pyf = static_cast<float>(py) + 0.5f;
+    // sub-tile rectangles of this wave (kf:389-398)
+    const unsigned sub_y0 = tile_y * kTileH + wave * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
+    const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
+
+    const uint2 range = a.ranges[tile];
+    const unsigned n_total = range.y - range.x;
+    unsigned bucket_base = 0;
+    if (TRAINING) {
+        bucket_base = tile == 0 ? 0u : a.bucket_offsets[tile - 1];
+        const unsigned nb = (n_total + kBucket - 1) / kBucket;
+        for (unsigned b = tid; b < nb; b += kBlendBlock) a.bucket_tile[bucket_base + b] = tile;   // kf:407-411
+    }
+
+    __shared__ float4 s_a[kBlendBlock];   // mean.x mean.y conic.a conic.b
+    __shared__ float4 s_b[kBlendBlock];   // conic.c opacity r g
+    __shared__ float4 s_c[kBlendBlock];   // b bounds_x bounds_y -
+    __shared__ unsigned s_max[kBlendBlock / kWave];
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;
+    unsigned n_used = 0;
+    bool done = !inside;
+
+    for (unsigned batch_start = 0; batch_start < n_total; batch_start += kBlendBlock) {
+        if (__syncthreads_and(done ? 1 : 0)) break;                                    // kf:424
+        const unsigned batch = min(static_cast<unsigned>(kBlendBlock), n_total - batch_start);
+        if (tid < batch) {
+            const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
+            const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            s_a[tid] = r0;
+            if (TRAINING) {                                                            // kf:430 (inference clamps at store, ki:200)
+                s_b[tid] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
+                s_c[tid] = make_float4(fmaxf(r2.x, 0.0f), r2.y, r2.z, 0.0f);
+            } else {
+                s_b[tid] = r1;
+                s_c[tid] = r2;
+            }
+        }
+        __syncthreads();
+        for (unsigned chunk = 0; chunk < batch; chunk += kBucket) {
+            if (TRAINING && !done)                                                     // kf:436-442, every 64 instead of 32
+                a.ckpt[(size_t)(bucket_base + (batch_start + chunk) / kBucket) * kTilePixels + local] = make_float4(cr, cg, cb, T);
+            bool in_l = false, in_r = false;
+            const unsigned j = chunk + lane;
+            if (j < batch) {                                                           // kf:445-450
+                const uint32_t bx = __float_as_uint(s_c[j].y), by = __float_as_uint(s_c[j].z);
+                const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
+                const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
+                in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
+                in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
+            }
+            const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
+            const uint64_t mine = half ? mask_r : mask_l;
+            uint64_t pending = mask_l | mask_r;
+            if (wave_ballot(!done) == 0) pending = 0;
+            while (pending != 0) {                                                     // wave-uniform scalar loop
+                const int k = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+                pending &= pending - 1;
+                if (done || !((mine >> k) & 1ull)) continue;
+                const unsigned jj = chunk + static_cast<unsigned>(k);
+                const float4 ga = s_a[jj], gb = s_b[jj];
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                const float gauss = __expf(fminf(power, 0.0f));
+                const float alpha = gb.y * gauss;
+                if (alpha < kMinAlphaThreshold) continue;
+                const float w = T * alpha;
+                cr += w * gb.z; cg += w * gb.w; cb += w * s_c[jj].x;
+                T *= 1.0f - alpha;
+                n_used = batch_start + jj + 1;                                         // kf:474
+                if (T < kTransmittanceThreshold) done = true;                          // kf:477
+            }
+        }
+    }
+
+    if (inside) {
+        cr += T * a.bg[0]; cg += T * a.bg[1]; cb += T * a.bg[2];                      // kf:483
+        const size_t pix = (size_t)a.width * py + px;
+        const size_t n_pixels = (size_t)a.width * a.height;
+        if (TRAINING) {
+            a.image[pix] = cr; a.image[n_pixels + pix] = cg; a.image[2 * n_pixels + pix] = cb;
+        } else {
+            if (a.clamp_output) { cr = saturate_f(cr); cg = saturate_f(cg); cb = saturate_f(cb); }   // ki:445-449
+            if (a.to_chw) { a.image[pix] = cr; a.image[n_pixels + pix] = cg; a.image[2 * n_pixels + pix] = cb; }
+            else { a.image[3 * pix] = cr; a.image[3 * pix + 1] = cg; a.image[3 * pix + 2] = cb; }
+        }
+    }
+    if (TRAINING) {
+        // tile-major (the reference indexes these image-linear, kf:485-491; they are private to the backend)
+        a.final_T[(size_t)tile * kTilePixels + local] = T;
+        a.n_processed[(size_t)tile * kTilePixels + local] = n_used;                    // 0 for pixels outside the image
+        const unsigned wmax = wave_max(n_used);
+        if (lane == 0) s_max[wave] = wmax;
+        __syncthreads();
+        if (tid == 0) a.max_n_processed[tile] = max(s_max[0], max(s_max[1], s_max[2]));   // kf:493-497
+    }
+}
+
+hipError_t launch_blend(bool training, const BlendArgs& a, hipStream_t s) {
+    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
+    const dim3 grid(per_xcd * kXcds), block(kBlendBlock);
+    if (training) hipLaunchKernelGGL(blend_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(blend_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace fgs

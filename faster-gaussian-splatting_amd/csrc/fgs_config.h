@@ -1,0 +1,35 @@
+// Compile-time constants of the gfx950 rasterizer.
+// Rendering constants restate the reference (rasterization/include/rasterization_config.h:8-60); the work-shape
+// constants (wave width, bucket size, block sizes) are chosen for CDNA4 wave64, not translated from warp32.
+#pragma once
+#include <cstdint>
+
+namespace fgs {
+
+// --- rendering constants (must equal the reference, cfg:10-22) ---
+constexpr float kDilation = 0.3f;
+constexpr float kDilationProperAA = 0.1f;
+constexpr float kMinCov2dDeterminant = 1e-6f;
+constexpr float kOneMinusAlphaEps = 1e-6f;
+constexpr float kTransmittanceThreshold = 1e-4f;
+constexpr float kMinAlphaThresholdRcp = 255.0f;
+constexpr float kMinAlphaThreshold = 1.0f / kMinAlphaThresholdRcp;
+
+// --- tiling (cfg:55-60): tile ids / sort keys are only comparable with the reference at 16x12 ---
+constexpr int kTileW = 16;
+constexpr int kTileH = 12;
+constexpr int kTilePixels = kTileW * kTileH;  // 192 = 3 wavefronts
+constexpr int kSubtileW = 8;                  // the reference culls per 8x4 sub-tile (kernels_forward.cuh:445-451);
+constexpr int kSubtileH = 4;                  // one wave64 covers a 16x4 strip = two such sub-tiles
+
+// --- CDNA4 work shapes ---
+constexpr int kWave = 64;
+constexpr int kBucket = 64;            // Gaussians per backward bucket = one wavefront (reference: 32 = one warp)
+constexpr int kSeqTiles = 4;           // candidate tiles tested per lane before the wave cooperates (cfg:54)
+constexpr int kPreprocessBlock = 256;
+constexpr int kInstanceBlock = 256;
+constexpr int kBlendBlock = kTilePixels;       // 3 waves
+constexpr int kBackwardWavesPerBlock = 4;      // 4 buckets per 256-thread block
+constexpr int kXcds = 8;                       // tile -> workgroup mapping keeps image bands on one XCD's L2
+
+}  // namespace fgs

@@ -1,0 +1,93 @@
+// Launch interface between the C-ABI host layer (api.hip) and the gfx950 kernels. One launcher per pipeline stage;
+// stage ids K0..K13 refer to SURVEY.md section 2.1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "fgs_config.h"
+#include "fgs_math.h"
+
+namespace fgs {
+
+struct PreprocessArgs {                 // K1
+    const float* means; const float* scales; const float* rotations; const float* opacities;
+    const float* sh0; const float* sh_rest;
+    PrimRec* rec; uint32_t* n_touched;
+    uint32_t* depth_keys; uint32_t* prim_idx;     // compacted (unsorted) visible list
+    uint32_t* counters;                            // [0] n_visible, [1] n_instances
+    uint32_t n;
+    CameraArgs cam;
+};
+hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s);
+
+// K2-K4: depth sort of the visible list + exclusive scan of per-primitive tile counts in depth order
+size_t depth_sort_temp_bytes(uint32_t n);
+hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
+                          uint32_t n_visible, hipStream_t s);
+hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const PrimRec* rec, uint32_t* offsets,
+                            uint32_t n_visible, hipStream_t s);
+
+// K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.
+size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
+hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const PrimRec* rec,
+                                   void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible, hipStream_t s);
+hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
+                         uint32_t n_instances, int end_bit, hipStream_t s);
+hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, hipStream_t s);
+
+// K8+K9: inclusive scan of ceil(len/kBucket) per tile
+size_t bucket_scan_temp_bytes(uint32_t n_tiles);
+hipError_t run_bucket_scan(void* temp, size_t temp_bytes, const uint2* ranges, uint32_t* bucket_offsets, uint32_t n_tiles, hipStream_t s);
+
+struct BlendArgs {                      // K10 / inference blend
+    const uint2* ranges; const uint32_t* bucket_offsets; const uint32_t* inst_prims; const PrimRec* rec;
+    const float* bg; float* image;
+    float* final_T; uint32_t* n_processed; uint32_t* max_n_processed;     // tile-major [T][192]
+    uint32_t* bucket_tile; float4* ckpt;                                   // [B], [B][192]
+    uint32_t width, height, grid_w, n_tiles;
+    int to_chw, clamp_output;
+};
+hipError_t launch_blend(bool training, const BlendArgs& a, hipStream_t s);
+
+struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
+    const uint2* ranges; const uint32_t* bucket_offsets; const uint32_t* inst_prims; const PrimRec* rec;
+    const float* bg; const float* grad_image; const float* image;
+    const float* final_T; const uint32_t* n_processed; const uint32_t* max_n_processed;
+    const uint32_t* bucket_tile; const float4* ckpt;
+    float4* pixrec;                       // [T][192][2] staged per-pixel constants
+    float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
+    int proper_aa;
+};
+hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);
+
+struct AdamHyper { float step_size, beta1, beta2, eps, bc2_sqrt_rcp; };
+
+struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for the 14 non-SH-rest floats
+    const float* means; const float* scales; const float* rotations; const float* opacities; const float* sh_rest;
+    const uint32_t* n_touched; const float* acc;
+    float* view_dir;                      // [N][3] scratch: unit view direction of visible primitives, consumed by the SH-rest pass
+    float* grad_means; float* grad_scales; float* grad_rotations; float* grad_opacities; float* grad_sh0;
+    float* densification_info;
+    uint32_t n;
+    CameraArgs cam;
+    // fused mode (grad_* unused): parameters and moments updated in place, order means, sh0, opacities, scales, rotations
+    float* p[5]; float* m[5]; float* v[5]; AdamHyper h[5];
+};
+hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s);
+
+struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload, streamed flat and fully coalesced
+    const float* view_dir; const uint32_t* n_touched; const float* acc;
+    float* grad_sh_rest;                  // unfused: [N][K-1][3] written for every primitive
+    float* p; float* m; float* v; AdamHyper h;   // fused
+    uint32_t n; uint32_t total_sh_rest; uint32_t active_sh_bases;
+};
+hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s);
+
+struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
+struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s);   // K13, all groups in one launch
+
+hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
+
+}  // namespace fgs

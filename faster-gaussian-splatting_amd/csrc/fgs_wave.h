@@ -1,0 +1,55 @@
+// Wave64 primitives for gfx950 (CDNA4). Everything cross-lane in the kernels goes through these few functions:
+// 64-bit ballots, v_readlane broadcasts (scalar, no LDS), DPP wave shifts/rotates for the backward pixel pipeline.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace fgs {
+
+__device__ __forceinline__ unsigned lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ unsigned lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
+}
+
+// broadcast from a wave-uniform source lane (v_readlane_b32 -> SGPR)
+__device__ __forceinline__ unsigned wave_read(unsigned v, int src_lane) {
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), src_lane));
+}
+__device__ __forceinline__ float wave_read(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+// One step of the backward pixel pipeline for NV per-pixel values:
+//   feed[]  rotates down by one lane (lane l takes lane l+1, lane 63 takes lane 0)      -- DPP wave_rol:1
+//   state[] shifts up by one lane (lane l takes lane l-1) and lane 0 takes its own feed[] -- DPP wave_shr:1 with
+//           `old` = feed, so the inject costs no extra instruction.
+// Call order inside a step: state first (uses feed before it rotates), then feed.
+template <int NV>
+__device__ __forceinline__ void pipeline_advance(float (&state)[NV], float (&feed)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        state[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(feed[k]), __float_as_int(state[k]),
+                                                              0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+        feed[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(feed[k]), __float_as_int(feed[k]),
+                                                             0x134 /*wave_rol:1*/, 0xf, 0xf, false));
+    }
+}
+
+}  // namespace fgs

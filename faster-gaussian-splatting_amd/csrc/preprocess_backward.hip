@@ -1,0 +1,277 @@
+// K12 (+ optional K13 fusion): per-Gaussian backward of projection / EWA / covariance / quaternion / SH, for gfx950.
+// Semantics: reference kernels_backward.cuh:15-257 + sh_utils.cuh:71-155; the fused mode equals
+// "backward -> FusedAdam.step()" of the reference (torch_bindings/adam.py:11-36, adam/src/adam.cu:10-34).
+//
+// CDNA4 shape -- the per-Gaussian payload is 59 floats of which 45 are sh_coefficients_rest, so the work is split by
+// access pattern instead of by Gaussian:
+//  * geometry kernel: one lane per Gaussian for the 14 "small" floats (means, scales, rotations, opacity, sh0): 12-16 B
+//    per lane per tensor, contiguous across the wave. It also leaves the unit view direction of visible Gaussians in a
+//    12-byte scratch slot.
+//  * SH-rest kernel: one lane per (Gaussian, basis) pair = 12 contiguous bytes, i.e. the [N,15,3] tensors (parameter,
+//    both Adam moments, gradient) are streamed flat and fully coalesced; the gradient basis_k(dir) * dL/dcolour is
+//    recomputed per pair from the 12-byte direction + 12-byte colour gradient (L1/L2 hits shared by 15 lanes) instead of
+//    being gathered with a 180-byte per-lane stride as in the reference.
+//  * every element of every gradient is written (zeros for invisible Gaussians), which replaces the reference's eight
+//    torch::zeros fills (rasterization_api.cu:127-134, 256 B per Gaussian).
+//  * fused mode never materialises the 59-float gradient: Adam is applied in registers. Invisible Gaussians still
+//    decay their moments and move by momentum (reference: dense zero grads, adam.py:16).
+#include "fgs_kernels.h"
+#include <fgs_wave.h>
+
+namespace fgs {
+
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, const float g, const AdamHyper& h) {   // adam.cu:22-33
+    const float gsq = g * g;
+    const float m1 = fmaf(h.beta1, m - g, g);
+    const float m2 = fmaf(h.beta2, v - gsq, gsq);
+    const float denom = sqrtf(m2) * h.bc2_sqrt_rcp + h.eps;
+    p -= h.step_size * m1 / denom;
+    m = m1;
+    v = m2;
+}
+
+template <int W>
+__device__ __forceinline__ void emit(const bool fused, float* grad_out, float* p, float* m, float* v, const AdamHyper& h,
+                                     const size_t idx, const float (&g)[W]) {
+    if (!fused) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) grad_out[idx * W + k] = g[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float pp = p[idx * W + k], mm = m[idx * W + k], vv = v[idx * W + k];
+            adam_update(pp, mm, vv, g[k], h);
+            p[idx * W + k] = pp; m[idx * W + k] = mm; v[idx * W + k] = vv;
+        }
+    }
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kPreprocessBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
+    const unsigned i = blockIdx.x * kPreprocessBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const Camera cam = load_camera(a.cam);
+    const size_t n = a.n;
+    float g_mean[3] = {0.0f, 0.0f, 0.0f}, g_scale[3] = {0.0f, 0.0f, 0.0f}, g_rot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float g_op[1] = {0.0f}, g_sh0[3] = {0.0f, 0.0f, 0.0f};
+
+    if (a.n_touched[i] != 0) {                                                         // kb:45
+        float m[3], s[3], q[4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { m[k] = a.means[3 * (size_t)i + k]; s[k] = a.scales[3 * (size_t)i + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * (size_t)i + k];
+        const float gcol[3] = {a.acc[6 * n + i], a.acc[7 * n + i], a.acc[8 * n + i]};
+
+        // ---- SH backward w.r.t. sh0 and the view direction (sh_utils.cuh:84-153) ----
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_sh0[c] = kC0 * gcol[c];
+        float dpos[3] = {0.0f, 0.0f, 0.0f};
+        const unsigned active = static_cast<unsigned>(cam.active_sh_bases);
+        if (active > 1) {
+            const float xr = m[0] - cam.pos[0], yr = m[1] - cam.pos[1], zr = m[2] - cam.pos[2];
+            const float inv = 1.0f / sqrtf(xr * xr + yr * yr + zr * zr);
+            const float x = xr * inv, y = yr * inv, z = zr * inv;
+            a.view_dir[3 * (size_t)i] = x; a.view_dir[3 * (size_t)i + 1] = y; a.view_dir[3 * (size_t)i + 2] = z;
+            const float* k = a.sh_rest + (size_t)i * cam.total_sh_rest * 3;
+            float gdx[3], gdy[3], gdz[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { gdx[c] = -kC1 * k[6 + c]; gdy[c] = -kC1 * k[0 + c]; gdz[c] = kC1 * k[3 + c]; }
+            if (active > 4) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gdx[c] = gdx[c] + kC2a * y * k[9 + c] - kC2a * z * k[18 + c] + kC2a * x * k[21 + c];
+                    gdy[c] = gdy[c] + kC2a * x * k[9 + c] - kC2a * z * k[12 + c] - kC2a * y * k[21 + c];
+                    gdz[c] = gdz[c] - kC2a * y * k[12 + c] + kC2e * z * k[15 + c] - kC2a * x * k[18 + c];
+                }
+                if (active > 9) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        gdx[c] = gdx[c] - kC3i * xy * k[24 + c] + kC3c * yz * k[27 + c] + (kC3d - kC3e * zz) * k[36 + c]
+                                 + kC3c * xz * k[39 + c] + kC3b * (yy - xx) * k[42 + c];
+                        gdy[c] = gdy[c] + kC3b * (yy - xx) * k[24 + c] + kC3c * xz * k[27 + c] + (kC3d - kC3e * zz) * k[30 + c]
+                                 - kC3c * yz * k[39 + c] + kC3i * xy * k[42 + c];
+                        gdz[c] = gdz[c] + kC3c * xy * k[27 + c] - kC3j * yz * k[30 + c] + (kC3k * zz - kC3g) * k[33 + c]
+                                 - kC3j * xz * k[36 + c] + kC3h * (xx - yy) * k[39 + c];
+                    }
+                }
+            }
+            const float gd0 = gdx[0] * gcol[0] + gdx[1] * gcol[1] + gdx[2] * gcol[2];
+            const float gd1 = gdy[0] * gcol[0] + gdy[1] * gcol[1] + gdy[2] * gcol[2];
+            const float gd2 = gdz[0] * gcol[0] + gdz[1] * gcol[1] + gdz[2] * gcol[2];
+            const float xxr = xr * xr, yyr = yr * yr, zzr = zr * zr, xyr = xr * yr, xzr = xr * zr, yzr = yr * zr;
+            const float nsq = xxr + yyr + zzr;
+            const float sc = 1.0f / sqrtf(nsq * nsq * nsq);
+            dpos[0] = ((yyr + zzr) * gd0 - xyr * gd1 - xzr * gd2) * sc;
+            dpos[1] = (-xyr * gd0 + (xxr + zzr) * gd1 - yzr * gd2) * sc;
+            dpos[2] = (-xzr * gd0 - yzr * gd1 + (xxr + yyr) * gd2) * sc;
+        }
+
+        // ---- EWA backward (kb:57-255) ----
+        Projection P;
+        project_gaussian(cam, m, s, q, P);
+        const float ks = cam.proper_aa ? kDilationProperAA : kDilation;
+        const float ea = P.a_raw + ks, eb = P.b, ec = P.c_raw + ks;
+        const float aa = ea * ea, bb = eb * eb, cc = ec * ec, ac = ea * ec, ab = ea * eb, bc = eb * ec;
+        const float det = ac - bb;
+        const float det_rcp_sq = 1.0f / (det * det);
+        const float gcx = a.acc[2 * n + i], gcy = a.acc[3 * n + i], gcz = a.acc[4 * n + i];
+        const float dcov_x = det_rcp_sq * (2.0f * bc * gcy - cc * gcx - bb * gcz);     // kb:130-134
+        const float dcov_y = det_rcp_sq * (bc * gcx - (ac + bb) * gcy + ab * gcz);
+        const float dcov_z = det_rcp_sq * (2.0f * ab * gcy - bb * gcx - aa * gcz);
+        g_op[0] = a.acc[5 * n + i];
+        if (cam.proper_aa) {                                                           // kb:137-145 (cov2d branch off, cfg:12)
+            const float opacity = sigmoid_f(a.opacities[i]);
+            const float det_raw = P.a_raw * P.c_raw - bb;
+            g_op[0] = g_op[0] * sqrtf(fmaxf(det_raw / det, 0.0f)) * opacity * (1.0f - opacity);
+        }
+        const float* j1 = P.jw1; const float* j2 = P.jw2;
+        float d3[6];                                                                   // kb:163-170
+        d3[0] = j1[0] * j1[0] * dcov_x + 2.0f * j1[0] * j2[0] * dcov_y + j2[0] * j2[0] * dcov_z;
+        d3[1] = j1[0] * j1[1] * dcov_x + (j1[0] * j2[1] + j1[1] * j2[0]) * dcov_y + j2[0] * j2[1] * dcov_z;
+        d3[2] = j1[0] * j1[2] * dcov_x + (j1[0] * j2[2] + j1[2] * j2[0]) * dcov_y + j2[0] * j2[2] * dcov_z;
+        d3[3] = j1[1] * j1[1] * dcov_x + 2.0f * j1[1] * j2[1] * dcov_y + j2[1] * j2[1] * dcov_z;
+        d3[4] = j1[1] * j1[2] * dcov_x + (j1[1] * j2[2] + j1[2] * j2[1]) * dcov_y + j2[1] * j2[2] * dcov_z;
+        d3[5] = j1[2] * j1[2] * dcov_x + 2.0f * j1[2] * j2[2] * dcov_y + j2[2] * j2[2] * dcov_z;
+        float djw1[3], djw2[3];                                                        // kb:173-182
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            djw1[k] = 2.0f * (P.jwc1[k] * dcov_x + P.jwc2[k] * dcov_y);
+            djw2[k] = 2.0f * (P.jwc1[k] * dcov_y + P.jwc2[k] * dcov_z);
+        }
+        const float dj11 = cam.r1[0] * djw1[0] + cam.r1[1] * djw1[1] + cam.r1[2] * djw1[2];
+        const float dj22 = cam.r2[0] * djw2[0] + cam.r2[1] * djw2[1] + cam.r2[2] * djw2[2];
+        const float dj13 = cam.r3[0] * djw1[0] + cam.r3[1] * djw1[1] + cam.r3[2] * djw1[2];
+        const float dj23 = cam.r3[0] * djw2[0] + cam.r3[1] * djw2[1] + cam.r3[2] * djw2[2];
+        const float gm2x = a.acc[i], gm2y = a.acc[n + i];
+        if (a.densification_info != nullptr) {                                         // kb:194-201
+            a.densification_info[i] += 1.0f;
+            const float nx = 0.5f * (gm2x * cam.width), ny = 0.5f * (gm2y * cam.height);
+            a.densification_info[n + i] += sqrtf(nx * nx + ny * ny);
+        }
+        float dcam[3];                                                                 // kb:204-217
+        dcam[0] = P.j11 * gm2x;
+        dcam[1] = P.j22 * gm2y;
+        dcam[2] = -P.j11 * P.x * gm2x - P.j22 * P.y * gm2y;
+        const bool valid_x = P.x >= P.clip_l && P.x <= P.clip_r;
+        const bool valid_y = P.y >= P.clip_t && P.y <= P.clip_b;
+        if (valid_x) dcam[0] -= P.j11 * dj13 / P.depth;
+        if (valid_y) dcam[1] -= P.j22 * dj23 / P.depth;
+        const float fxm = valid_x ? 2.0f : 1.0f, fym = valid_y ? 2.0f : 1.0f;
+        dcam[2] += (P.j11 * (fxm * P.x_clipped * dj13 - dj11) + P.j22 * (fym * P.y_clipped * dj23 - dj22)) / P.depth;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)                                                    // kb:220-228
+            g_mean[k] = (cam.r1[k] * dcam[0] + cam.r2[k] * dcam[1] + cam.r3[k] * dcam[2]) + dpos[k];
+        const float* R = P.R; const float* G = P.RSS;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                                  // kb:231-240
+            const float dvar = R[k] * R[k] * d3[0] + R[3 + k] * R[3 + k] * d3[3] + R[6 + k] * R[6 + k] * d3[5]
+                               + 2.0f * (R[k] * R[3 + k] * d3[1] + R[k] * R[6 + k] * d3[2] + R[3 + k] * R[6 + k] * d3[4]);
+            g_scale[k] = 2.0f * P.var[k] * dvar;
+        }
+        float dR[9];                                                                   // kb:243-253
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dR[0 + k] = 2.0f * (G[0 + k] * d3[0] + G[3 + k] * d3[1] + G[6 + k] * d3[2]);
+            dR[3 + k] = 2.0f * (G[0 + k] * d3[1] + G[3 + k] * d3[3] + G[6 + k] * d3[4]);
+            dR[6 + k] = 2.0f * (G[0 + k] * d3[2] + G[3 + k] * d3[4] + G[6 + k] * d3[5]);
+        }
+        quat_to_rotation_backward(q[0], q[1], q[2], q[3], dR, g_rot);
+    }
+
+    // group order in fused mode: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations
+    emit<3>(FUSED, a.grad_means, a.p[0], a.m[0], a.v[0], a.h[0], i, g_mean);
+    emit<3>(FUSED, a.grad_sh0, a.p[1], a.m[1], a.v[1], a.h[1], i, g_sh0);
+    emit<1>(FUSED, a.grad_opacities, a.p[2], a.m[2], a.v[2], a.h[2], i, g_op);
+    emit<3>(FUSED, a.grad_scales, a.p[3], a.m[3], a.v[3], a.h[3], i, g_scale);
+    emit<4>(FUSED, a.grad_rotations, a.p[4], a.m[4], a.v[4], a.h[4], i, g_rot);
+}
+
+hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);
+    if (fused_adam) hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- SH-rest pass: one lane per (Gaussian, basis) pair, 12 contiguous bytes per lane --------------------------------
+template <bool FUSED>
+__global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs a) {
+    const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_pairs = (size_t)a.n * a.total_sh_rest;
+    if (pair >= n_pairs) return;
+    const uint32_t gi = static_cast<uint32_t>(pair / a.total_sh_rest);
+    const uint32_t k = static_cast<uint32_t>(pair - (size_t)gi * a.total_sh_rest);
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    // coefficient k belongs to degree 1 (k<3), 2 (k<8), 3 (k<15); it receives a gradient only if that degree is active
+    const bool degree_on = (k < 3 && a.active_sh_bases > 1) || (k >= 3 && k < 8 && a.active_sh_bases > 4) ||
+                           (k >= 8 && k < 15 && a.active_sh_bases > 9);
+    if (degree_on && a.n_touched[gi] != 0) {
+        const float x = a.view_dir[3 * (size_t)gi], y = a.view_dir[3 * (size_t)gi + 1], z = a.view_dir[3 * (size_t)gi + 2];
+        float B[15];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) B[j] = 0.0f;
+        sh_basis(x, y, z, a.active_sh_bases, B);
+        float bk = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) bk = (k == static_cast<uint32_t>(j)) ? B[j] : bk;   // select, no dynamic register indexing
+        const size_t n = a.n;
+        g[0] = bk * a.acc[6 * n + gi]; g[1] = bk * a.acc[7 * n + gi]; g[2] = bk * a.acc[8 * n + gi];   // sh_utils.cuh:90-111
+    }
+    if (!FUSED) {
+        a.grad_sh_rest[3 * pair] = g[0]; a.grad_sh_rest[3 * pair + 1] = g[1]; a.grad_sh_rest[3 * pair + 2] = g[2];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float pp = a.p[3 * pair + c], mm = a.m[3 * pair + c], vv = a.v[3 * pair + c];
+            adam_update(pp, mm, vv, g[c], a.h);
+            a.p[3 * pair + c] = pp; a.m[3 * pair + c] = mm; a.v[3 * pair + c] = vv;
+        }
+    }
+}
+
+hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s) {
+    const size_t n_pairs = (size_t)a.n * a.total_sh_rest;
+    if (n_pairs == 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((n_pairs + 255) / 256)), block(256);
+    if (fused_adam) hipLaunchKernelGGL(sh_rest_backward_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(sh_rest_backward_kernel<false>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- K13: Adam for all parameter groups in one launch (adam.cu:10-34), float4-vectorised ----------------------------
+__global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
+    int gidx = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) if (j < a.n_groups && blockIdx.x >= a.g[j].first_block) gidx = j;
+    const AdamGroup& G = a.g[gidx];
+    const int64_t base = ((int64_t)(blockIdx.x - G.first_block) * 256 + threadIdx.x) * 4;
+    if (base >= G.n) return;
+    if (base + 4 <= G.n) {
+        const float4 g4 = *reinterpret_cast<const float4*>(G.grad + base);
+        float4 p4 = *reinterpret_cast<float4*>(G.param + base);
+        float4 m4 = *reinterpret_cast<float4*>(G.exp_avg + base);
+        float4 v4 = *reinterpret_cast<float4*>(G.exp_avg_sq + base);
+        adam_update(p4.x, m4.x, v4.x, g4.x, G.h); adam_update(p4.y, m4.y, v4.y, g4.y, G.h);
+        adam_update(p4.z, m4.z, v4.z, g4.z, G.h); adam_update(p4.w, m4.w, v4.w, g4.w, G.h);
+        *reinterpret_cast<float4*>(G.param + base) = p4;
+        *reinterpret_cast<float4*>(G.exp_avg + base) = m4;
+        *reinterpret_cast<float4*>(G.exp_avg_sq + base) = v4;
+    } else {
+        for (int64_t e = base; e < G.n; ++e) {
+            float pp = G.param[e], mm = G.exp_avg[e], vv = G.exp_avg_sq[e];
+            adam_update(pp, mm, vv, G.grad[e], G.h);
+            G.param[e] = pp; G.exp_avg[e] = mm; G.exp_avg_sq[e] = vv;
+        }
+    }
+}
+
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
+    if (a.total_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_kernel, dim3(a.total_blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace fgs

@@ -1,0 +1,27 @@
+// Device self-test of the wave64 primitives in fgs_wave.h (DPP wave_shr/wave_rol semantics, ballot prefix, readlane).
+// Exposed through fgs_debug_wave_selftest(); the GPU test-suite runs it first so a wrong lane-shift direction is
+// reported as such and not as a gradient mismatch.
+#include "fgs_kernels.h"
+#include <fgs_wave.h>
+
+namespace fgs {
+
+__global__ void __launch_bounds__(kWave) wave_selftest_kernel(uint32_t* out) {
+    const unsigned lane = lane_id();
+    float state[1] = {static_cast<float>(lane + 100u)};
+    float feed[1] = {static_cast<float>(lane + 1000u)};
+    pipeline_advance<1>(state, feed);
+    out[lane] = static_cast<uint32_t>(state[0]);             // expect lane 0: 1000, lane l: 99 + l
+    out[64 + lane] = static_cast<uint32_t>(feed[0]);         // expect 1000 + (l + 1) % 64
+    const uint64_t m = wave_ballot(lane % 3u == 0u);
+    out[128 + lane] = lanes_below(m);                        // expect ceil(l / 3)
+    const int src = __ffsll(static_cast<unsigned long long>(m >> 7)) - 1 + 7;   // first multiple of 3 at or above 7 -> 9
+    out[192 + lane] = wave_read(lane * 7u, src) + wave_sum(lane) + wave_max(lane ^ 5u);   // 63 + 2016 + 63
+}
+
+hipError_t launch_wave_selftest(uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(wave_selftest_kernel, dim3(1), dim3(kWave), 0, s, out);
+    return hipGetLastError();
+}
+
+}  // namespace fgs

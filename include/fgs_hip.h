@@ -1,0 +1,132 @@
+/*
+ * fgs_hip.h -- C ABI of libfgs_hip.so, the MI355X (gfx950) implementation of the FasterGS rasterizer hot path.
+ *
+ * This is the drop-in boundary: each entry point replaces one function of the reference's pybind module
+ * `FasterGSCudaBackend._C` (reference: FasterGSCudaBackend/FasterGSCudaBackend/torch_bindings/bindings.cpp:12-21).
+ * Plain pointers and sizes only -- no torch types. All pointers are DEVICE pointers unless marked [host].
+ * Every function returns FGS_OK (0) or a negative fgs_status and never throws; fgs_last_error() gives the text.
+ * All work is enqueued on `stream` (a hipStream_t passed as void*); the reference uses the legacy default stream
+ * (rasterization/src/forward.cu:64 etc.), an explicit stream is the MI355X-side change.
+ *
+ * Tensor layouts are the reference's (torch_bindings/rasterization.py:113-132):
+ *   means[N,3] scales[N,3] (log) rotations[N,4] (w first, unnormalised) opacities[N,1] (logit)
+ *   sh_coefficients_0[N,1,3] sh_coefficients_rest[N,K-1,3], fp32, contiguous.
+ */
+#ifndef FGS_HIP_H
+#define FGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGS_ABI_VERSION 1
+
+typedef enum fgs_status {
+    FGS_OK = 0,
+    FGS_ERR_INVALID_ARGUMENT = -1,
+    FGS_ERR_ALLOC = -2,      /* the resize callback returned NULL */
+    FGS_ERR_HIP = -3,        /* a HIP runtime call or kernel launch failed */
+    FGS_ERR_INTERNAL = -4
+} fgs_status;
+
+/* The 13 fields of RasterizerSettings (torch_bindings/rasterization.py:8-38) plus total_sh_bases_rest, which the
+ * reference derives from sh_coefficients_rest.size(1) (rasterization/src/rasterization_api.cu:44). */
+typedef struct fgs_settings {
+    const float* w2c;           /* >= 12 floats: rows 0..2 of the row-major world-to-camera matrix */
+    const float* cam_position;  /* 3 floats */
+    const float* bg_color;      /* 3 floats */
+    int32_t active_sh_bases;
+    int32_t total_sh_bases_rest;
+    int32_t width;
+    int32_t height;
+    float focal_x, focal_y, center_x, center_y, near_plane, far_plane;
+    int32_t proper_antialiasing;
+} fgs_settings;
+
+/* Scratch ownership follows the reference: the caller owns four byte buffers and hands the library a callback that
+ * (re)sizes buffer `which` to `bytes` and returns its device pointer -- the C form of resize_function_wrapper
+ * (utils/torch_utils.h:6-12) as used at rasterization/src/forward.cu:44,58,179,236. Layout inside is private. */
+enum { FGS_BUF_PRIMITIVE = 0, FGS_BUF_TILE = 1, FGS_BUF_INSTANCE = 2, FGS_BUF_BUCKET = 3, FGS_BUF_COUNT = 4 };
+typedef void* (*fgs_resize_fn)(void* user, int32_t which, size_t bytes);
+
+/* What _C.forward returns next to the image and what _C.backward takes back (rasterization_api.h:8-59):
+ * (n_instances, n_buckets, selector). Opaque to callers; n_visible is extra (reported by bench.py). */
+typedef struct fgs_forward_state {
+    int32_t n_visible;
+    int32_t n_instances;
+    int32_t n_buckets;   /* capacity of the bucket buffer (upper bound of the device-side count) */
+    int32_t selector;    /* which half of the instance double buffer holds the tile-sorted list */
+} fgs_forward_state;
+
+int32_t fgs_abi_version(void);
+const char* fgs_last_error(void);   /* [host] thread-local, valid until the next call on this thread */
+const char* fgs_build_info(void);   /* [host] e.g. "gfx950 wave64 tile16x12 bucket64" */
+
+/* replaces _C.forward  (rasterization_api.cu:13-91 -> rasterization/src/forward.cu:11-259). image: [3,H,W]. */
+int32_t fgs_forward(const float* means, const float* scales, const float* rotations, const float* opacities,
+                    const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                    const fgs_settings* settings, float* image,
+                    fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
+
+/* Bytes of zero-initialisable scratch fgs_backward needs (replaces the two helper tensors grad_mean2d_helper /
+ * grad_conic_helper of rasterization_api.cu:133-134 plus per-pixel staging). */
+size_t fgs_backward_scratch_bytes(int32_t n_primitives, int32_t width, int32_t height);
+
+/* replaces _C.backward (rasterization_api.cu:94-178 -> rasterization/src/backward.cu:8-125).
+ * The six grad_* outputs need NOT be zero-filled by the caller: every element is written (zeros for primitives
+ * that were not visible), which replaces the reference's 8 torch::zeros fills (rasterization_api.cu:127-134).
+ * densification_info: [2,N] accumulated in place (kernels_backward.cuh:194-201) or NULL. */
+int32_t fgs_backward(const float* grad_image, const float* image,
+                     const float* means, const float* scales, const float* rotations, const float* opacities,
+                     const float* sh_coefficients_rest,
+                     void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                     float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                     float* densification_info, void* scratch,
+                     int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream);
+
+/* replaces _C.inference (rasterization_api.cu:181-247 -> rasterization/src/inference.cu:11-226).
+ * image: [3,H,W] if to_chw else [H,W,3]. Only FGS_BUF_PRIMITIVE/TILE/INSTANCE are requested. */
+int32_t fgs_inference(const float* means, const float* scales, const float* rotations, const float* opacities,
+                      const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                      const fgs_settings* settings, float* image, int32_t to_chw, int32_t clamp_output,
+                      fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
+
+/* replaces _C.adam_step (adam/src/adam.cu:36-71): in-place Adam on one tensor, bias corrections in double on the host. */
+int32_t fgs_adam_step(const float* grad, float* param, float* exp_avg, float* exp_avg_sq, int64_t n_elements,
+                      int32_t step, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* All parameter groups of FusedAdam.step() (torch_bindings/adam.py:11-36) in ONE launch. Arrays are [host], length n_groups <= 8. */
+int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
+                            double beta1, double beta2, double eps, void* stream);
+
+/* Fused backward + Adam (the reference's FasterGSFused branch, README.md:37; not in /root/reference -- defined here as
+ * "equal to fgs_backward followed by FusedAdam.step() on all six groups"). Gradients are never
+ * materialised. params/exp_avg/exp_avg_sq are arrays [host] of 6 device pointers in the order
+ * means, sh_coefficients_0, sh_coefficients_rest, opacities, scales, rotations (Model.py:238-245); lrs likewise. */
+int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
+                                float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                float* densification_info, void* scratch,
+                                int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state,
+                                int32_t step, const double* lrs, double beta1, double beta2, double eps, void* stream);
+
+/* Test/bench introspection: byte offsets of the named sub-arrays inside a scratch buffer, so tests can compare every
+ * intermediate with the oracle. Returns the number of entries written (<= max_entries); names are static strings. */
+typedef struct fgs_blob_entry { const char* name; size_t offset; size_t bytes; } fgs_blob_entry;
+int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int32_t height, int32_t n_instances,
+                        int32_t n_buckets, fgs_blob_entry* entries, int32_t max_entries);
+
+/* Device self-test of the wave64 primitives (DPP shift/rotate direction, ballot prefix, readlane); writes 256 words that
+ * tests/test_gpu_parity.py checks against the expected pattern. which == FGS_BUF_COUNT in fgs_blob_layout describes the
+ * backward scratch buffer. */
+int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGS_HIP_H */

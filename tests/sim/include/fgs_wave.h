@@ -1,0 +1,72 @@
+// TEST-ONLY shadow of csrc/fgs_wave.h for the CPU simulation build: same interface, collectives implemented on the fiber
+// scheduler in hip/hip_runtime.h instead of gfx950 cross-lane instructions. Semantics mirror the hardware ones
+// (64-bit ballots of active lanes, wave_shr:1 / wave_rol:1 data movement) as documented in the product header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace fgs {
+
+inline unsigned lane_id() { return sim::tid() & 63u; }
+
+inline uint64_t wave_ballot(bool p) {
+    const int par = sim::next_parity(true);
+    sim::me().slot[par][0] = p ? 1 : 0;
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    uint64_t m = 0;
+    for (int i = first; i < std::min(first + 64, b.n); ++i)
+        if (b.lanes[i].gen_wave >= g && b.lanes[i].slot[par][0]) m |= 1ull << (i - first);
+    return m;
+}
+inline unsigned lanes_below(uint64_t m) { return static_cast<unsigned>(__builtin_popcountll(m & ((1ull << lane_id()) - 1ull))); }
+
+inline uint64_t sim_exchange(uint64_t v, int src_lane) {
+    const int par = sim::next_parity(true);
+    sim::me().slot[par][0] = v;
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    const sim::Lane& s = b.lanes[first + src_lane];
+    return s.gen_wave >= g ? s.slot[par][0] : 0;
+}
+inline unsigned wave_read(unsigned v, int src_lane) { return static_cast<unsigned>(sim_exchange(v, src_lane)); }
+inline float wave_read(float v, int src_lane) { return __uint_as_float(static_cast<unsigned>(sim_exchange(__float_as_uint(v), src_lane))); }
+
+template <class Op> inline unsigned sim_reduce(unsigned v, Op op) {
+    const int par = sim::next_parity(true);
+    sim::me().slot[par][0] = v;
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    bool have = false; unsigned r = 0;
+    for (int i = first; i < std::min(first + 64, b.n); ++i) {
+        if (b.lanes[i].gen_wave < g) continue;
+        const unsigned x = static_cast<unsigned>(b.lanes[i].slot[par][0]);
+        r = have ? op(r, x) : x; have = true;
+    }
+    return r;
+}
+inline unsigned wave_sum(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a + b; }); }
+inline unsigned wave_max(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
+
+template <int NV>
+inline void pipeline_advance(float (&state)[NV], float (&feed)[NV]) {
+    static_assert(2 * NV <= sim::kSlots, "slot overflow");
+    const int par = sim::next_parity(true);
+    sim::Lane& L = sim::me();
+    for (int k = 0; k < NV; ++k) { L.slot[par][k] = __float_as_uint(state[k]); L.slot[par][NV + k] = __float_as_uint(feed[k]); }
+    sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    const int lane = b.cur - first;
+    const sim::Lane& up = b.lanes[first + (lane + 63) % 64];     // lane - 1
+    const sim::Lane& down = b.lanes[first + (lane + 1) % 64];    // lane + 1
+    for (int k = 0; k < NV; ++k) {
+        state[k] = lane == 0 ? feed[k] : __uint_as_float(static_cast<unsigned>(up.slot[par][k]));       // wave_shr:1, old = feed
+        feed[k] = __uint_as_float(static_cast<unsigned>(down.slot[par][NV + k]));                       // wave_rol:1
+    }
+}
+
+}  // namespace fgs

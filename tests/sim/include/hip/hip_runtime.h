@@ -1,0 +1,166 @@
+// TEST-ONLY stand-in for <hip/hip_runtime.h>: lets g++ compile the product's .hip sources into a CPU library in which
+// every workgroup runs as cooperatively scheduled fibers (one per work-item). Purpose: exercise the real kernel
+// sources + the C-ABI host orchestration against the oracle in the GPU-less build container (tests/test_sim_parity.py).
+// It is never built by, shipped with, or loaded from the product package; see tests/sim/README.md.
+#pragma once
+#include <ucontext.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipMemcpyDeviceToHost = 2, hipHostMallocDefault = 0 };
+typedef void* hipStream_t;
+
+struct uint2 { unsigned x, y; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+namespace sim {
+
+constexpr int kSlots = 24;
+struct Lane {
+    ucontext_t ctx;
+    bool alive = false;
+    unsigned gen_wave = 0, gen_block = 0;
+    uint64_t slot[2][kSlots];
+};
+struct Block {
+    std::vector<Lane> lanes;
+    std::vector<char> stacks;
+    int n = 0, cur = 0;
+    unsigned block_idx = 0, block_dim = 0, grid_dim = 0;
+    ucontext_t main_ctx;
+    std::function<void()> body;
+    unsigned long progress = 0;
+};
+inline Block& blk() { static Block b; return b; }
+inline Lane& me() { return blk().lanes[blk().cur]; }
+inline unsigned tid() { return static_cast<unsigned>(blk().cur); }
+inline void yield() { Block& b = blk(); swapcontext(&b.lanes[b.cur].ctx, &b.main_ctx); }
+
+inline void trampoline() {
+    Block& b = blk();
+    b.body();
+    b.lanes[b.cur].alive = false;
+    ++b.progress;
+    swapcontext(&b.lanes[b.cur].ctx, &b.main_ctx);
+}
+
+inline void run_block(unsigned block_idx, unsigned block_dim, unsigned grid_dim, const std::function<void()>& body) {
+    Block& b = blk();
+    constexpr size_t kStack = 128 * 1024;
+    if (b.lanes.size() < block_dim) { b.lanes.resize(block_dim); b.stacks.resize(kStack * block_dim); }
+    b.n = static_cast<int>(block_dim); b.block_idx = block_idx; b.block_dim = block_dim; b.grid_dim = grid_dim; b.body = body;
+    for (int i = 0; i < b.n; ++i) {
+        Lane& L = b.lanes[i];
+        L.alive = true; L.gen_wave = 0; L.gen_block = 0;
+        getcontext(&L.ctx);
+        L.ctx.uc_stack.ss_sp = b.stacks.data() + kStack * i;
+        L.ctx.uc_stack.ss_size = kStack;
+        L.ctx.uc_link = &b.main_ctx;
+        makecontext(&L.ctx, (void (*)())trampoline, 0);
+    }
+    int alive = b.n;
+    unsigned long stale_rounds = 0;
+    while (alive > 0) {
+        const unsigned long before = b.progress;
+        alive = 0;
+        for (int i = 0; i < b.n; ++i) {
+            if (!b.lanes[i].alive) continue;
+            b.cur = i;
+            swapcontext(&b.main_ctx, &b.lanes[i].ctx);
+            if (b.lanes[i].alive) ++alive;
+        }
+        if (b.progress == before && alive > 0) {
+            if (++stale_rounds > 4) { fprintf(stderr, "[sim] deadlock: a collective is waiting for lanes that never arrive (block %u)\n", block_idx); abort(); }
+        } else stale_rounds = 0;
+    }
+}
+
+// Wait until every ALIVE lane of the scope (my wave, or the whole block) reached my generation; returns that generation.
+// A lane took part in collective `g` iff its generation counter is >= g (it may have exited since -- its slots stay valid).
+inline unsigned sync_scope(bool wave) {
+    Block& b = blk();
+    Lane& L = me();
+    const unsigned my_gen = wave ? ++L.gen_wave : ++L.gen_block;
+    ++b.progress;
+    const int first = wave ? (b.cur / 64) * 64 : 0;
+    const int last = wave ? std::min(first + 64, b.n) : b.n;
+    for (;;) {
+        bool all = true;
+        for (int i = first; i < last; ++i) {
+            const Lane& o = b.lanes[i];
+            if (o.alive && (wave ? o.gen_wave : o.gen_block) < my_gen) { all = false; break; }
+        }
+        if (all) break;
+        yield();
+    }
+    return my_gen;
+}
+inline int next_parity(bool wave) { Lane& L = me(); return static_cast<int>(((wave ? L.gen_wave : L.gen_block) + 1u) & 1u); }
+
+struct Idx3 { unsigned x, y, z; };
+template <class F> inline void launch(dim3 grid, dim3 block, F f) {
+    if (getenv("FGS_SIM_TRACE")) fprintf(stderr, "[sim] launch grid=%u block=%u\n", grid.x, block.x);
+    for (unsigned bi = 0; bi < grid.x; ++bi) run_block(bi, block.x, grid.x, f);
+}
+
+}  // namespace sim
+
+#define threadIdx (sim::Idx3{sim::tid(), 0u, 0u})
+#define blockIdx (sim::Idx3{sim::blk().block_idx, 0u, 0u})
+#define blockDim (sim::Idx3{sim::blk().block_dim, 1u, 1u})
+#define gridDim (sim::Idx3{sim::blk().grid_dim, 1u, 1u})
+
+template <class K, class... A>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
+    sim::launch(grid, block, [=]() { kernel(args...); });
+}
+
+inline void __syncthreads() { sim::sync_scope(false); }
+inline int __syncthreads_and(int p) {
+    const int par = sim::next_parity(false);
+    sim::me().slot[par][0] = p ? 1 : 0;
+    const unsigned g = sim::sync_scope(false);
+    sim::Block& b = sim::blk();
+    int r = 1;
+    for (int i = 0; i < b.n; ++i) if (b.lanes[i].gen_block >= g && !b.lanes[i].slot[par][0]) r = 0;
+    return r;
+}
+
+using std::min;
+using std::max;
+inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll(static_cast<long long>(v)); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+inline float unsafeAtomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "sim"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (n) memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 1; }
