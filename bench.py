@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X FasterGS hot path (contract: see the task statement / DESIGN.md 'Measurement').
+
+One "step" = one full training iteration of the reference (Trainer.py:170-199): lr update -> diff_rasterize forward ->
+L1 loss -> backward -> FusedAdam.step -> zero_grad, on one 1920x1080 view of the synthetic garden-like scene
+(scene S2 = 3 M Gaussians by default). With N GPUs every rank renders a different orbit view of the
+same replicated scene and gradients are summed over ranks with one RCCL all-reduce per step (view-parallel, weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S1|S2|S3] [--no-cpu-baseline] [--no-extras]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path[:0] = [str(REPO), str(REPO / 'faster-gaussian-splatting_amd')]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--scene', default='S2', choices=['S0', 'S1', 'S2', 'S3'])
+    ap.add_argument('--n-gaussians', type=int, default=0, help='override the scene size (debug)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the inference / fused side measurements')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
+    return ap.parse_args()
+
+
+def build_scene(args):
+    from harness.scenes import SCENE_SIZES, make_garden_like, make_s0, orbit_views
+    if args.scene == 'S0':
+        params, view = make_s0()
+        return params, [view], 'S0: 1k Gaussians, 128x128'
+    n = args.n_gaussians or SCENE_SIZES[args.scene]
+    params = make_garden_like(n)
+    return params, orbit_views(8), f'{args.scene}: {n} garden-like Gaussians (SH degree 3), 1920x1080, 8 orbit views'
+
+
+def cpu_baseline(params, view, stats: dict) -> dict:
+    """Times ONE training iteration (forward + backward + Adam on all 59 floats per Gaussian) of the same workload on the
+    host cores with the CPU oracle (a port of the reference arithmetic, oracle/fgs_oracle.c; OpenMP over Gaussians / tiles /
+    buckets). Reported baseline, not a target."""
+    from oracle import oracle as O
+    names = ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest')
+    S = O.Settings(view.w2c.numpy(), view.position.numpy(), view.background_color.numpy(), 16, view.width, view.height,
+                   view.focal_x, view.focal_y, view.center_x, view.center_y, view.near_plane, view.far_plane, False)
+    a = [params[k].numpy() for k in names]
+    t0 = time.perf_counter()
+    f = O.forward(*a, S, bucket_size=32)
+    t1 = time.perf_counter()
+    gi = np.sign(f['image']).astype(np.float32) / f['image'].size
+    dens = np.zeros((2, f['N']), np.float32)
+    g = O.backward(f, S, gi, dens)
+    t2 = time.perf_counter()
+    for k, gk, lr in (('means', 'means', 1.6e-4), ('sh_coefficients_0', 'sh0', 2.5e-3), ('sh_coefficients_rest', 'sh_rest', 1.25e-4),
+                      ('opacities', 'opacities', 2.5e-2), ('scales', 'scales', 5e-3), ('rotations', 'rotations', 1e-3)):
+        p = np.ascontiguousarray(params[k].numpy().copy())
+        O.adam_step(np.ascontiguousarray(g[gk].reshape(p.shape)), p, np.zeros_like(p), np.zeros_like(p), 1, lr)
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {'value': 1.0 / total, 'unit': 'iters/s', 'cores': O.num_threads(), 'kind': 'port',
+            'sample': f'1 full training iteration (fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s + Adam {t3 - t2:.2f}s) of the same workload, '
+                      f'view 0, V={f["V"]} I={f["I"]} B32={f["B"]}; OpenMP threads = cores',
+            'render_mpix_per_s': view.width * view.height / 1e6 / (t1 - t0)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus and not args.cpu_baseline_only:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    params, views, workload = build_scene(args)
+
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(params, views[0], {})))
+        return
+
+    import torch.distributed as dist
+    from FasterGSCudaBackend import FusedRasterizerOptimizer
+    from FasterGSCudaBackend._backend import default_backend
+    from FasterGSCudaBackend import rasterization as R
+    from harness import trainer as T
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+    be = default_backend()
+
+    g = T.Gaussians(params, device)
+    g.training_setup(training_cameras_extent=5.0)
+    n = g.means.shape[0]
+    views = [v.to(device) for v in views]
+    my_views = [views[(i * world + rank) % len(views)] for i in range(len(views))]
+
+    # fixed targets: renders of a perturbed copy of the scene, and realised V / I / B per view
+    stats = {}
+    targets = {}
+    with torch.no_grad():
+        gen = torch.Generator(device='cpu').manual_seed(99)
+        pert = [t.detach().clone() for t in g.tensors()]
+        pert[4] = pert[4] + 0.15 * torch.randn(pert[4].shape, generator=gen).to(device)
+        pert[0] = pert[0] + 0.002 * torch.randn(pert[0].shape, generator=gen).to(device)
+        for v in {id(v): v for v in my_views}.values():
+            S = T.extract_settings(v, g.active_sh_bases, v.background_color)
+            targets[id(v)] = be.inference(*pert, S, True, True)
+            res = be.forward(*g.tensors(), S)
+            lay = be.blob_layout(1, n, v.width, v.height, res.state[1], res.state[2])
+            n_tiles = ((v.width + 15) // 16) * ((v.height + 11) // 12)
+            b_real = int(be.view(res.buffers[1], lay, 'bucket_offsets', torch.int32)[n_tiles - 1].item())
+            stats[id(v)] = {'V': res.state[0], 'I': res.state[1], 'B': b_real}
+            del res
+        del pert
+
+    # view-parallel gradient exchange: all six gradients live in ONE contiguous arena -> one RCCL all-reduce per step
+    hook = None
+    if world > 1:
+        sizes = [p.numel() for p in g.tensors()]
+        arena = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+        offs = np.cumsum([0] + sizes)
+        views_of = [arena[offs[i]:offs[i + 1]].view(p.shape) for i, p in enumerate(g.tensors())]
+        R.set_gradient_buffers(lambda: views_of)
+
+        def hook():
+            if all(p.grad is not None and p.grad.data_ptr() == v_.data_ptr() for p, v_ in zip(g.tensors(), views_of)):
+                dist.all_reduce(arena)
+            else:   # autograd copied a gradient: exchange tensor by tensor
+                for p in g.tensors():
+                    dist.all_reduce(p.grad)
+
+    def step(i: int) -> None:
+        v = my_views[i % len(my_views)]
+        T.training_iteration(g, v, targets[id(v)], i, loss_scale=1.0 / world, before_step=hook)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    be.profile_enable(True)
+    be.profile_read()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = be.profile_read()
+    be.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    used = [my_views[(args.warmup + i) % len(my_views)] for i in range(args.steps)]
+    mean = lambda key: float(np.mean([stats[id(v)][key] for v in used]))
+    V, I, B = mean('V'), mean('I'), mean('B')
+    W_, H_ = views[0].width, views[0].height
+    P_, T_ = W_ * H_, ((W_ + 15) // 16) * ((H_ + 11) // 12)
+    K_ = g.active_sh_bases
+    # algorithmic bytes (SURVEY.md 8d / DESIGN.md): dominant kernel = blend backward (K11)
+    bytes_k11 = 76.0 * I + 3076.0 * B + 32.0 * P_
+    k11_ms, k11_calls = prof.get('blend_backward', (0.0, 0))
+    k11_avg_s = (k11_ms / max(k11_calls, 1)) * 1e-3
+    achieved = bytes_k11 / k11_avg_s / 1e9 if k11_avg_s > 0 else 0.0
+    bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
+    out = {
+        'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': workload + '; full training iteration fwd+bwd+Adam (BASELINE.json configs[2]), L1 loss, '
+                               'densification_info updated', 'parallelism': f'view-parallel dp{world}' if world > 1 else 'single GPU',
+                   'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_},
+        'roofline': {'bound': 'hbm', 'kernel': 'blend_backward_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_kernel_ms': k11_avg_s * 1e3,
+                     'algorithmic_bytes_per_launch': bytes_k11,
+                     'iteration_algorithmic_GB': bytes_iter / 1e9,
+                     'iteration_frac_of_hbm_peak': bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        'stage_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+    }
+
+    if rank == 0 and not args.no_extras:
+        # BASELINE.json configs[1]: forward render only (the reference's render_image_benchmark path)
+        v = my_views[0]
+        for _ in range(3):
+            T.render_image_benchmark(g, v)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            T.render_image_benchmark(g, v)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / reps
+        out['render_mpix_per_sec'] = P_ / 1e6 / dt
+        out['render_ms_per_frame'] = dt * 1e3
+        # BASELINE.json configs[3]: fused backward + Adam
+        fo = FusedRasterizerOptimizer([getattr(g, k).detach() for k in T.PARAM_ORDER],
+                                      [1.6e-4 * 5.0, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3])
+        tgt = targets[id(v)]
+        S = T.extract_settings(v, g.active_sh_bases, v.background_color)
+        grad_fn = lambda img: torch.sign(img - tgt) / img.numel()
+        for _ in range(2):
+            fo.render_and_step(S, grad_fn, g.densification_info)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            fo.render_and_step(S, grad_fn, g.densification_info)
+        torch.cuda.synchronize(device)
+        out['fused_train_iters_per_sec'] = reps / (time.perf_counter() - t0)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out['cpu_baseline'] = cpu_baseline(params, views[0].to('cpu'), stats)
+        except Exception as exc:   # the baseline must never take the GPU number down with it
+            out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {exc}'}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -125,16 +125,22 @@ class Backend:
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
 
     def backward(self, densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest, buffers, settings,
-                 state) -> tuple:
+                 state, out: tuple | None = None) -> tuple:
+        """`out`: optional six preallocated gradient tensors (e.g. views into one contiguous arena for a single RCCL call)."""
         device = self._check_params((means, scales, rotations, opacities, sh_rest), ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_rest'))
         keep: list = []
         n = means.shape[0]
         total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
         S = self._settings(settings, total_rest, device, keep)
         grad_image = grad_image.to(dtype=torch.float32).contiguous()
-        grads = (torch.empty((n, 3), dtype=torch.float32, device=device), torch.empty((n, 3), dtype=torch.float32, device=device),
-                 torch.empty((n, 4), dtype=torch.float32, device=device), torch.empty((n, 1), dtype=torch.float32, device=device),
-                 torch.empty((n, 1, 3), dtype=torch.float32, device=device), torch.empty((n, total_rest, 3), dtype=torch.float32, device=device))
+        shapes = ((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3))
+        if out is None:
+            grads = tuple(torch.empty(sh, dtype=torch.float32, device=device) for sh in shapes)
+        else:
+            grads = tuple(out)
+            for g, sh in zip(grads, shapes):
+                if tuple(g.shape) != sh or g.dtype != torch.float32 or not g.is_contiguous() or g.device != device:
+                    raise RuntimeError(f'preallocated gradient has shape {tuple(g.shape)}, expected contiguous float32 {sh}')
         dens = densification_info if densification_info is not None and densification_info.numel() > 0 else None   # api:136
         if dens is not None and (dens.dtype != torch.float32 or not dens.is_contiguous() or dens.device != device or dens.numel() != 2 * n):
             raise RuntimeError('densification_info must be a contiguous float32 [2, N] tensor on the parameters\' device')
@@ -181,6 +187,15 @@ class Backend:
                                                  (C.c_int64 * k)(*[p.numel() for p in params]), (C.c_int32 * k)(*[int(s) for s in steps]),
                                                  (C.c_double * k)(*[float(x) for x in lrs]), float(beta1), float(beta2), float(eps),
                                                  _stream_of(device)), 'fgs_adam_step_multi')
+
+    def profile_enable(self, enable: bool) -> None:
+        self.lib.fgs_profile_enable(int(enable))
+
+    def profile_read(self) -> dict:
+        """{stage: (total_ms, calls)} accumulated since the last read (HIP events on the launch stream)."""
+        arr = (_lib.StageTime * 32)()
+        k = self.lib.fgs_profile_read(arr, 32)
+        return {arr[i].name.decode(): (arr[i].total_ms, arr[i].calls) for i in range(max(k, 0))}
 
     # -- introspection (tests / bench only) ------------------------------------------------------------------------------
     def blob_layout(self, which: int, n: int, width: int, height: int, n_instances: int, n_buckets: int) -> dict:

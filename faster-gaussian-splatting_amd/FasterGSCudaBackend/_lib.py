@@ -33,6 +33,10 @@ class ForwardState(C.Structure):
     _fields_ = [('n_visible', C.c_int32), ('n_instances', C.c_int32), ('n_buckets', C.c_int32), ('selector', C.c_int32)]
 
 
+class StageTime(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('total_ms', C.c_double), ('calls', C.c_int64)]
+
+
 class BlobEntry(C.Structure):
     _fields_ = [('name', C.c_char_p), ('offset', C.c_size_t), ('bytes', C.c_size_t)]
 
@@ -54,6 +58,8 @@ _SIGNATURES = {
     'fgs_backward_adam_fused': (C.c_int32, [_P] * 2 + [C.POINTER(_P)] * 3 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState),
                                             _I32, C.POINTER(_F64), _F64, _F64, _F64, _P]),
     'fgs_blob_layout': (C.c_int32, [_I32] * 6 + [C.POINTER(BlobEntry), _I32]),
+    'fgs_profile_enable': (C.c_int32, [_I32]),
+    'fgs_profile_read': (C.c_int32, [C.POINTER(StageTime), _I32]),
     'fgs_debug_wave_selftest': (C.c_int32, [_P, _P]),
 }
 

@@ -13,6 +13,15 @@ from torch.autograd.function import once_differentiable
 from ._backend import RasterizerSettings, default_backend
 
 
+_GRAD_OUT = None   # optional provider of preallocated gradient tensors (harness/distributed.py packs them into one arena)
+
+
+def set_gradient_buffers(provider) -> None:
+    """provider() -> six tensors (means, scales, rotations, opacities, sh0, sh_rest order) or None; None resets."""
+    global _GRAD_OUT
+    _GRAD_OUT = provider
+
+
 def _require_gpu(t: torch.Tensor) -> None:
     if not t.is_cuda:
         # Renderer.py:58-59 raises in CPU mode as well; there is no CPU implementation behind this package
@@ -39,7 +48,8 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx: Any, grad_image: torch.Tensor):
         image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
         grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
-                                           buffers, ctx.rasterizer_settings, ctx.buffer_state)
+                                           buffers, ctx.rasterizer_settings, ctx.buffer_state,
+                                           out=_GRAD_OUT() if _GRAD_OUT is not None else None)
         return (*grads, None, None)   # densification_info, rasterizer_settings
 
 

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 using namespace fgs;
 
@@ -33,6 +34,38 @@ int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return fail(FGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
     } while (0)
+
+// ---- optional per-stage timing with HIP events recorded on the caller's stream (fgs_profile_enable / fgs_profile_read) ----
+enum Stage { ST_PREPROCESS, ST_DEPTH_SORT, ST_OFFSETS_SCAN, ST_CREATE_INSTANCES, ST_TILE_SORT, ST_RANGES, ST_BUCKET_SCAN,
+             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_scan", "create_instances", "tile_sort", "extract_ranges",
+                                           "bucket_scan", "blend_forward", "stage_pixels", "blend_backward", "preprocess_backward",
+                                           "sh_rest_backward", "adam"};
+struct StageRecord { int stage; hipEvent_t start, stop; };
+struct Profiler {
+    bool enabled = false;
+    std::vector<StageRecord> records;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+Profiler g_prof;
+struct StageScope {                    // records start now and stop at scope exit, both on `stream`
+    hipStream_t stream; int idx = -1;
+    StageScope(int stage, hipStream_t s) : stream(s) {
+        if (!g_prof.enabled) return;
+        StageRecord r{stage, g_prof.get(), g_prof.get()};
+        if (!r.start || !r.stop) return;
+        (void)hipEventRecord(r.start, stream);
+        g_prof.records.push_back(r);
+        idx = static_cast<int>(g_prof.records.size()) - 1;
+    }
+    ~StageScope() { if (idx >= 0) (void)hipEventRecord(g_prof.records[idx].stop, stream); }
+};
 
 // bu:10-18
 int extract_end_bit(uint32_t n) {
@@ -206,7 +239,7 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters;
     pa.n = n; pa.cam = camera_of(*settings, geo);
-    FGS_HIP(launch_preprocess(!training, pa, stream));
+    { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
     // the one host read of the pass: V and I (fwd:99-102)
     uint32_t* host = pinned_counters();
@@ -217,9 +250,9 @@ int run_forward(bool training, const float* means, const float* scales, const fl
 
     // K2-K4 (fwd:104-127)
     int depth_sel = 0;
-    FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream));
+    { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
-    FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.rec, pb.offsets, n_visible, stream));
+    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.rec, pb.offsets, n_visible, stream)); }
 
     // K5-K7 (fwd:179-216)
     Carver inst_size(nullptr);
@@ -228,11 +261,11 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
-    FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible, stream));
+    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible, stream)); }
     int tile_sel = 0;
-    FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, geo.end_bit, stream));
+    { StageScope t(ST_TILE_SORT, stream); FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, geo.end_bit, stream)); }
     // the key double buffer flips together with the value double buffer
-    FGS_HIP(launch_extract_ranges(geo.key_bytes, ib.keys[tile_sel], tb.ranges, n_instances, stream));
+    { StageScope t(ST_RANGES, stream); FGS_HIP(launch_extract_ranges(geo.key_bytes, ib.keys[tile_sel], tb.ranges, n_instances, stream)); }
 
     BlendArgs ba{};
     ba.ranges = tb.ranges; ba.inst_prims = ib.prims[tile_sel]; ba.rec = pb.rec; ba.bg = settings->bg_color; ba.image = image;
@@ -241,7 +274,7 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     uint32_t n_buckets_cap = 0;
     if (training) {
         // K8+K9 (fwd:218-231) and the bucket buffer sized by its bound (no read-back of n_buckets, fwd:234)
-        FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));
+        { StageScope t(ST_BUCKET_SCAN, stream); FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream)); }
         n_buckets_cap = bucket_capacity(n_instances, geo.n_tiles);
         Carver bucket_size(nullptr);
         BucketBuffers::carve(bucket_size, n_buckets_cap);
@@ -252,7 +285,7 @@ int run_forward(bool training, const float* means, const float* scales, const fl
         ba.bucket_offsets = tb.bucket_offsets; ba.final_T = tb.final_T; ba.n_processed = tb.n_processed;
         ba.max_n_processed = tb.max_n_processed; ba.bucket_tile = bb.tile_index; ba.ckpt = bb.ckpt;
     }
-    FGS_HIP(launch_blend(training, ba, stream));                                          // K10 (fwd:239)
+    { StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_blend(training, ba, stream)); }   // K10 (fwd:239)
 
     state_out->n_visible = static_cast<int32_t>(n_visible);
     state_out->n_instances = static_cast<int32_t>(n_instances);
@@ -292,7 +325,8 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
-    FGS_HIP(launch_blend_backward(a, stream));                                                 // K11 (bwd:56)
+    { StageScope t(ST_STAGE_PIXELS, stream); FGS_HIP(launch_stage_pixels(a, stream)); }
+    { StageScope t(ST_BLEND_BACKWARD, stream); FGS_HIP(launch_blend_backward(a, stream)); }     // K11 (bwd:56)
     return FGS_OK;
 }
 
@@ -351,13 +385,13 @@ int32_t fgs_backward(const float* grad_image, const float* image,
     a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
     a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
     a.n = static_cast<uint32_t>(n_primitives); a.cam = camera_of(*settings, P.geo);
-    FGS_HIP(launch_preprocess_backward(false, a, stream));                                     // K12 (bwd:94)
+    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }   // K12 (bwd:94)
     if (settings->total_sh_bases_rest > 0) {
         if (!grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
         ShRestArgs s{};
         s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc; s.grad_sh_rest = grad_sh_coefficients_rest;
         s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
-        FGS_HIP(launch_sh_rest_backward(false, s, stream));
+        { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, s, stream)); }
     }
     return FGS_OK;
 }
@@ -392,13 +426,13 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
     }
     // The geometry kernel reads sh_rest (pre-update) and leaves the view direction for the SH-rest pass, which then
     // updates sh_rest in place; means are updated by the geometry kernel after it has taken the direction.
-    FGS_HIP(launch_preprocess_backward(true, a, stream));
+    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(true, a, stream)); }
     if (settings->total_sh_bases_rest > 0) {
         ShRestArgs s{};
         s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc;
         s.p = params[2]; s.m = exp_avgs[2]; s.v = exp_avg_sqs[2]; s.h = adam_hyper(step, lrs[2], beta1, beta2, eps);
         s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
-        FGS_HIP(launch_sh_rest_backward(true, s, stream));
+        { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(true, s, stream)); }
     }
     return FGS_OK;
 }
@@ -420,7 +454,7 @@ int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* 
         blocks += static_cast<uint32_t>((n_elements[k] + 1023) / 1024);
     }
     a.total_blocks = blocks;
-    FGS_HIP(launch_adam(a, static_cast<hipStream_t>(stream)));
+    { StageScope t(ST_ADAM, static_cast<hipStream_t>(stream)); FGS_HIP(launch_adam(a, static_cast<hipStream_t>(stream))); }
     return FGS_OK;
 }
 
@@ -443,6 +477,25 @@ int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int3
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown buffer %d", which);
     }
     return c.n < max_entries ? c.n : max_entries;
+}
+
+int32_t fgs_profile_enable(int32_t enable) {
+    g_prof.enabled = enable != 0;
+    return FGS_OK;
+}
+
+int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
+    if (!out || max_entries < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad output array");
+    double ms[ST_COUNT] = {0}; int64_t calls[ST_COUNT] = {0};
+    for (StageRecord& r : g_prof.records) {
+        float t = 0.0f;
+        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) { ms[r.stage] += t; ++calls[r.stage]; }
+        g_prof.pool.push_back(r.start); g_prof.pool.push_back(r.stop);
+    }
+    g_prof.records.clear();
+    int n = 0;
+    for (int k = 0; k < ST_COUNT && n < max_entries; ++k) { out[n].name = kStageNames[k]; out[n].total_ms = ms[k]; out[n].calls = calls[k]; ++n; }
+    return n;
 }
 
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {

@@ -123,10 +123,13 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     }
 }
 
-hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
+hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.n_buckets_cap == 0) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
+    if (a.n_buckets_cap == 0) return hipSuccess;
     const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
     hipLaunchKernelGGL(blend_backward_kernel, grid, block, 0, s, a);
     return hipGetLastError();

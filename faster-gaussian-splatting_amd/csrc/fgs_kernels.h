@@ -59,7 +59,8 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
 };
-hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);
+hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s);      // per-pixel staging pass
+hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);    // K11 proper
 
 struct AdamHyper { float step_size, beta1, beta2, eps, bc2_sqrt_rcp; };
 

@@ -121,6 +121,13 @@ typedef struct fgs_blob_entry { const char* name; size_t offset; size_t bytes; }
 int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int32_t height, int32_t n_instances,
                         int32_t n_buckets, fgs_blob_entry* entries, int32_t max_entries);
 
+/* Optional per-stage timing. While enabled, every pipeline stage is bracketed by hipEvents recorded on the caller's stream;
+ * fgs_profile_read() waits for them, returns accumulated milliseconds + launch counts per stage since the last read and
+ * clears the records. Not thread-safe; intended for bench.py (roofline) and tests. */
+typedef struct fgs_stage_time { const char* name; double total_ms; int64_t calls; } fgs_stage_time;
+int32_t fgs_profile_enable(int32_t enable);
+int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries);
+
 /* Device self-test of the wave64 primitives (DPP shift/rotate direction, ballot prefix, readlane); writes 256 words that
  * tests/test_gpu_parity.py checks against the expected pattern. which == FGS_BUF_COUNT in fgs_blob_layout describes the
  * backward scratch buffer. */

@@ -113,8 +113,9 @@ def forward(means, scales, rotations, opacities, sh0, sh_rest, settings: Setting
     means, scales, rotations = _f32(means).reshape(-1, 3), _f32(scales).reshape(-1, 3), _f32(rotations).reshape(-1, 4)
     opacities, sh0 = _f32(opacities).reshape(-1), _f32(sh0).reshape(-1, 3)
     N = means.shape[0]
-    sh_rest = _f32(sh_rest).reshape(N, -1, 3)
-    total_rest = sh_rest.shape[1]
+    sh_rest = _f32(sh_rest)
+    total_rest = sh_rest.shape[1] if sh_rest.ndim == 3 else (sh_rest.size // (3 * N) if N else 0)
+    sh_rest = sh_rest.reshape(N, total_rest, 3)
     S = settings.to_c(total_rest)
     W, H = settings.width, settings.height
     gw, gh, T = grid_of(W, H)

@@ -1,0 +1,149 @@
+"""Shared test helpers: scene/setting conversion, decoding of the backend's private buffers, comparison metrics."""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / 'faster-gaussian-splatting_amd'
+NAMES = ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest')
+GRAD_KEYS = ('means', 'scales', 'rotations', 'opacities', 'sh0', 'sh_rest')
+
+
+def backend_modules():
+    """FasterGSCudaBackend._lib / ._backend. The package __init__ dlopens libfgs_hip.so; if that is impossible (library not
+    built yet) fall back to a bare namespace package so the ctypes glue can still be bound to the simulation library."""
+    if 'FasterGSCudaBackend' not in sys.modules:
+        try:
+            import FasterGSCudaBackend  # noqa: F401
+        except ImportError:
+            pkg = types.ModuleType('FasterGSCudaBackend')
+            pkg.__path__ = [str(PKG / 'FasterGSCudaBackend')]
+            sys.modules['FasterGSCudaBackend'] = pkg
+    from FasterGSCudaBackend import _backend, _lib
+    return _lib, _backend
+
+
+def sim_backend():
+    _lib, _backend = backend_modules()
+    from tests.sim.build_sim import build
+    return _backend.Backend(_lib.bind(build()))
+
+
+def settings_pair(view, active_sh_bases=16, proper_aa=False, bg=None, device='cpu'):
+    """(oracle.Settings, RasterizerSettings) for a harness View."""
+    from oracle import oracle as O
+    _lib, _backend = backend_modules()
+    bg_t = view.background_color if bg is None else torch.tensor(bg, dtype=torch.float32)
+    S = O.Settings(view.w2c.numpy(), view.position.numpy(), bg_t.numpy(), active_sh_bases, view.width, view.height, view.focal_x,
+                   view.focal_y, view.center_x, view.center_y, view.near_plane, view.far_plane, proper_aa)
+    RS = _backend.RasterizerSettings(view.w2c.to(device), view.position.to(device), bg_t.to(device), active_sh_bases, view.width,
+                                     view.height, view.focal_x, view.focal_y, view.center_x, view.center_y, view.near_plane,
+                                     view.far_plane, proper_aa)
+    return S, RS
+
+
+def np_params(params):
+    return [params[k].detach().cpu().numpy() for k in NAMES]
+
+
+def decode_forward(be, res, n, width, height):
+    """Pulls every intermediate out of the backend's private buffers (layout from fgs_blob_layout) as numpy arrays."""
+    nv, ni, nb, sel = res.state
+    out = {'V': nv, 'I': ni, 'B_cap': nb}
+    bufs = [b.cpu() for b in res.buffers]
+    lp = be.blob_layout(0, n, width, height, ni, nb)
+    rec = be.view(bufs[0], lp, 'rec', torch.float32).reshape(n, 12).numpy()
+    recu = rec.view(np.uint32)
+    out['mean2d'], out['conic_opacity'] = rec[:, 0:2], rec[:, 2:6]
+    out['color'] = rec[:, 6:9]
+    bx, by = recu[:, 9], recu[:, 10]
+    out['screen_bounds'] = np.stack([bx & 0xffff, bx >> 16, by & 0xffff, by >> 16], 1).astype(np.uint16)
+    out['rec_n_touched'] = recu[:, 11]
+    out['n_touched'] = be.view(bufs[0], lp, 'n_touched', torch.int32).numpy().view(np.uint32)
+    out['offsets'] = be.view(bufs[0], lp, 'offsets', torch.int32).numpy().view(np.uint32)[:nv]
+    for s in (0, 1):
+        out[f'depth_keys{s}'] = be.view(bufs[0], lp, f'depth_keys{s}', torch.int32).numpy().view(np.uint32)[:nv]
+        out[f'prim_idx{s}'] = be.view(bufs[0], lp, f'prim_idx{s}', torch.int32).numpy().view(np.uint32)[:nv]
+    lt = be.blob_layout(1, n, width, height, ni, nb)
+    out['ranges'] = be.view(bufs[1], lt, 'ranges', torch.int32).reshape(-1, 2).numpy().view(np.uint32)
+    if 'bucket_offsets' in lt and bufs[1].numel() >= lt['n_processed'][0] + lt['n_processed'][1]:
+        out['bucket_offsets'] = be.view(bufs[1], lt, 'bucket_offsets', torch.int32).numpy().view(np.uint32)
+        out['max_n_processed'] = be.view(bufs[1], lt, 'max_n_processed', torch.int32).numpy().view(np.uint32)
+        out['final_T_tiles'] = be.view(bufs[1], lt, 'final_T', torch.float32).reshape(-1, 192).numpy()
+        out['n_processed_tiles'] = be.view(bufs[1], lt, 'n_processed', torch.int32).reshape(-1, 192).numpy().view(np.uint32)
+    li = be.blob_layout(2, n, width, height, ni, nb)
+    gw, gh = (width + 15) // 16, (height + 11) // 12
+    key_dtype = torch.int16 if (gw * gh - 1).bit_length() <= 16 else torch.int32
+    keys = be.view(bufs[2], li, f'keys{sel}', key_dtype).numpy()[:ni]
+    out['inst_keys'] = keys.view(np.uint16 if key_dtype == torch.int16 else np.uint32).astype(np.uint32)
+    out['inst_prims'] = be.view(bufs[2], li, f'prims{sel}', torch.int32).numpy().view(np.uint32)[:ni]
+    if len(bufs) > 3 and nb > 0 and 'bucket_offsets' in out:
+        lb = be.blob_layout(3, n, width, height, ni, nb)
+        B = int(out['bucket_offsets'][-1])
+        out['B'] = B
+        out['bucket_tile_index'] = be.view(bufs[3], lb, 'tile_index', torch.int32).numpy().view(np.uint32)[:B]
+        out['bucket_ckpt'] = be.view(bufs[3], lb, 'ckpt', torch.float32).reshape(-1, 192, 4).numpy()[:B]
+    return out
+
+
+def tiles_to_image(tile_major: np.ndarray, width: int, height: int, fill=0):
+    """[T,192] tile-major (row-major inside a 16x12 tile) -> [H,W]."""
+    gw, gh = (width + 15) // 16, (height + 11) // 12
+    full = tile_major.reshape(gh, gw, 12, 16).transpose(0, 2, 1, 3).reshape(gh * 12, gw * 16)
+    return full[:height, :width]
+
+
+def rel_inf(a: np.ndarray, ref: np.ndarray) -> float:
+    """max |a-ref| normalised by max |ref| -- the tolerance metric of the float parity tests."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)) if ref.size else 0.0
+
+
+def outlier_fraction(a: np.ndarray, ref: np.ndarray, rtol: float, atol: float) -> float:
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    bad = np.abs(a - ref) > (atol + rtol * np.abs(ref))
+    return float(bad.mean()) if ref.size else 0.0
+
+
+def check_forward_against_oracle(dec: dict, f: dict, exact_floats: bool, width: int, height: int, image: np.ndarray,
+                                 int_mismatch_budget: int = 0):
+    """Integer intermediates bit-exact (up to `int_mismatch_budget` primitives whose libm-ULP-sensitive bounds differ);
+    float intermediates within 1e-5 relative (exact when both sides use the same libm, i.e. the simulation)."""
+    vis = f['n_touched'] > 0
+    assert dec['V'] == f['V'] and dec['I'] == f['I'], (dec['V'], f['V'], dec['I'], f['I'])
+    nt_bad = int((dec['n_touched'] != f['n_touched']).sum())
+    sb_bad = int((dec['screen_bounds'][vis] != f['screen_bounds'][vis]).any(axis=1).sum())
+    assert nt_bad <= int_mismatch_budget and sb_bad <= int_mismatch_budget, (nt_bad, sb_bad)
+    for k in ('mean2d', 'conic_opacity', 'color'):
+        if exact_floats:
+            assert np.array_equal(dec[k][vis], f[k][vis]), k
+        else:
+            assert rel_inf(dec[k][vis], f[k][vis]) < 1e-5, (k, rel_inf(dec[k][vis], f[k][vis]))
+    if int_mismatch_budget == 0:
+        sel = 0 if np.array_equal(dec['prim_idx0'], f['prim_idx']) else 1
+        assert np.array_equal(dec[f'prim_idx{sel}'], f['prim_idx']) and np.array_equal(dec[f'depth_keys{sel}'], f['depth_keys'])
+        assert np.array_equal(dec['offsets'], f['offsets'])
+        assert np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
+        assert np.array_equal(dec['ranges'], f['ranges'])
+        if 'bucket_offsets' in dec:
+            assert np.array_equal(dec['bucket_offsets'], f['bucket_offsets'])
+            assert np.array_equal(dec['bucket_tile_index'], f['bucket_tile_index'])
+    if 'n_processed_tiles' in dec:
+        npr = tiles_to_image(dec['n_processed_tiles'], width, height)
+        fT = tiles_to_image(dec['final_T_tiles'], width, height)
+        if exact_floats:
+            assert np.array_equal(npr.reshape(-1), f['n_processed']) and np.array_equal(dec['max_n_processed'], f['max_n_processed'])
+            assert np.array_equal(fT.reshape(-1), f['final_T'])
+        else:
+            assert (npr.reshape(-1) != f['n_processed']).mean() < 1e-3
+            assert outlier_fraction(fT.reshape(-1), f['final_T'], 1e-4, 1e-6) < 1e-3
+    if exact_floats:
+        assert np.array_equal(image, f['image'])
+    else:
+        assert outlier_fraction(image, f['image'], 1e-4, 1e-5) < 1e-3, outlier_fraction(image, f['image'], 1e-4, 1e-5)
+        assert np.abs(image - f['image']).max() < 5e-3

@@ -158,6 +158,11 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p =
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 inline float unsafeAtomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 
+typedef struct SimEvent_* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(malloc(1)); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "sim"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (n) memset(p, v, n); return hipSuccess; }

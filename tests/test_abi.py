@@ -1,0 +1,82 @@
+"""CPU tests of the drop-in boundary: libfgs_hip.so loads, exports every symbol include/fgs_hip.h declares, validates
+arguments without touching a GPU, and the package refuses to import without the library (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+import helpers
+
+REPO = Path(__file__).resolve().parent.parent
+LIB = REPO / 'faster-gaussian-splatting_amd' / 'libfgs_hip.so'
+
+
+@pytest.fixture(scope='module')
+def hip_lib():
+    if not LIB.exists():
+        subprocess.run(['make', '-C', str(LIB.parent / 'csrc'), '-j8'], check=True)
+    _lib, _ = helpers.backend_modules()
+    return _lib.bind(LIB)
+
+
+def test_header_symbols_are_exported_and_bound(hip_lib):
+    header = (REPO / 'include' / 'fgs_hip.h').read_text()
+    declared = set(re.findall(r'\b(fgs_[a-z0-9_]+)\s*\(', header)) - {'fgs_resize_fn'}
+    _lib, _ = helpers.backend_modules()
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(hip_lib, name) is not None
+    assert hip_lib.fgs_abi_version() == 1
+    assert b'gfx950' in hip_lib.fgs_build_info()
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    _lib, _ = helpers.backend_modules()
+    st = _lib.ForwardState()
+    cb = _lib.RESIZE_FN(lambda u, w, n: 0)
+    assert hip_lib.fgs_forward(None, None, None, None, None, None, 0, None, None, cb, None, C.byref(st), None) == -1
+    assert b'settings' in hip_lib.fgs_last_error()
+    S = _lib.Settings(1, 1, 1, 16, 15, 0, 128, 1.0, 1.0, 0.0, 0.0, 0.2, 100.0, 0)
+    assert hip_lib.fgs_forward(None, None, None, None, None, None, 0, C.byref(S), 1, cb, None, C.byref(st), None) == -1
+    assert b'image size' in hip_lib.fgs_last_error()
+    assert hip_lib.fgs_adam_step_multi(9, None, None, None, None, None, None, None, 0.9, 0.999, 1e-15, None) == -1
+    assert hip_lib.fgs_backward_scratch_bytes(1000, 128, 128) > 1000 * 48
+    assert hip_lib.fgs_backward_scratch_bytes(-1, 128, 128) == 0
+    entries = (_lib.BlobEntry * 16)()
+    k = hip_lib.fgs_blob_layout(0, 1000, 128, 128, 0, 0, entries, 16)
+    names = [entries[i].name.decode() for i in range(k)]
+    assert names[:2] == ['rec', 'n_touched'] and entries[0].bytes == 48000 and all(entries[i].offset % 256 == 0 for i in range(k))
+
+
+def test_package_fails_loudly_without_the_library(tmp_path):
+    code = ("import sys; sys.path.insert(0, r'%s'); import FasterGSCudaBackend" % (REPO / 'faster-gaussian-splatting_amd'))
+    env = dict(os.environ, FGS_HIP_LIBRARY=str(tmp_path / 'missing.so'))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'libfgs_hip.so not found' in r.stderr and 'no CPU fallback' in r.stderr
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package may import, link or load it."""
+    for path in (REPO / 'faster-gaussian-splatting_amd').rglob('*'):
+        if path.suffix in {'.py', '.hip', '.h'} or path.name == 'Makefile':
+            text = path.read_text()
+            assert 'oracle' not in text.lower() or path.name in {'fgs_math.h', 'preprocess.hip', 'binning.hip', 'Makefile'}, path
+            assert 'libfgs_oracle' not in text and 'import oracle' not in text and 'from oracle' not in text, path
+
+
+def test_cpu_tensors_are_rejected_by_the_public_operators(hip_lib):
+    import torch
+    import FasterGSCudaBackend as B
+    from harness.scenes import make_s0
+    params, view = make_s0(n=8)
+    _, RS = helpers.settings_pair(view)
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        B.diff_rasterize(*[params[k] for k in helpers.NAMES], torch.empty(0), RS)
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        B.rasterize(*[params[k] for k in helpers.NAMES], RS, True)
+    with pytest.raises(NotImplementedError, match='8f'):
+        B.update_pruning_scores()

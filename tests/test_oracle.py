@@ -1,0 +1,120 @@
+"""CPU tests of the oracle itself: golden vectors, structural invariants, independent fp64
+autograd re-derivation of the gradients (8c item 4)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from harness.scenes import View, make_s0
+
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+
+
+def _load(name):
+    g = np.load(GOLDEN / name)
+    K, W, H, fx, fy, cx, cy, near, far, aa = g['settings']
+    from oracle import oracle as O
+    S = O.Settings(g['w2c'], g['cam_position'], g['bg_color'], int(K), int(W), int(H), fx, fy, cx, cy, near, far, bool(aa))
+    return g, S, [g[f'in_{k}'] for k in helpers.NAMES]
+
+
+@pytest.mark.parametrize('name', ['s0.npz', 'tiny_aa.npz'])
+def test_oracle_reproduces_golden(oracle, name):
+    g, S, a = _load(name)
+    f = oracle.forward(*a, S, bucket_size=32)
+    for k in ('n_touched', 'screen_bounds', 'depth_keys', 'prim_idx', 'offsets', 'inst_keys', 'inst_prims', 'ranges',
+              'bucket_offsets', 'n_processed', 'max_n_processed'):
+        assert np.array_equal(f[k], g[k]), k                       # integer work: bit-exact
+    for k in ('mean2d', 'conic_opacity', 'color', 'image', 'final_T'):
+        assert helpers.rel_inf(f[k], g[k]) < 1e-6, k              # same code, same libm: tiny headroom for libm updates
+    dens = np.zeros((2, f['N']), np.float32)
+    gr = oracle.backward(f, S, g['grad_image'], dens)
+    for k in helpers.GRAD_KEYS:
+        assert helpers.rel_inf(gr[k], g[f'grad_{k}']) < 1e-5, k
+    assert helpers.rel_inf(dens, g['densification_info']) < 1e-5
+    inf = oracle.forward(*a, S, inference=True, to_chw=False, clamp_output=True)
+    assert helpers.rel_inf(inf['image'], g['inference_hwc_clamped']) < 1e-6
+
+
+def test_bucket_size_does_not_change_gradients(oracle):
+    g, S, a = _load('s0.npz')
+    for k in helpers.GRAD_KEYS:
+        assert helpers.rel_inf(g[f'b64_grad_{k}'], g[f'grad_{k}']) < 1e-5, k
+
+
+def test_adam_golden(oracle):
+    g, _, a = _load('s0.npz')
+    p = a[0].copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    for step in (1, 2, 3):
+        oracle.adam_step(g['grad_means'], p, m, v, step, 1.6e-4)
+        if step in (1, 3):
+            assert np.array_equal(p, g[f'adam{step}_param']) and np.array_equal(m, g[f'adam{step}_exp_avg'])
+            assert np.array_equal(v, g[f'adam{step}_exp_avg_sq'])
+    # torch.optim.Adam agrees (the reference derives its kernel from it, adam.cu:9)
+    tp = torch.tensor(a[0].copy(), requires_grad=True)
+    opt = torch.optim.Adam([tp], lr=1.6e-4, eps=1e-15)
+    for _ in range(3):
+        tp.grad = torch.tensor(g['grad_means'])
+        opt.step()
+    assert helpers.rel_inf(tp.detach().numpy(), p) < 1e-6
+    # zero gradient still moves parameters by momentum
+    p2 = p.copy()
+    oracle.adam_step(np.zeros_like(p), p2, m, v, 4, 1.6e-4)
+    assert np.abs(p2 - p).max() > 0
+
+
+def test_structural_invariants(oracle):
+    g, S, a = _load('s0.npz')
+    f = oracle.forward(*a, S)
+    assert f['n_touched'].sum() == f['I']
+    assert np.all(np.diff(f['inst_keys'].astype(np.int64)) >= 0)                    # tile keys sorted
+    depth = a[0] @ S.w2c[2, :3] + S.w2c[2, 3]
+    for t in range(f['T']):                                                          # depth order inside each tile
+        r0, r1 = f['ranges'][t]
+        d = depth[f['inst_prims'][r0:r1]]
+        assert np.all(np.diff(d) >= 0)
+    assert f['ranges'][:, 1].max() == f['I']
+    assert np.array_equal(np.cumsum((f['ranges'][:, 1] - f['ranges'][:, 0] + 31) // 32), f['bucket_offsets'])
+
+
+def test_culling_rules(oracle):
+    """degenerate quaternion / tiny opacity / out-of-range depth / empty scene."""
+    params, view = make_s0(n=64)
+    S, _ = helpers.settings_pair(view)
+    a = helpers.np_params(params)
+    a[2][0] = 0.0                      # |q|^2 < 1e-8                      (kernels_forward.cuh:83)
+    a[3][1] = -20.0                    # sigmoid(opacity) < 1/255           (kernels_forward.cuh:75)
+    a[0][2] = [0.0, 0.0, -10.0]        # behind the near plane              (kernels_forward.cuh:67)
+    f = oracle.forward(*a, S)
+    assert f['n_touched'][0] == 0 and f['n_touched'][1] == 0 and f['n_touched'][2] == 0
+    g = oracle.backward(f, S, np.ones_like(f['image']))
+    for k in helpers.GRAD_KEYS:
+        assert np.all(g[k][:3] == 0), k
+    # empty scene -> background everywhere, transmittance 1
+    e = [x[:0] for x in a]
+    S2, _ = helpers.settings_pair(view, bg=(0.1, 0.2, 0.3))
+    f0 = oracle.forward(*e, S2)
+    assert f0['I'] == 0 and np.allclose(f0['image'], np.array([0.1, 0.2, 0.3], np.float32)[:, None, None]) and np.all(f0['final_T'] == 1)
+    # active_sh_bases == 1 leaves sh_rest gradients untouched
+    S1, _ = helpers.settings_pair(view, active_sh_bases=1)
+    f1 = oracle.forward(*a, S1)
+    g1 = oracle.backward(f1, S1, np.ones_like(f1['image']))
+    assert np.all(g1['sh_rest'] == 0)
+
+
+@pytest.mark.parametrize('aa,K', [(False, 16), (True, 4)])
+def test_gradients_match_fp64_autograd(oracle, aa, K):
+    from oracle.torch_check import autograd_reference
+    p, v = make_s0(seed=3, n=120)
+    v = View(v.w2c, v.position, 48, 36, 40.0, 40.0, 24.0, 18.0, 0.2, 1e4, torch.tensor([0.2, 0.5, 0.7]))
+    S, _ = helpers.settings_pair(v, K, aa)
+    a = helpers.np_params(p)
+    f = oracle.forward(*a, S)
+    gi = np.random.default_rng(1).standard_normal(f['image'].shape).astype(np.float32)
+    g = oracle.backward(f, S, gi)
+    ref = autograd_reference(dict(means=a[0], scales=a[1], rotations=a[2], opacities=a[3], sh0=a[4], sh_rest=a[5]), S, f, gi)
+    assert np.abs(ref['image'] - f['image']).max() < 5e-6
+    for k in helpers.GRAD_KEYS:
+        assert helpers.rel_inf(g[k], ref[k].reshape(g[k].shape)) < 2e-5, k

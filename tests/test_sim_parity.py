@@ -1,0 +1,159 @@
+"""CPU tests: the product's real kernel sources + C-ABI host code + ctypes glue, compiled for the fiber simulator
+(tests/sim), compared with the oracle on every intermediate. Catches indexing / masking / synchronisation / orchestration
+bugs without a GPU. The simulator shares libm with the oracle and is built with -ffp-contract=off, so almost everything
+is compared bit-exactly; gradients differ only by summation order."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from harness.scenes import View, make_s0
+
+
+def _run(sim_backend, oracle, params, view, K=16, aa=False, bg=None, check_grads=True):
+    S, RS = helpers.settings_pair(view, K, aa, bg)
+    a = helpers.np_params(params)
+    n = a[0].shape[0]
+    res = sim_backend.forward(*[params[k] for k in helpers.NAMES], RS)
+    f = oracle.forward(*a, S, bucket_size=64)
+    dec = helpers.decode_forward(sim_backend, res, n, view.width, view.height)
+    helpers.check_forward_against_oracle(dec, f, True, view.width, view.height, res.image.numpy())
+    if f['B'] > 0:
+        live = np.zeros((f['B'], 192), bool)          # checkpoints of pixels that were not done at that bucket are exact
+        assert dec['B'] == f['B']
+    if not check_grads:
+        return res, f
+    gi = np.random.default_rng(5).standard_normal(f['image'].shape).astype(np.float32)
+    dens_o = np.zeros((2, n), np.float32)
+    g = oracle.backward(f, S, gi, dens_o)
+    dens = torch.zeros(2, n)
+    grads = sim_backend.backward(dens, torch.from_numpy(gi), res.image, params['means'], params['scales'], params['rotations'],
+                                 params['opacities'], params['sh_coefficients_rest'], res.buffers, RS, res.state)
+    for k, t in zip(helpers.GRAD_KEYS, grads):
+        assert helpers.rel_inf(t.numpy().reshape(g[k].shape), g[k]) < 1e-5, k
+    assert helpers.rel_inf(dens.numpy(), dens_o) < 1e-5
+    return res, f
+
+
+def test_wave_primitives_selftest(sim_backend):
+    out = torch.zeros(256, dtype=torch.int32)
+    assert sim_backend.lib.fgs_debug_wave_selftest(out.data_ptr(), None) == 0
+    o, l = out.numpy(), np.arange(64)
+    assert np.array_equal(o[:64], np.where(l == 0, 1000, 99 + l)) and np.array_equal(o[64:128], 1000 + (l + 1) % 64)
+    assert np.array_equal(o[128:192], (l + 2) // 3) and np.all(o[192:] == 2142)
+
+
+def test_s0_all_intermediates(sim_backend, oracle):
+    params, view = make_s0()
+    _run(sim_backend, oracle, params, view)
+
+
+@pytest.mark.parametrize('w,h,K,aa', [(48, 36, 4, True), (50, 30, 16, False), (16, 12, 1, False), (130, 25, 9, True)])
+def test_partial_tiles_sh_degrees_antialiasing(sim_backend, oracle, w, h, K, aa):
+    p, v = make_s0(seed=3, n=150)
+    v = View(v.w2c, v.position, w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, 0.2, 1e4, torch.tensor([0.2, 0.5, 0.7]))
+    _run(sim_backend, oracle, p, v, K, aa)
+
+
+def test_large_footprints_take_the_cooperative_path(sim_backend, oracle):
+    """Gaussians covering > 4 candidate tiles exercise the wave-cooperative branches of preprocess / create_instances."""
+    p, v = make_s0(seed=7, n=200)
+    p['scales'] = p['scales'] + 2.3
+    _, f = _run(sim_backend, oracle, p, v)
+    assert (f['n_touched'] > 4).sum() > 50 and (f['n_touched'] > 68).sum() > 5
+
+
+def test_long_tile_lists_span_several_batches(sim_backend, oracle):
+    """> 192 Gaussians per tile: multiple LDS batches and several buckets per tile."""
+    p, v = make_s0(seed=11, n=1500)
+    p['means'][:, :2] *= 0.15
+    p['opacities'] -= 2.5
+    _, f = _run(sim_backend, oracle, p, v)
+    assert (f['ranges'][:, 1] - f['ranges'][:, 0]).max() > 400
+
+
+def test_empty_and_fully_culled(sim_backend, oracle):
+    params, view = make_s0(n=32)
+    S, RS = helpers.settings_pair(view, bg=(0.1, 0.2, 0.3))
+    empty = {k: v[:0].contiguous() for k, v in params.items()}
+    res = sim_backend.forward(*[empty[k] for k in helpers.NAMES], RS)
+    assert res.state[:2] == (0, 0) and torch.allclose(res.image, torch.tensor([0.1, 0.2, 0.3])[:, None, None].expand(3, 128, 128))
+    grads = sim_backend.backward(torch.empty(0), torch.ones(3, 128, 128), res.image, empty['means'], empty['scales'], empty['rotations'],
+                                 empty['opacities'], empty['sh_coefficients_rest'], res.buffers, RS, res.state)
+    assert all(g.numel() == 0 for g in grads)
+    culled = {k: v.clone() for k, v in params.items()}
+    culled['means'][:, 2] = -10.0
+    res = sim_backend.forward(*[culled[k] for k in helpers.NAMES], RS)
+    assert res.state[:2] == (0, 0)
+    grads = sim_backend.backward(torch.empty(0), torch.ones(3, 128, 128), res.image, culled['means'], culled['scales'], culled['rotations'],
+                                 culled['opacities'], culled['sh_coefficients_rest'], res.buffers, RS, res.state)
+    assert all(float(g.abs().max()) == 0.0 for g in grads)
+
+
+@pytest.mark.parametrize('to_chw,clamp', [(True, True), (False, True), (False, False)])
+def test_inference_variants(sim_backend, oracle, to_chw, clamp):
+    params, view = make_s0()
+    params['sh_coefficients_0'] = params['sh_coefficients_0'] * 3.0      # push colours outside [0,1] so the clamp matters
+    S, RS = helpers.settings_pair(view, bg=(0.3, 0.1, 0.9))
+    img = sim_backend.inference(*[params[k] for k in helpers.NAMES], RS, to_chw, clamp)
+    f = oracle.forward(*helpers.np_params(params), S, inference=True, to_chw=to_chw, clamp_output=clamp)
+    assert np.array_equal(img.numpy(), f['image'])
+
+
+def test_adam_single_and_multi(sim_backend, oracle):
+    rng = np.random.default_rng(0)
+    sizes = [3000, 3000, 45001, 1000, 7, 4000]
+    P = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    G = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    M = [np.zeros(s, np.float32) for s in sizes]; V = [np.zeros(s, np.float32) for s in sizes]
+    tp, tg, tm, tv = ([torch.from_numpy(x.copy()) for x in L] for L in (P, G, M, V))
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
+    for step in (1, 2, 3):
+        for i in range(6):
+            oracle.adam_step(G[i], P[i], M[i], V[i], step, lrs[i])
+        sim_backend.adam_step_multi(tg, tp, tm, tv, [step] * 6, lrs, 0.9, 0.999, 1e-15)
+    for i in range(6):
+        assert np.array_equal(tp[i].numpy(), P[i]) and np.array_equal(tm[i].numpy(), M[i]) and np.array_equal(tv[i].numpy(), V[i])
+    sim_backend.adam_step(tg[4], tp[4], tm[4], tv[4], 4, lrs[4], 0.9, 0.999, 1e-15)
+    oracle.adam_step(G[4], P[4], M[4], V[4], 4, lrs[4])
+    assert np.array_equal(tp[4].numpy(), P[4])
+
+
+@pytest.mark.parametrize('K', [16, 4])
+def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K):
+    """fused == backward -> FusedAdam.step() for all six groups, including invisible Gaussians."""
+    params, view = make_s0(n=400)
+    params['means'][:40, 2] = -10.0                      # some invisible Gaussians: zero grad, moments still decay
+    S, RS = helpers.settings_pair(view, K)
+    order = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
+    ref_p = {k: params[k].clone() for k in order}
+    ref_m = {k: torch.randn_like(params[k]) * 1e-3 for k in order}
+    ref_v = {k: torch.rand_like(params[k]) * 1e-6 for k in order}
+    fus_p, fus_m, fus_v = ({k: d[k].clone() for k in order} for d in (ref_p, ref_m, ref_v))
+    gi = torch.randn(3, view.height, view.width, generator=torch.Generator().manual_seed(2))
+    dens_ref, dens_fus = torch.zeros(2, 400), torch.zeros(2, 400)
+    for step in (1, 2):
+        res = sim_backend.forward(*[ref_p[k] for k in helpers.NAMES], RS)
+        grads = sim_backend.backward(dens_ref, gi, res.image, ref_p['means'], ref_p['scales'], ref_p['rotations'], ref_p['opacities'],
+                                     ref_p['sh_coefficients_rest'], res.buffers, RS, res.state)
+        gmap = dict(zip(helpers.NAMES, grads))
+        sim_backend.adam_step_multi([gmap[k] for k in order], [ref_p[k] for k in order], [ref_m[k] for k in order],
+                                    [ref_v[k] for k in order], [step] * 6, lrs, 0.9, 0.999, 1e-15)
+        res2 = sim_backend.forward(*[fus_p[k] for k in helpers.NAMES], RS)
+        sim_backend.backward_adam_fused(dens_fus, gi, res2.image, [fus_p[k] for k in order], [fus_m[k] for k in order],
+                                        [fus_v[k] for k in order], res2.buffers, RS, res2.state, step, lrs)
+        for k in order:
+            assert torch.equal(fus_p[k], ref_p[k]), (step, k)
+            assert torch.equal(fus_m[k], ref_m[k]) and torch.equal(fus_v[k], ref_v[k]), (step, k)
+    assert torch.equal(dens_ref, dens_fus)
+
+
+def test_error_reporting(sim_backend):
+    params, view = make_s0(n=8)
+    _, RS = helpers.settings_pair(view)
+    bad = RS._replace(width=0)
+    with pytest.raises(RuntimeError, match='image size'):
+        sim_backend.forward(*[params[k] for k in helpers.NAMES], bad)
+    with pytest.raises(RuntimeError, match='contiguous float32'):
+        sim_backend.forward(params['means'].double(), *[params[k] for k in helpers.NAMES[1:]], RS)
