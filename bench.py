@@ -181,11 +181,31 @@ def main():
     W_, H_ = views[0].width, views[0].height
     P_, T_ = W_ * H_, ((W_ + 15) // 16) * ((H_ + 11) // 12)
     K_ = g.active_sh_bases
-    # algorithmic bytes (SURVEY.md 8d / DESIGN.md): dominant kernel = blend backward (K11)
-    bytes_k11 = 76.0 * I + 3076.0 * B + 32.0 * P_
-    k11_ms, k11_calls = prof.get('blend_backward', (0.0, 0))
-    k11_avg_s = (k11_ms / max(k11_calls, 1)) * 1e-3
-    achieved = bytes_k11 / k11_avg_s / 1e9 if k11_avg_s > 0 else 0.0
+    # algorithmic bytes per stage (DESIGN.md 'Measurement'). N Gaussians, V visible, I instances,
+    # B buckets(64), P pixels, T tiles, K active SH bases -- all realised values of the timed views.
+    stage_bytes = {
+        'preprocess': 48.0 * n + (12 * K_ + 56.0) * V,
+        'depth_sort': 68.0 * V,
+        'offsets_scan': 20.0 * V,
+        'create_instances': 40.0 * V + 6.0 * I,
+        'tile_sort': 26.0 * I,
+        'extract_ranges': 2.0 * I + 8.0 * T_,
+        'bucket_scan': 12.0 * T_,
+        'blend_forward': 48.0 * I + 8.0 * T_ + 20.0 * P_ + 3076.0 * B,
+        'stage_pixels': 32.0 * P_,
+        'blend_backward': 76.0 * I + 3076.0 * B,
+        'preprocess_backward': 4.0 * n + 128.0 * V + 56.0 * n,           # + every one of the 14 small gradients written once
+        'sh_rest_backward': 24.0 * K_ * V + 12.0 * (K_ - 1) * n,         # + the [N,K-1,3] gradient written once
+        'adam': 1652.0 * n,
+    }
+    kernel_of = {'preprocess': 'preprocess_kernel<false>', 'blend_backward': 'blend_backward_kernel', 'adam': 'adam_kernel',
+                 'blend_forward': 'blend_kernel<true>', 'create_instances': 'create_instances_kernel<u16>',
+                 'tile_sort': 'rocprim radix_sort_onesweep (u16 keys)', 'sh_rest_backward': 'sh_rest_backward_kernel<false>',
+                 'preprocess_backward': 'preprocess_backward_kernel<false>', 'depth_sort': 'rocprim radix_sort_onesweep (u32 keys)'}
+    per_launch = {k: (v_[0] / max(v_[1], 1)) * (v_[1] / args.steps) for k, v_ in prof.items() if v_[1] > 0}   # ms per step
+    dom = max(per_launch, key=per_launch.get)
+    dom_s = per_launch[dom] * 1e-3
+    achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
     bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
     out = {
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
@@ -194,12 +214,14 @@ def main():
         'config': {'workload': workload + '; full training iteration fwd+bwd+Adam (BASELINE.json configs[2]), L1 loss, '
                                'densification_info updated', 'parallelism': f'view-parallel dp{world}' if world > 1 else 'single GPU',
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_},
-        'roofline': {'bound': 'hbm', 'kernel': 'blend_backward_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_kernel_ms': k11_avg_s * 1e3,
-                     'algorithmic_bytes_per_launch': bytes_k11,
+        'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_kernel_ms': dom_s * 1e3,
+                     'algorithmic_bytes_per_launch': stage_bytes[dom],
+                     'note': 'dominant = longest kernel of the timed region (HIP events on the launch stream); traffic: see profiles/ PMC summaries',
                      'iteration_algorithmic_GB': bytes_iter / 1e9,
                      'iteration_frac_of_hbm_peak': bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         'stage_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+        'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes},
     }
 
     if rank == 0 and not args.no_extras:
@@ -225,12 +247,16 @@ def main():
         for _ in range(2):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
+        be.profile_enable(True)
+        be.profile_read()
         t0 = time.perf_counter()
         reps = 10
         for _ in range(reps):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
         out['fused_train_iters_per_sec'] = reps / (time.perf_counter() - t0)
+        out['fused_stage_ms_per_step'] = {k: v_[0] / reps for k, v_ in be.profile_read().items() if v_[1] > 0}
+        be.profile_enable(False)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -252,7 +252,7 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     int depth_sel = 0;
     { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
-    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.rec, pb.offsets, n_visible, stream)); }
+    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, stream)); }
 
     // K5-K7 (fwd:179-216)
     Carver inst_size(nullptr);

@@ -18,8 +18,8 @@ namespace fgs {
 
 // ---- K2-K4 -------------------------------------------------------------------------------------------------
 struct TouchedFromRec {                  // offsets input: n_touched of the i-th primitive in depth order (kf:211-221)
-    const PrimRec* rec;
-    __host__ __device__ uint32_t operator()(uint32_t prim) const { return rec[prim].n_touched; }
+    const uint32_t* n_touched;           // compact 4-byte array (L2-resident gather), not the 48-byte records
+    __host__ __device__ uint32_t operator()(uint32_t prim) const { return n_touched[prim]; }
 };
 
 size_t depth_sort_temp_bytes(uint32_t n) {
@@ -42,10 +42,10 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
     return hipSuccess;
 }
 
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const PrimRec* rec, uint32_t* offsets,
+hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
                             uint32_t n_visible, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;
-    auto in = rocprim::make_transform_iterator(sorted_prims, TouchedFromRec{rec});
+    auto in = rocprim::make_transform_iterator(sorted_prims, TouchedFromRec{n_touched});
     return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
 }
 

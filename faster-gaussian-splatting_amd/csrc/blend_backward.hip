@@ -6,8 +6,11 @@
 // CDNA4 shape:
 //  * bucket = wavefront = 64 Gaussians: 255 steps serve 64 lanes (reference: 223 steps serve 32), and the forward
 //    pass writes half as many checkpoints.
-//  * the per-step lane shift is DPP wave_shr:1 and the next pixel is injected into lane 0 by the same instruction
-//    (its `old` operand), fed from a register ring rotated with DPP wave_rol:1 -- no LDS, no barrier, no readlane.
+//  * only the 4 values a Gaussian changes (remaining colour, transmittance) travel through the lanes, one in-place DPP
+//    wave_shr:1 each; the next pixel enters at lane 0 from a wave-uniform LDS read, and the 5 per-pixel constants are
+//    read by lane l at LDS slot (step - l) -- conflict-free consecutive slots -- instead of being shifted. The wave's
+//    6.9 KB LDS slice is private: no workgroup barrier anywhere. (v1 shifted all 9 values through a register ring:
+//    ~40 mov/DPP per step; this form needs 8 + 3 LDS reads.)
 //  * per-pixel constants (dL/dC, C_final - T_final*bg, T_final*-(dL/dC . bg), last contributor) are staged ONCE per
 //    backward pass into a tile-major 32-byte record, so each bucket reads 48 B per pixel with three coalesced 16-byte
 //    loads instead of gathering 9 scalars from image-linear arrays per bucket.
@@ -35,19 +38,34 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
     a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1] = c;
 }
 
-constexpr int kNV = 9;   // after.rgb, T, dL/dC.rgb, alpha-common, last contributor
-
 __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward_kernel(const BlendBackwardArgs a) {
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned bucket = blockIdx.x * kBackwardWavesPerBlock + (threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned bucket = blockIdx.x * kBackwardWavesPerBlock + wv;
     const unsigned n_buckets = a.bucket_offsets[a.n_tiles - 1];          // device-side count: no host sync for the grid size
-    if (bucket >= n_buckets) return;                                       // wave-uniform
+    if (bucket >= n_buckets) return;                                       // wave-uniform (no block-level barrier below)
     const unsigned tile = a.bucket_tile[bucket];
     const uint2 range = a.ranges[tile];
     const unsigned tile_n = range.y - range.x;
     const unsigned first = tile == 0 ? 0u : a.bucket_offsets[tile - 1];
     const unsigned tb = bucket - first;
     if (tb * kBucket >= a.max_n_processed[tile]) return;                   // kb:295
+
+    // ---- stage this bucket's 192 pixels in the wave's private LDS slice (kb:349-380): 36 B per pixel ----
+    __shared__ float4 s_init[kBackwardWavesPerBlock][kTilePixels];   // C_final - T_final*bg - C_ckpt (rgb), T_ckpt: injected at lane 0
+    __shared__ float4 s_grad[kBackwardWavesPerBlock][kTilePixels];   // dL/dC rgb, T_final * -(dL/dC . bg): read by lane l at pixel i-l
+    __shared__ unsigned s_last[kBackwardWavesPerBlock][kTilePixels]; // last contributor (0 outside the image)
+    {
+        const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
+        const float4* __restrict__ ck = a.ckpt + (size_t)bucket * kTilePixels;
+#pragma unroll
+        for (int c = 0; c < kTilePixels / kWave; ++c) {
+            const unsigned p = static_cast<unsigned>(c) * kWave + lane;
+            const float4 g = pix[2 * p], cst = pix[2 * p + 1], k = ck[p];
+            s_init[wv][p] = make_float4(cst.x - k.x, cst.y - k.y, cst.z - k.z, k.w);               // kb:371-374
+            s_grad[wv][p] = g;
+            s_last[wv][p] = __float_as_uint(cst.w);
+        }
+    }
 
     const unsigned tp = tb * kBucket + lane;
     const bool valid_prim = tp < tile_n;
@@ -65,48 +83,47 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     }
     const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f;
     const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
-    const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
-    const float4* __restrict__ ck = a.ckpt + (size_t)bucket * kTilePixels;
+    wave_lds_fence();
 
     float d_mx = 0.0f, d_my = 0.0f, d_ca = 0.0f, d_cb = 0.0f, d_cc = 0.0f, d_op = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
-    float state[kNV], feed[kNV];
-#pragma unroll
-    for (int k = 0; k < kNV; ++k) { state[k] = 0.0f; feed[k] = 0.0f; }
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sT = 0.0f;                      // the pixel state travelling through the lanes
+    const bool lane0 = lane == 0;
 
-    for (int chunk = 0; chunk < 4; ++chunk) {
-        if (chunk < 3) {                                                   // lane l stages pixel 64*chunk + l
-            const unsigned p = static_cast<unsigned>(chunk) * kWave + lane;
-            const float4 g = pix[2 * p], c = pix[2 * p + 1], k = ck[p];
-            feed[0] = c.x - k.x; feed[1] = c.y - k.y; feed[2] = c.z - k.z; feed[3] = k.w;      // kb:371-374
-            feed[4] = g.x; feed[5] = g.y; feed[6] = g.z; feed[7] = g.w; feed[8] = c.w;
-        }
-        const int steps = chunk < 3 ? kWave : kWave - 1;
-        for (int s = 0; s < steps; ++s) {
-            pipeline_advance<kNV>(state, feed);                            // kb:383-410 in two DPP ops per value
-            const int idx = chunk * kWave + s - static_cast<int>(lane);    // pixel handled by this lane in this step
-            const unsigned last = __float_as_uint(state[8]);
-            if (!valid_prim || idx < 0 || idx >= kTilePixels || tp >= last) continue;          // kb:412
-            const float dx = mx - (x0 + static_cast<float>(idx & (kTileW - 1)));
-            const float dy = my - (y0 + static_cast<float>(idx >> 4));
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float gauss = __expf(fminf(power, 0.0f));
-            const float alpha = op * gauss;
-            if (alpha < kMinAlphaThreshold) continue;
-            const float T = state[3];
-            const float w = T * alpha;
-            d_c0 += w * state[4] * f0; d_c1 += w * state[5] * f1; d_c2 += w * state[6] * f2;  // kb:426-427
-            state[0] -= w * col0; state[1] -= w * col1; state[2] -= w * col2;                  // kb:429
-            const float oma = 1.0f - alpha;
-            const float oma_rcp = __frcp_rn(fmaxf(oma, kOneMinusAlphaEps));
-            const float dl_dalpha = (T * col0 - state[0] * oma_rcp) * state[4] + (T * col1 - state[1] * oma_rcp) * state[5]
-                                    + (T * col2 - state[2] * oma_rcp) * state[6] + state[7] * oma_rcp;   // kb:434-436
-            d_op += gauss * dl_dalpha;
-            const float h = -alpha * dl_dalpha;
-            const float hh = 0.5f * h;
-            d_ca += hh * (dx * dx); d_cb += hh * (dx * dy); d_cc += hh * (dy * dy);            // kb:443-448
-            d_mx += h * (ca * dx + cb * dy); d_my += h * (cb * dx + cc * dy);                  // kb:449-453
-            state[3] = T * oma;
-        }
+    // software-pipelined LDS reads: the values of step i+1 are requested while step i computes
+    float4 init_next = s_init[wv][0];
+    unsigned last_next = s_last[wv][0];
+    for (int i = 0; i < kTilePixels + kWave - 1; ++i) {
+        // shift the 4 mutable values one lane up (kb:383-393) and inject pixel i at lane 0 (kb:401-410)
+        s0 = wave_shift_up1(s0); s1 = wave_shift_up1(s1); s2 = wave_shift_up1(s2); sT = wave_shift_up1(sT);
+        const float4 init = init_next;
+        const unsigned last = last_next;
+        const int idx = i - static_cast<int>(lane);                        // pixel handled by this lane in this step
+        const int cidx = min(max(idx, 0), kTilePixels - 1);
+        init_next = s_init[wv][i + 1 < kTilePixels ? i + 1 : kTilePixels - 1];   // wave-uniform address: LDS broadcast
+        last_next = s_last[wv][min(max(idx + 1, 0), kTilePixels - 1)];
+        s0 = lane0 ? init.x : s0; s1 = lane0 ? init.y : s1; s2 = lane0 ? init.z : s2; sT = lane0 ? init.w : sT;
+        if (!valid_prim || idx < 0 || idx >= kTilePixels || tp >= last) continue;              // kb:412
+        const float dx = mx - (x0 + static_cast<float>(idx & (kTileW - 1)));
+        const float dy = my - (y0 + static_cast<float>(idx >> 4));
+        const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+        const float gauss = __expf(fminf(power, 0.0f));
+        const float alpha = op * gauss;
+        if (alpha < kMinAlphaThreshold) continue;
+        const float4 g = s_grad[wv][cidx];
+        const float T = sT;
+        const float w = T * alpha;
+        d_c0 += w * g.x * f0; d_c1 += w * g.y * f1; d_c2 += w * g.z * f2;                      // kb:426-427
+        s0 -= w * col0; s1 -= w * col1; s2 -= w * col2;                                        // kb:429
+        const float oma = 1.0f - alpha;
+        const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+        const float dl_dalpha = (T * col0 - s0 * oma_rcp) * g.x + (T * col1 - s1 * oma_rcp) * g.y
+                                + (T * col2 - s2 * oma_rcp) * g.z + g.w * oma_rcp;             // kb:434-436
+        d_op += gauss * dl_dalpha;
+        const float h = -alpha * dl_dalpha;
+        const float hh = 0.5f * h;
+        d_ca += hh * (dx * dx); d_cb += hh * (dx * dy); d_cc += hh * (dy * dy);                // kb:443-448
+        d_mx += h * (ca * dx + cb * dy); d_my += h * (cb * dx + cc * dy);                      // kb:449-453
+        sT = T * oma;
     }
 
     if (valid_prim) {                                                      // kb:459-470

@@ -26,10 +26,11 @@ constexpr int kSubtileH = 4;                  // one wave64 covers a 16x4 strip 
 constexpr int kWave = 64;
 constexpr int kBucket = 64;            // Gaussians per backward bucket = one wavefront (reference: 32 = one warp)
 constexpr int kSeqTiles = 4;           // candidate tiles tested per lane before the wave cooperates (cfg:54)
-constexpr int kPreprocessBlock = 256;
+constexpr int kPreprocessBlock = 512;           // one packed counter atomic per workgroup (see preprocess.hip)
+constexpr int kPreprocessBackwardBlock = 256;
 constexpr int kInstanceBlock = 256;
 constexpr int kBlendBlock = kTilePixels;       // 3 waves
-constexpr int kBackwardWavesPerBlock = 4;      // 4 buckets per 256-thread block
+constexpr int kBackwardWavesPerBlock = 1;      // 1 bucket per 64-thread workgroup: inactive buckets free their slot at once
 constexpr int kXcds = 8;                       // tile -> workgroup mapping keeps image bands on one XCD's L2
 
 }  // namespace fgs

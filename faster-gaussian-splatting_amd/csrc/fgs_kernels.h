@@ -24,7 +24,7 @@ hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_
 size_t depth_sort_temp_bytes(uint32_t n);
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
                           uint32_t n_visible, hipStream_t s);
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const PrimRec* rec, uint32_t* offsets,
+hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
                             uint32_t n_visible, hipStream_t s);
 
 // K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.

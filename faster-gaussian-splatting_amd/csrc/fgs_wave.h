@@ -36,6 +36,20 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
     return v;
 }
 
+// lane l takes lane l-1's value, lane 0 keeps its own (DPP wave_shr:1, in place: one instruction, no copy)
+__device__ __forceinline__ float wave_shift_up1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+
+// LDS written by some lanes of this wave and read by others: DS operations of one wave execute in order, this only stops
+// the compiler from moving the reads above the writes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+
 // One step of the backward pixel pipeline for NV per-pixel values:
 //   feed[]  rotates down by one lane (lane l takes lane l+1, lane 63 takes lane 0)      -- DPP wave_rol:1
 //   state[] shifts up by one lane (lane l takes lane l-1) and lane 0 takes its own feed[] -- DPP wave_shr:1 with

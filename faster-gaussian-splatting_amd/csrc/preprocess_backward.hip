@@ -47,8 +47,8 @@ __device__ __forceinline__ void emit(const bool fused, float* grad_out, float* p
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(kPreprocessBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
-    const unsigned i = blockIdx.x * kPreprocessBlock + threadIdx.x;
+__global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
+    const unsigned i = blockIdx.x * kPreprocessBackwardBlock + threadIdx.x;
     if (i >= a.n) return;
     const Camera cam = load_camera(a.cam);
     const size_t n = a.n;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_backward_kernel(c
 
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);
+    const dim3 grid((a.n + kPreprocessBackwardBlock - 1) / kPreprocessBackwardBlock), block(kPreprocessBackwardBlock);
     if (fused_adam) hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();

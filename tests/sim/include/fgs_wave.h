@@ -51,6 +51,14 @@ template <class Op> inline unsigned sim_reduce(unsigned v, Op op) {
 inline unsigned wave_sum(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a + b; }); }
 inline unsigned wave_max(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
 
+inline float wave_shift_up1(float v) {
+    const unsigned lane = lane_id();
+    const float up = __uint_as_float(static_cast<unsigned>(sim_exchange(__float_as_uint(v), static_cast<int>((lane + 63u) % 64u))));
+    return lane == 0 ? v : up;
+}
+inline void wave_lds_fence() { sim::sync_scope(true); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+
 template <int NV>
 inline void pipeline_advance(float (&state)[NV], float (&feed)[NV]) {
     static_assert(2 * NV <= sim::kSlots, "slot overflow");

@@ -155,6 +155,7 @@ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll(static_cast<long long>(v)); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 inline float unsafeAtomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 
