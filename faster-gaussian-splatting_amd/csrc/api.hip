@@ -237,7 +237,7 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
     PreprocessArgs pa;
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
-    pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters;
+    pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
     pa.n = n; pa.cam = camera_of(*settings, geo);
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
@@ -261,7 +261,8 @@ int run_forward(bool training, const float* means, const float* scales, const fl
     if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
-    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible, stream)); }
+    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.n_touched, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
+                                                                                 pb.keys[depth_sel ^ 1], pb.counters + 2, stream)); }
     int tile_sel = 0;
     { StageScope t(ST_TILE_SORT, stream); FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, geo.end_bit, stream)); }
     // the key double buffer flips together with the value double buffer

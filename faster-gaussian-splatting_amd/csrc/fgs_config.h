@@ -25,6 +25,7 @@ constexpr int kSubtileH = 4;                  // one wave64 covers a 16x4 strip 
 // --- CDNA4 work shapes ---
 constexpr int kWave = 64;
 constexpr int kBucket = 64;            // Gaussians per backward bucket = one wavefront (reference: 32 = one warp)
+constexpr unsigned kHugeFootprint = 1024;   // candidate tiles above which a footprint gets its own workgroup (K1 and K5)
 constexpr int kSeqTiles = 4;           // candidate tiles tested per lane before the wave cooperates (cfg:54)
 constexpr int kPreprocessBlock = 512;           // one packed counter atomic per workgroup (see preprocess.hip)
 constexpr int kPreprocessBackwardBlock = 256;

@@ -14,7 +14,8 @@ struct PreprocessArgs {                 // K1
     const float* sh0; const float* sh_rest;
     PrimRec* rec; uint32_t* n_touched;
     uint32_t* depth_keys; uint32_t* prim_idx;     // compacted (unsorted) visible list
-    uint32_t* counters;                            // [0] n_visible, [1] n_instances
+    uint32_t* counters;                            // [0] n_visible, [1] n_instances (one packed 64-bit word), [2] K5 work list, [3] huge list
+    uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint32_t n;
     CameraArgs cam;
 };
@@ -29,8 +30,9 @@ hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorte
 
 // K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
-hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const PrimRec* rec,
-                                   void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible, hipStream_t s);
+hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const uint32_t* n_touched,
+                                   const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
+                                   uint32_t* big_list, uint32_t* big_count, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
                          uint32_t n_instances, int end_bit, hipStream_t s);
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, hipStream_t s);

@@ -49,7 +49,7 @@ struct alignas(16) PrimRec {
     float cc, opacity, r, g;       // conic.z (c), opacity, colour.rg
     float b;                       // colour.b
     uint32_t bx, by;               // screen bounds: x_min | x_max<<16, y_min | y_max<<16   (ushort4 of kf:168-175)
-    uint32_t n_touched;            // exact number of overlapped tiles
+    uint32_t hit_mask;             // exact-overlap bitmap over the (<= 32) candidate tiles of the bounding box, 0 if larger
 };
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 

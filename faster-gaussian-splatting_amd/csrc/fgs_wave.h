@@ -30,6 +30,14 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// exclusive prefix sum over the wave (Hillis-Steele, 6 cross-lane steps)
+__device__ __forceinline__ unsigned wave_exclusive_sum(unsigned v) {
+    const unsigned lane = lane_id();
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= static_cast<unsigned>(o)) incl += t; }
+    return incl - v;
+}
 __device__ __forceinline__ unsigned wave_max(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(v, o, 64); v = t > v ? t : v; }

@@ -77,10 +77,16 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
         if (wave_ballot(active) != 0) {                                                // kf:181
             // ---- exact tile count (kernel_utils.cuh:117-180), wave64 version ----
             const float sx = m2x - 0.5f, sy = m2y - 0.5f;
+            uint32_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 32
+            // Footprints above kHugeFootprint candidate tiles are counted by preprocess_huge_kernel (a workgroup each):
+            // Morton order keeps the Gaussians nearest to the camera in the same wave, and counting their tens of
+            // thousands of candidates here would stall that wave and the workgroup barrier below for ~0.3 ms.
+            const bool huge = active && n_max > kHugeFootprint;
+            if (huge) active = false;
             if (active) {
                 const unsigned n_seq = n_max < (unsigned)kSeqTiles ? n_max : (unsigned)kSeqTiles;
                 for (unsigned t = 0; t < n_seq; ++t)
-                    cnt += tile_contributes(sx, sy, ca, cb, cc, tx0 + t % tbw, ty0 + t / tbw, power_threshold) ? 1u : 0u;
+                    if (tile_contributes(sx, sy, ca, cb, cc, tx0 + t % tbw, ty0 + t / tbw, power_threshold)) { ++cnt; hit_mask |= 1u << t; }
             }
             uint64_t pending = wave_ballot(active && n_max > (unsigned)kSeqTiles);
             while (pending != 0) {                              // wave-uniform loop over lanes with large footprints
@@ -95,13 +101,15 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
                 for (unsigned base = kSeqTiles; base < o_cnt; base += kWave) {
                     const unsigned t = base + lane;
                     const bool hit = t < o_cnt && tile_contributes(o_sx, o_sy, o_ca, o_cb, o_cc, o_tx0 + t % o_tbw, o_ty0 + t / o_tbw, o_pt);
-                    found += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(wave_ballot(hit))));
+                    const uint64_t hits = wave_ballot(hit);
+                    found += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
+                    if (base == (unsigned)kSeqTiles && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << kSeqTiles);
                 }
                 if (lane == static_cast<unsigned>(src)) cnt += found;
             }
 
             visible = active && cnt > 0;                                               // kf:190
-            if (visible) {
+            if (visible || huge) {
                 float col[3];
                 const float* k = a.sh_rest + (size_t)idx * cam.total_sh_rest * 3;
                 sh_to_color(a.sh0 + 3 * (size_t)idx, k, m[0] - cam.pos[0], m[1] - cam.pos[1], m[2] - cam.pos[2],
@@ -110,7 +118,16 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
                 float4* dst = reinterpret_cast<float4*>(a.rec + idx);
                 dst[0] = make_float4(m2x, m2y, ca, cb);
                 dst[1] = make_float4(cc, opacity, col[0], col[1]);
-                dst[2] = make_float4(col[2], __uint_as_float(bx), __uint_as_float(by), __uint_as_float(cnt));
+                // footprints of <= 32 candidate tiles hand their exact-overlap bitmap to the instance generator (0 = recompute)
+                dst[2] = make_float4(col[2], __uint_as_float(bx), __uint_as_float(by), __uint_as_float(n_max <= 32u ? hit_mask : 0u));
+            }
+            const uint64_t huge_mask = wave_ballot(huge);
+            if (huge_mask != 0) {
+                const int leader = __ffsll(static_cast<unsigned long long>(huge_mask)) - 1;
+                unsigned hbase = 0;
+                if (lane == static_cast<unsigned>(leader)) hbase = atomicAdd(&a.counters[3], static_cast<unsigned>(__popcll(static_cast<unsigned long long>(huge_mask))));
+                hbase = wave_read(hbase, leader);
+                if (huge) a.huge_list[hbase + lanes_below(huge_mask)] = idx;
             }
         }
     }
@@ -145,11 +162,49 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
     }
 }
 
+// Exact tile count + compaction for the few screen-filling footprints: one 256-thread workgroup per Gaussian, 256 candidate
+// tiles per step (kernel_utils.cuh:117-180 with the whole workgroup cooperating instead of one warp).
+__global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessArgs a) {
+    __shared__ unsigned s_cnt[4];
+    const Camera cam = load_camera(a.cam);
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const unsigned n_huge = a.counters[3];
+    for (unsigned h = blockIdx.x; h < n_huge; h += gridDim.x) {            // workgroup-uniform
+        const uint32_t idx = a.huge_list[h];
+        const float4* r = reinterpret_cast<const float4*>(a.rec + idx);
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+        const float sx = r0.x - 0.5f, sy = r0.y - 0.5f;
+        const float pt = logf(r1.y * kMinAlphaThresholdRcp);
+        unsigned tx0, tx1, ty0, ty1;
+        tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
+        const unsigned tbw = tx1 - tx0, count = tbw * (ty1 - ty0);
+        unsigned mine = 0;
+        for (unsigned t = threadIdx.x; t < count; t += 256u)
+            mine += tile_contributes(sx, sy, r0.z, r0.w, r1.x, tx0 + t % tbw, ty0 + t / tbw, pt) ? 1u : 0u;
+        const unsigned wsum = wave_sum(mine);
+        if (lane == 0) s_cnt[wv] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            a.n_touched[idx] = cnt;
+            if (cnt != 0) {
+                const unsigned long long packed = (static_cast<unsigned long long>(cnt) << 32) | 1ull;
+                const unsigned off = static_cast<unsigned>(atomicAdd(reinterpret_cast<unsigned long long*>(a.counters), packed));
+                const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
+                a.depth_keys[off] = __float_as_uint(depth);
+                a.prim_idx[off] = idx;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);
     if (inference) hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(preprocess_huge_kernel, dim3(a.n < 1024u ? a.n : 1024u), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -7,10 +7,10 @@
 //  * geometry kernel: one lane per Gaussian for the 14 "small" floats (means, scales, rotations, opacity, sh0): 12-16 B
 //    per lane per tensor, contiguous across the wave. It also leaves the unit view direction of visible Gaussians in a
 //    12-byte scratch slot.
-//  * SH-rest kernel: one lane per (Gaussian, basis) pair = 12 contiguous bytes, i.e. the [N,15,3] tensors (parameter,
-//    both Adam moments, gradient) are streamed flat and fully coalesced; the gradient basis_k(dir) * dL/dcolour is
-//    recomputed per pair from the 12-byte direction + 12-byte colour gradient (L1/L2 hits shared by 15 lanes) instead of
-//    being gathered with a 180-byte per-lane stride as in the reference.
+//  * SH-rest kernel: the [N,15,3] tensors (parameter, both Adam moments, gradient) are streamed flat in 16-byte pieces by
+//    a grid-stride loop; the gradient basis_k(dir) * dL/dcolour is recomputed per (Gaussian, basis) pair from the 12-byte
+//    direction + 12-byte colour gradient (L1/L2 hits shared by neighbouring lanes) instead of being gathered with a
+//    180-byte per-lane stride as in the reference.
 //  * every element of every gradient is written (zeros for invisible Gaussians), which replaces the reference's eight
 //    torch::zeros fills (rasterization_api.cu:127-134, 256 B per Gaussian).
 //  * fused mode never materialises the 59-float gradient: Adam is applied in registers. Invisible Gaussians still
@@ -30,21 +30,10 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const 
     v = m2;
 }
 
-template <int W>
-__device__ __forceinline__ void emit(const bool fused, float* grad_out, float* p, float* m, float* v, const AdamHyper& h,
-                                     const size_t idx, const float (&g)[W]) {
-    if (!fused) {
-#pragma unroll
-        for (int k = 0; k < W; ++k) grad_out[idx * W + k] = g[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < W; ++k) {
-            float pp = p[idx * W + k], mm = m[idx * W + k], vv = v[idx * W + k];
-            adam_update(pp, mm, vv, g[k], h);
-            p[idx * W + k] = pp; m[idx * W + k] = mm; v[idx * W + k] = vv;
-        }
-    }
-}
+// fused mode: the 14 small floats of a Gaussian (kernel group order means 3, sh0 3, opacity 1, scales 3, rotations 4) and
+// their two Adam moments are requested at kernel entry, so the 42 loads are in flight while the gradient is computed.
+constexpr int kGroupWidth[5] = {3, 3, 1, 3, 4};
+constexpr int kGroupOffset[5] = {0, 3, 6, 7, 10};
 
 template <bool FUSED>
 __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
@@ -54,13 +43,26 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
     const size_t n = a.n;
     float g_mean[3] = {0.0f, 0.0f, 0.0f}, g_scale[3] = {0.0f, 0.0f, 0.0f}, g_rot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float g_op[1] = {0.0f}, g_sh0[3] = {0.0f, 0.0f, 0.0f};
+    float st_p[14], st_m[14], st_v[14];
+    if (FUSED) {
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                const size_t e = (size_t)i * kGroupWidth[grp] + k;
+                st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
+            }
+    }
 
     if (a.n_touched[i] != 0) {                                                         // kb:45
         float m[3], s[3], q[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { m[k] = a.means[3 * (size_t)i + k]; s[k] = a.scales[3 * (size_t)i + k]; }
+        for (int k = 0; k < 3; ++k) {
+            m[k] = FUSED ? st_p[0 + k] : a.means[3 * (size_t)i + k];
+            s[k] = FUSED ? st_p[7 + k] : a.scales[3 * (size_t)i + k];
+        }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * (size_t)i + k];
+        for (int k = 0; k < 4; ++k) q[k] = FUSED ? st_p[10 + k] : a.rotations[4 * (size_t)i + k];
         const float gcol[3] = {a.acc[6 * n + i], a.acc[7 * n + i], a.acc[8 * n + i]};
 
         // ---- SH backward w.r.t. sh0 and the view direction (sh_utils.cuh:84-153) ----
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         const float dcov_z = det_rcp_sq * (2.0f * ab * gcy - bb * gcx - aa * gcz);
         g_op[0] = a.acc[5 * n + i];
         if (cam.proper_aa) {                                                           // kb:137-145 (cov2d branch off, cfg:12)
-            const float opacity = sigmoid_f(a.opacities[i]);
+            const float opacity = sigmoid_f(FUSED ? st_p[6] : a.opacities[i]);
             const float det_raw = P.a_raw * P.c_raw - bb;
             g_op[0] = g_op[0] * sqrtf(fmaxf(det_raw / det, 0.0f)) * opacity * (1.0f - opacity);
         }
@@ -180,12 +182,26 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         quat_to_rotation_backward(q[0], q[1], q[2], q[3], dR, g_rot);
     }
 
-    // group order in fused mode: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations
-    emit<3>(FUSED, a.grad_means, a.p[0], a.m[0], a.v[0], a.h[0], i, g_mean);
-    emit<3>(FUSED, a.grad_sh0, a.p[1], a.m[1], a.v[1], a.h[1], i, g_sh0);
-    emit<1>(FUSED, a.grad_opacities, a.p[2], a.m[2], a.v[2], a.h[2], i, g_op);
-    emit<3>(FUSED, a.grad_scales, a.p[3], a.m[3], a.v[3], a.h[3], i, g_scale);
-    emit<4>(FUSED, a.grad_rotations, a.p[4], a.m[4], a.v[4], a.h[4], i, g_rot);
+    // group order: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations. Every element is written (zeros if invisible).
+    float grad[14];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { grad[0 + k] = g_mean[k]; grad[3 + k] = g_sh0[k]; grad[7 + k] = g_scale[k]; }
+    grad[6] = g_op[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) grad[10 + k] = g_rot[k];
+    float* const outs[5] = {a.grad_means, a.grad_sh0, a.grad_opacities, a.grad_scales, a.grad_rotations};
+#pragma unroll
+    for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+        for (int k = 0; k < kGroupWidth[grp]; ++k) {
+            const size_t e = (size_t)i * kGroupWidth[grp] + k;
+            const int o = kGroupOffset[grp] + k;
+            if (!FUSED) outs[grp][e] = grad[o];
+            else {
+                adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
+                a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
+            }
+        }
 }
 
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {
@@ -196,48 +212,116 @@ hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardA
     return hipGetLastError();
 }
 
-// ---- SH-rest pass: one lane per (Gaussian, basis) pair, 12 contiguous bytes per lane --------------------------------
-template <bool FUSED>
-__global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs a) {
-    const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n_pairs = (size_t)a.n * a.total_sh_rest;
-    if (pair >= n_pairs) return;
-    const uint32_t gi = static_cast<uint32_t>(pair / a.total_sh_rest);
-    const uint32_t k = static_cast<uint32_t>(pair - (size_t)gi * a.total_sh_rest);
-    float g[3] = {0.0f, 0.0f, 0.0f};
+// ---- SH-rest pass: the [N, R, 3] tensors are streamed FLAT in 16-byte pieces (grid-stride, a few thousand workgroups) ----
+// A float4 piece starting at element e0 covers exactly the (Gaussian, basis) pairs p0 = e0/3 and p0+1; for each of the two
+// the lane rebuilds basis_k(view_dir) * dL/dcolour (sh_utils.cuh:90-111) from 28 bytes that 15 neighbouring lanes share.
+struct PairGrad { float b; float c[3]; };
+
+template <int RT>
+__device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const uint32_t pair_in, const uint32_t n_pairs) {
+    // All seven loads are issued unconditionally (one memory round trip instead of a dependent chain); the result is
+    // SELECTED to zero for invisible Gaussians / inactive degrees because their view_dir slot is uninitialised scratch.
+    const uint32_t pair = pair_in < n_pairs ? pair_in : n_pairs - 1u;
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t gi = pair / R, k = pair - gi * R;
+    const size_t n = a.n;
+    const uint32_t touched = a.n_touched[gi];
+    const float x = a.view_dir[3 * (size_t)gi], y = a.view_dir[3 * (size_t)gi + 1], z = a.view_dir[3 * (size_t)gi + 2];
+    const float c0 = a.acc[6 * n + gi], c1 = a.acc[7 * n + gi], c2 = a.acc[8 * n + gi];
     // coefficient k belongs to degree 1 (k<3), 2 (k<8), 3 (k<15); it receives a gradient only if that degree is active
     const bool degree_on = (k < 3 && a.active_sh_bases > 1) || (k >= 3 && k < 8 && a.active_sh_bases > 4) ||
                            (k >= 8 && k < 15 && a.active_sh_bases > 9);
-    if (degree_on && a.n_touched[gi] != 0) {
-        const float x = a.view_dir[3 * (size_t)gi], y = a.view_dir[3 * (size_t)gi + 1], z = a.view_dir[3 * (size_t)gi + 2];
-        float B[15];
+    const bool on = pair_in < n_pairs && degree_on && touched != 0;
+    float B[15];
 #pragma unroll
-        for (int j = 0; j < 15; ++j) B[j] = 0.0f;
-        sh_basis(x, y, z, a.active_sh_bases, B);
-        float bk = 0.0f;
+    for (int j = 0; j < 15; ++j) B[j] = 0.0f;
+    sh_basis(x, y, z, a.active_sh_bases, B);
+    float bk = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 15; ++j) bk = (k == static_cast<uint32_t>(j)) ? B[j] : bk;   // select, no dynamic register indexing
-        const size_t n = a.n;
-        g[0] = bk * a.acc[6 * n + gi]; g[1] = bk * a.acc[7 * n + gi]; g[2] = bk * a.acc[8 * n + gi];   // sh_utils.cuh:90-111
-    }
-    if (!FUSED) {
-        a.grad_sh_rest[3 * pair] = g[0]; a.grad_sh_rest[3 * pair + 1] = g[1]; a.grad_sh_rest[3 * pair + 2] = g[2];
-    } else {
+    for (int j = 0; j < 15; ++j) bk = (k == static_cast<uint32_t>(j)) ? B[j] : bk;   // select, no dynamic register indexing
+    PairGrad r;
+    r.b = on ? bk : 0.0f;
+    r.c[0] = on ? c0 : 0.0f; r.c[1] = on ? c1 : 0.0f; r.c[2] = on ? c2 : 0.0f;
+    return r;
+}
+
+// Unfused form: one lane per (Gaussian, basis) pair writes its 12 bytes (one basis evaluation per 12 B; the float4 form
+// below needs two per 16 B and measured slower for a pure 540 MB write), two pairs per lane for memory-level parallelism.
+template <int RT>
+__global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs a) {
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t n_pairs = a.n * R;
+    const uint32_t p0 = blockIdx.x * 512u + threadIdx.x, p1 = p0 + 256u;
+    const PairGrad q0 = pair_gradient<RT>(a, p0, n_pairs), q1 = pair_gradient<RT>(a, p1, n_pairs);
+    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = q0.b * q0.c[0]; o[1] = q0.b * q0.c[1]; o[2] = q0.b * q0.c[2]; }
+    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = q1.b * q1.c[0]; o[1] = q1.b * q1.c[1]; o[2] = q1.b * q1.c[2]; }
+}
+
+template <bool FUSED, int RT>
+__global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs a) {
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t n_pairs = a.n * R;
+    const uint32_t n_elems = n_pairs * 3u;                 // host guarantees < 2^32
+    const uint32_t n_vec = (n_elems + 3u) / 4u;
+    for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < n_vec; v += gridDim.x * 256u) {
+        const uint32_t e0 = 4u * v;
+        const uint32_t p0 = e0 / 3u, c0 = e0 - 3u * p0;
+        const bool full = e0 + 4u <= n_elems;
+        float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), m4 = p4, v4 = p4;
+        if (FUSED && full) {                     // request the 48 bytes of state before the gradient is rebuilt
+            p4 = *reinterpret_cast<const float4*>(a.p + e0);
+            m4 = *reinterpret_cast<const float4*>(a.m + e0);
+            v4 = *reinterpret_cast<const float4*>(a.v + e0);
+        }
+        const PairGrad q0 = pair_gradient<RT>(a, p0, n_pairs), q1 = pair_gradient<RT>(a, p0 + 1u, n_pairs);
+        float g[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float pp = a.p[3 * pair + c], mm = a.m[3 * pair + c], vv = a.v[3 * pair + c];
-            adam_update(pp, mm, vv, g[c], a.h);
-            a.p[3 * pair + c] = pp; a.m[3 * pair + c] = mm; a.v[3 * pair + c] = vv;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cj = c0 + static_cast<uint32_t>(j);               // 0..5: first pair while < 3
+            const PairGrad& q = cj < 3u ? q0 : q1;
+            const uint32_t c = cj < 3u ? cj : cj - 3u;
+            g[j] = q.b * (c == 0u ? q.c[0] : (c == 1u ? q.c[1] : q.c[2]));
+        }
+        if (full) {
+            if (!FUSED) {
+                *reinterpret_cast<float4*>(a.grad_sh_rest + e0) = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+                adam_update(p4.x, m4.x, v4.x, g[0], a.h); adam_update(p4.y, m4.y, v4.y, g[1], a.h);
+                adam_update(p4.z, m4.z, v4.z, g[2], a.h); adam_update(p4.w, m4.w, v4.w, g[3], a.h);
+                *reinterpret_cast<float4*>(a.p + e0) = p4;
+                *reinterpret_cast<float4*>(a.m + e0) = m4;
+                *reinterpret_cast<float4*>(a.v + e0) = v4;
+            }
+        } else {
+            for (uint32_t j = 0; e0 + j < n_elems; ++j) {
+                if (!FUSED) a.grad_sh_rest[e0 + j] = g[j];
+                else {
+                    float pp = a.p[e0 + j], mm = a.m[e0 + j], vv = a.v[e0 + j];
+                    adam_update(pp, mm, vv, g[j], a.h);
+                    a.p[e0 + j] = pp; a.m[e0 + j] = mm; a.v[e0 + j] = vv;
+                }
+            }
         }
     }
 }
 
 hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s) {
-    const size_t n_pairs = (size_t)a.n * a.total_sh_rest;
-    if (n_pairs == 0) return hipSuccess;
-    const dim3 grid(static_cast<unsigned>((n_pairs + 255) / 256)), block(256);
-    if (fused_adam) hipLaunchKernelGGL(sh_rest_backward_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(sh_rest_backward_kernel<false>, grid, block, 0, s, a);
+    const uint64_t n_elems = (uint64_t)a.n * a.total_sh_rest * 3u;
+    if (n_elems == 0) return hipSuccess;
+    if (n_elems >= (1ull << 32)) return hipErrorInvalidValue;        // 32-bit element indices: N * (K-1) * 3 < 2^32
+    const uint64_t n_vec = (n_elems + 3) / 4;
+    const unsigned blocks = static_cast<unsigned>(n_vec / 256 + 1 < 8192 ? n_vec / 256 + 1 : 8192);   // grid-stride: 32 workgroups per CU
+    const dim3 grid(blocks), block(256);
+    if (!fused_adam) {
+        const uint64_t n_pairs = n_elems / 3;
+        const dim3 pgrid(static_cast<unsigned>((n_pairs + 511) / 512));
+        if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_gradient_kernel<15>, pgrid, block, 0, s, a);
+        else hipLaunchKernelGGL(sh_rest_gradient_kernel<0>, pgrid, block, 0, s, a);
+    } else if (a.total_sh_rest == 15) {
+        hipLaunchKernelGGL((sh_rest_backward_kernel<true, 15>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((sh_rest_backward_kernel<true, 0>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ def decode_forward(be, res, n, width, height):
     out['color'] = rec[:, 6:9]
     bx, by = recu[:, 9], recu[:, 10]
     out['screen_bounds'] = np.stack([bx & 0xffff, bx >> 16, by & 0xffff, by >> 16], 1).astype(np.uint16)
-    out['rec_n_touched'] = recu[:, 11]
+    out['rec_hit_mask'] = recu[:, 11]
     out['n_touched'] = be.view(bufs[0], lp, 'n_touched', torch.int32).numpy().view(np.uint32)
     out['offsets'] = be.view(bufs[0], lp, 'offsets', torch.int32).numpy().view(np.uint32)[:nv]
     for s in (0, 1):

@@ -48,6 +48,16 @@ template <class Op> inline unsigned sim_reduce(unsigned v, Op op) {
     }
     return r;
 }
+inline unsigned wave_exclusive_sum(unsigned v) {
+    const int par = sim::next_parity(true);
+    sim::me().slot[par][0] = v;
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    unsigned r = 0;
+    for (int i = first; i < b.cur; ++i) if (b.lanes[i].gen_wave >= g) r += static_cast<unsigned>(b.lanes[i].slot[par][0]);
+    return r;
+}
 inline unsigned wave_sum(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a + b; }); }
 inline unsigned wave_max(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
 

@@ -21,7 +21,7 @@
 #define __shared__ static
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipMemcpyDeviceToHost = 2, hipHostMallocDefault = 0 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipMemcpyDeviceToHost = 2, hipHostMallocDefault = 0 };
 typedef void* hipStream_t;
 
 struct uint2 { unsigned x, y; };
@@ -152,6 +152,8 @@ inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll(static_cast<long long>(v)); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }

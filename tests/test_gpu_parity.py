@@ -123,6 +123,14 @@ def test_large_footprints_and_long_lists(hip_backend, oracle):
     _grads_close(grads, g)
 
 
+def test_huge_footprints_workgroup_path(hip_backend, oracle):
+    p, v = make_s0(seed=13, n=40)
+    v = View(v.w2c, v.position, 640, 480, 500.0, 500.0, 320.0, 240.0, 0.2, 1e4, torch.zeros(3))
+    p['scales'][:6] = p['scales'][:6] + 3.2
+    p['scales'][6:20] = p['scales'][6:20] + 1.8
+    _forward_check(hip_backend, oracle, p, v)
+
+
 def test_public_operators_autograd_and_fused_adam(hip_backend, oracle):
     """diff_rasterize -> loss.backward() -> FusedAdam.step(): the call sequence of Trainer.py:170-199."""
     from FasterGSCudaBackend import FusedAdam, diff_rasterize

@@ -63,6 +63,18 @@ def test_large_footprints_take_the_cooperative_path(sim_backend, oracle):
     assert (f['n_touched'] > 4).sum() > 50 and (f['n_touched'] > 68).sum() > 5
 
 
+def test_huge_footprints_take_the_workgroup_path(sim_backend, oracle):
+    """> 1024 candidate tiles: the instance generator hands the footprint to create_instances_big_kernel."""
+    p, v = make_s0(seed=13, n=40)
+    v = View(v.w2c, v.position, 640, 480, 500.0, 500.0, 320.0, 240.0, 0.2, 1e4, torch.zeros(3))
+    p['scales'][:6] = p['scales'][:6] + 3.2          # six screen-filling Gaussians
+    p['scales'][6:20] = p['scales'][6:20] + 1.8      # medium ones (33..1024 candidates)
+    _, f = _run(sim_backend, oracle, p, v, check_grads=False)
+    sb = f['screen_bounds'].astype(np.int64)
+    n_max = ((sb[:, 1] + 15) // 16 - sb[:, 0] // 16) * ((sb[:, 3] + 11) // 12 - sb[:, 2] // 12)
+    assert (n_max > 1024).sum() >= 3 and ((n_max > 32) & (n_max <= 1024)).sum() >= 3 and (n_max <= 32).sum() >= 3
+
+
 def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     """> 192 Gaussians per tile: multiple LDS batches and several buckets per tile."""
     p, v = make_s0(seed=11, n=1500)
