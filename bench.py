@@ -107,6 +107,8 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=device)
     be = default_backend()
+    if 'FGS_BACKWARD_VARIANT' in os.environ:      # A/B switch of the blend-backward formulation (debug)
+        be.lib.fgs_debug_set_backward_variant(int(os.environ['FGS_BACKWARD_VARIANT']))
 
     g = T.Gaussians(params, device)
     g.training_setup(training_cameras_extent=5.0)

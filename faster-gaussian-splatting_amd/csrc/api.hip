@@ -499,6 +499,12 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
     return n;
 }
 
+int32_t fgs_debug_set_backward_variant(int32_t variant) {
+    if (variant != 0 && variant != 1) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic) or 1 (strip)");
+    fgs::g_backward_variant = variant;
+    return FGS_OK;
+}
+
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {
     if (!out_device_256) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL output");
     FGS_HIP(launch_wave_selftest(out_device_256, static_cast<hipStream_t>(stream)));

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     // ---- stage this bucket's 192 pixels in the wave's private LDS slice (kb:349-380): 36 B per pixel ----
     __shared__ float4 s_init[kBackwardWavesPerBlock][kTilePixels];   // C_final - T_final*bg - C_ckpt (rgb), T_ckpt: injected at lane 0
     __shared__ float4 s_grad[kBackwardWavesPerBlock][kTilePixels];   // dL/dC rgb, T_final * -(dL/dC . bg): read by lane l at pixel i-l
-    __shared__ unsigned s_last[kBackwardWavesPerBlock][kTilePixels]; // last contributor (0 outside the image)
+    // last contributor, padded by one wave width on both sides: slots outside the tile read 0, so `tp < last` is the only
+    // per-step validity test (no range compare, no index clamp)
+    __shared__ uint32_t s_last[kBackwardWavesPerBlock][kWave + kTilePixels + kWave];
     {
         const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
         const float4* __restrict__ ck = a.ckpt + (size_t)bucket * kTilePixels;
@@ -63,8 +65,10 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
             const float4 g = pix[2 * p], cst = pix[2 * p + 1], k = ck[p];
             s_init[wv][p] = make_float4(cst.x - k.x, cst.y - k.y, cst.z - k.z, k.w);               // kb:371-374
             s_grad[wv][p] = g;
-            s_last[wv][p] = __float_as_uint(cst.w);
+            s_last[wv][kWave + p] = __float_as_uint(cst.w);
         }
+        s_last[wv][lane] = 0u;
+        s_last[wv][kWave + kTilePixels + lane] = 0u;
     }
 
     const unsigned tp = tb * kBucket + lane;
@@ -89,27 +93,28 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sT = 0.0f;                      // the pixel state travelling through the lanes
     const bool lane0 = lane == 0;
 
-    // software-pipelined LDS reads: the values of step i+1 are requested while step i computes
+    // software-pipelined LDS reads: the values of step i+1 are requested while step i computes. Lanes beyond the bucket's
+    // Gaussians carry opacity 0 and fall out at the alpha test, so `tp < last` is the only per-step validity test.
     float4 init_next = s_init[wv][0];
-    unsigned last_next = s_last[wv][0];
+    const uint32_t* my_last = &s_last[wv][kWave - lane];   // slot of pixel (i - lane) at step i is my_last[i]
+    uint32_t last_next = my_last[0];
     for (int i = 0; i < kTilePixels + kWave - 1; ++i) {
         // shift the 4 mutable values one lane up (kb:383-393) and inject pixel i at lane 0 (kb:401-410)
         s0 = wave_shift_up1(s0); s1 = wave_shift_up1(s1); s2 = wave_shift_up1(s2); sT = wave_shift_up1(sT);
         const float4 init = init_next;
-        const unsigned last = last_next;
-        const int idx = i - static_cast<int>(lane);                        // pixel handled by this lane in this step
-        const int cidx = min(max(idx, 0), kTilePixels - 1);
+        const uint32_t last = last_next;
         init_next = s_init[wv][i + 1 < kTilePixels ? i + 1 : kTilePixels - 1];   // wave-uniform address: LDS broadcast
-        last_next = s_last[wv][min(max(idx + 1, 0), kTilePixels - 1)];
+        last_next = my_last[i + 1];
         s0 = lane0 ? init.x : s0; s1 = lane0 ? init.y : s1; s2 = lane0 ? init.z : s2; sT = lane0 ? init.w : sT;
-        if (!valid_prim || idx < 0 || idx >= kTilePixels || tp >= last) continue;              // kb:412
+        if (tp >= last) continue;                                                              // kb:412
+        const int idx = i - static_cast<int>(lane);                        // pixel handled by this lane in this step
         const float dx = mx - (x0 + static_cast<float>(idx & (kTileW - 1)));
         const float dy = my - (y0 + static_cast<float>(idx >> 4));
         const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
         const float gauss = __expf(fminf(power, 0.0f));
         const float alpha = op * gauss;
         if (alpha < kMinAlphaThreshold) continue;
-        const float4 g = s_grad[wv][cidx];
+        const float4 g = s_grad[wv][idx];
         const float T = sT;
         const float w = T * alpha;
         d_c0 += w * g.x * f0; d_c1 += w * g.y * f1; d_c2 += w * g.z * f2;                      // kb:426-427
@@ -140,6 +145,133 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     }
 }
 
+// ---- variant 2: pixel-per-lane ("strip") formulation ---------------------------------------------------------------
+// One 192-thread workgroup per bucket; wave w owns the 16x4 strip w of the tile, lane = pixel (state in registers, like the
+// forward pass). The bucket's 64 Gaussians are staged in LDS; each wave culls them against its strip with one ballot and
+// walks the survivors in depth order. Per surviving Gaussian the 9 per-pixel partial gradients are summed across the wave
+// with 6 DPP-fused adds each (wave_sum_to_lane63) and lane 63 stores them into the wave's LDS slice; at the end 64 lanes
+// add the three slices and issue the 9 global atomics (kb:459-470). Compared with the systolic form it touches only
+// (Gaussian, strip) pairs whose bounding boxes overlap -- about 1.4 of 3 strips per Gaussian -- instead of all 192 pixels.
+__global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const BlendBackwardArgs a) {
+    const unsigned bucket = blockIdx.x;
+    const unsigned n_buckets = a.bucket_offsets[a.n_tiles - 1];
+    if (bucket >= n_buckets) return;                                       // workgroup-uniform
+    const unsigned tile = a.bucket_tile[bucket];
+    const uint2 range = a.ranges[tile];
+    const unsigned tile_n = range.y - range.x;
+    const unsigned first = tile == 0 ? 0u : a.bucket_offsets[tile - 1];
+    const unsigned tb = bucket - first;
+    if (tb * kBucket >= a.max_n_processed[tile]) return;                   // kb:295, workgroup-uniform
+
+    __shared__ float4 s_a[kBucket];                  // mean.x mean.y conic.a conic.b
+    __shared__ float4 s_b[kBucket];                  // conic.c opacity colour.r colour.g (clamped)
+    __shared__ float4 s_c[kBucket];                  // colour.b (clamped), clamp mask bits, bounds x, bounds y
+    __shared__ float s_acc[kTilePixels / kWave][kBucket][12];   // per-wave slice: 9 sums per Gaussian (padded to 48 B)
+    __shared__ uint32_t s_prim[kBucket];
+
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const unsigned n_here = min(static_cast<unsigned>(kBucket), tile_n - tb * kBucket);
+    if (tid < kBucket) {
+        float4 ga = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gb = ga, gc = ga;
+        uint32_t prim = 0;
+        if (tid < n_here) {
+            prim = a.inst_prims[range.x + tb * kBucket + tid];
+            const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const unsigned fm = (r1.z >= 0.0f ? 1u : 0u) | (r1.w >= 0.0f ? 2u : 0u) | (r2.x >= 0.0f ? 4u : 0u);   // kb:313-318
+            ga = r0;
+            gb = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
+            gc = make_float4(fmaxf(r2.x, 0.0f), __uint_as_float(fm), r2.y, r2.z);
+        }
+        s_a[tid] = ga; s_b[tid] = gb; s_c[tid] = gc; s_prim[tid] = prim;
+    }
+    for (unsigned e = tid; e < (kTilePixels / kWave) * kBucket * 12; e += kTilePixels) (&s_acc[0][0][0])[e] = 0.0f;
+
+    // this lane's pixel (same mapping as the forward pass) and its per-pixel constants / checkpointed state
+    const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+    const unsigned lx = (lane >> 5) * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
+    const unsigned local = ly * kTileW + lx;
+    const float pxf = static_cast<float>(tile_x * kTileW + lx) + 0.5f, pyf = static_cast<float>(tile_y * kTileH + ly) + 0.5f;
+    const float4 g = a.pixrec[((size_t)tile * kTilePixels + local) * 2];
+    const float4 cst = a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1];
+    const float4 ck = a.ckpt[(size_t)bucket * kTilePixels + local];
+    float s0 = cst.x - ck.x, s1 = cst.y - ck.y, s2 = cst.z - ck.z, sT = ck.w;                  // kb:371-374
+    const unsigned last = __float_as_uint(cst.w);                                               // 0 outside the image
+    const unsigned strip_y0 = tile_y * kTileH + wave * kSubtileH, strip_y1 = strip_y0 + kSubtileH;
+    const unsigned strip_x0 = tile_x * kTileW, strip_x1 = strip_x0 + kTileW;
+    __syncthreads();
+
+    bool overlaps = false;
+    if (lane < n_here) {
+        const uint32_t bx = __float_as_uint(s_c[lane].z), by = __float_as_uint(s_c[lane].w);
+        overlaps = (bx & 0xffffu) < strip_x1 && strip_x0 < (bx >> 16) && (by & 0xffffu) < strip_y1 && strip_y0 < (by >> 16);
+    }
+    uint64_t pending = wave_ballot(overlaps);
+    // Gaussians at or beyond every pixel's last contributor cannot contribute (kb:412): trim with the wave maximum
+    const unsigned wave_last = wave_max(last);
+    while (pending != 0) {                                                 // wave-uniform, depth order
+        const int j = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+        pending &= pending - 1;
+        const unsigned tp = tb * kBucket + static_cast<unsigned>(j);
+        if (tp >= wave_last) break;
+        const float4 ga = s_a[j], gb = s_b[j], gc = s_c[j];
+        const float dx = ga.x - pxf, dy = ga.y - pyf;
+        const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+        const float gauss = __expf(fminf(power, 0.0f));
+        const float alpha = gb.y * gauss;
+        const bool contrib = tp < last && alpha >= kMinAlphaThreshold;
+        if (wave_ballot(contrib) == 0) continue;
+        float p_c0 = 0.0f, p_c1 = 0.0f, p_c2 = 0.0f, p_op = 0.0f, p_ca = 0.0f, p_cb = 0.0f, p_cc = 0.0f, p_mx = 0.0f, p_my = 0.0f;
+        if (contrib) {
+            const unsigned fm = __float_as_uint(gc.y);
+            const float T = sT, w = T * alpha;
+            p_c0 = (fm & 1u) ? w * g.x : 0.0f; p_c1 = (fm & 2u) ? w * g.y : 0.0f; p_c2 = (fm & 4u) ? w * g.z : 0.0f;   // kb:426-427
+            s0 -= w * gb.z; s1 -= w * gb.w; s2 -= w * gc.x;                                                            // kb:429
+            const float oma = 1.0f - alpha;
+            const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+            const float dl_dalpha = (T * gb.z - s0 * oma_rcp) * g.x + (T * gb.w - s1 * oma_rcp) * g.y
+                                    + (T * gc.x - s2 * oma_rcp) * g.z + g.w * oma_rcp;                                 // kb:434-436
+            p_op = gauss * dl_dalpha;
+            const float h = -alpha * dl_dalpha, hh = 0.5f * h;
+            p_ca = hh * (dx * dx); p_cb = hh * (dx * dy); p_cc = hh * (dy * dy);                                      // kb:443-448
+            p_mx = h * (ga.z * dx + ga.w * dy); p_my = h * (ga.w * dx + gb.x * dy);                                   // kb:449-453
+            sT = T * oma;
+        }
+        p_mx = wave_sum_to_lane63(p_mx); p_my = wave_sum_to_lane63(p_my);
+        p_ca = wave_sum_to_lane63(p_ca); p_cb = wave_sum_to_lane63(p_cb); p_cc = wave_sum_to_lane63(p_cc);
+        p_op = wave_sum_to_lane63(p_op);
+        p_c0 = wave_sum_to_lane63(p_c0); p_c1 = wave_sum_to_lane63(p_c1); p_c2 = wave_sum_to_lane63(p_c2);
+        if (lane == 63u) {
+            float4* dst = reinterpret_cast<float4*>(&s_acc[wave][j][0]);
+            dst[0] = make_float4(p_mx, p_my, p_ca, p_cb);
+            dst[1] = make_float4(p_cc, p_op, p_c0, p_c1);
+            s_acc[wave][j][8] = p_c2;
+        }
+    }
+    __syncthreads();
+
+    if (tid < n_here) {                                                    // kb:459-470
+        float t[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[k] = s_acc[0][tid][k] + s_acc[1][tid][k] + s_acc[2][tid][k];
+        const uint32_t prim = s_prim[tid];
+        const float op = s_b[tid].y;
+        const size_t n = a.n;
+        unsafeAtomicAdd(a.acc + prim, t[0]);
+        unsafeAtomicAdd(a.acc + n + prim, t[1]);
+        unsafeAtomicAdd(a.acc + 2 * n + prim, t[2]);
+        unsafeAtomicAdd(a.acc + 3 * n + prim, t[3]);
+        unsafeAtomicAdd(a.acc + 4 * n + prim, t[4]);
+        unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? t[5] : op * (1.0f - op) * t[5]);
+        unsafeAtomicAdd(a.acc + 6 * n + prim, t[6]);
+        unsafeAtomicAdd(a.acc + 7 * n + prim, t[7]);
+        unsafeAtomicAdd(a.acc + 8 * n + prim, t[8]);
+    }
+}
+
+int g_backward_variant = 0;   // 0: systolic (lane = Gaussian, default: 0.70 ms at S2), 1: strip (lane = pixel: 0.85 ms, the 81
+                              // reduction instructions per (Gaussian, strip) pair outweigh the culled pairs); fgs_debug_set_backward_variant()
+
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
     return hipGetLastError();
@@ -147,6 +279,10 @@ hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
 
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
     if (a.n_buckets_cap == 0) return hipSuccess;
+    if (g_backward_variant == 1) {
+        hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(a.n_buckets_cap), dim3(kTilePixels), 0, s, a);
+        return hipGetLastError();
+    }
     const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
     hipLaunchKernelGGL(blend_backward_kernel, grid, block, 0, s, a);
     return hipGetLastError();

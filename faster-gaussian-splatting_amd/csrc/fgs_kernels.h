@@ -91,6 +91,7 @@ struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_a
 struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);   // K13, all groups in one launch
 
+extern int g_backward_variant;                                  // 0 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 
 }  // namespace fgs

@@ -44,6 +44,22 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
     return v;
 }
 
+// Sum over the 64 lanes, result valid in lane 63 only: 4 row_shr scan steps inside each 16-lane row, then row_bcast:15 /
+// row_bcast:31 carry the row totals upward (6 DPP-fused adds; the gfx9 wave-reduction idiom).
+template <int CTRL, int ROW_MASK, bool ZERO_FILL>
+__device__ __forceinline__ float dpp_read(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, ZERO_FILL));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp_read<0x111 /*row_shr:1*/, 0xf, true>(v);
+    v += dpp_read<0x112 /*row_shr:2*/, 0xf, true>(v);
+    v += dpp_read<0x114 /*row_shr:4*/, 0xf, true>(v);
+    v += dpp_read<0x118 /*row_shr:8*/, 0xf, true>(v);
+    v += dpp_read<0x142 /*row_bcast:15*/, 0xa, false>(v);
+    v += dpp_read<0x143 /*row_bcast:31*/, 0xc, false>(v);
+    return v;
+}
+
 // lane l takes lane l-1's value, lane 0 keeps its own (DPP wave_shr:1, in place: one instruction, no copy)
 __device__ __forceinline__ float wave_shift_up1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));

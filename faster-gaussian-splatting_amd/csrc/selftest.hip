@@ -18,8 +18,10 @@ __global__ void __launch_bounds__(kWave) wave_selftest_kernel(uint32_t* out) {
     const int src = __ffsll(static_cast<unsigned long long>(m >> 7)) - 1 + 7;   // first multiple of 3 at or above 7 -> 9
     const unsigned shifted = static_cast<unsigned>(wave_shift_up1(static_cast<float>(lane + 10u)));   // lane 0: 10, lane l: 9 + l
     const unsigned shift_ok = shifted == (lane == 0 ? 10u : 9u + lane) ? 0u : 1000000u;
+    const float red = wave_sum_to_lane63(static_cast<float>(lane) * 0.5f + 1.0f);                   // 0.5 * 2016 + 64 = 1072
+    const unsigned red_ok = (lane != 63u || red == 1072.0f) ? 0u : 4000000u;
     const unsigned scan_ok = wave_exclusive_sum(lane + 1u) == lane * (lane + 1u) / 2u ? 0u : 2000000u;
-    out[192 + lane] = wave_read(lane * 7u, src) + wave_sum(lane) + wave_max(lane ^ 5u) + shift_ok + scan_ok;   // 63 + 2016 + 63
+    out[192 + lane] = wave_read(lane * 7u, src) + wave_sum(lane) + wave_max(lane ^ 5u) + shift_ok + scan_ok + red_ok;   // 63 + 2016 + 63
 }
 
 hipError_t launch_wave_selftest(uint32_t* out, hipStream_t s) {

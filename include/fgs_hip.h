@@ -132,6 +132,9 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries);
  * tests/test_gpu_parity.py checks against the expected pattern. which == FGS_BUF_COUNT in fgs_blob_layout describes the
  * backward scratch buffer. */
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
+/* Selects the blend-backward formulation: 0 = systolic (lane = Gaussian), 1 = strip (lane = pixel, default). A/B switch for
+ * tests and bench; both must give the same gradients. */
+int32_t fgs_debug_set_backward_variant(int32_t variant);
 
 #ifdef __cplusplus
 }

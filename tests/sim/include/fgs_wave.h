@@ -61,6 +61,16 @@ inline unsigned wave_exclusive_sum(unsigned v) {
 inline unsigned wave_sum(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a + b; }); }
 inline unsigned wave_max(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
 
+inline float wave_sum_to_lane63(float v) {   // valid in lane 63 only on hardware; the stand-in returns the total everywhere else too
+    const int par = sim::next_parity(true);
+    sim::me().slot[par][0] = __float_as_uint(v);
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& b = sim::blk();
+    const int first = (b.cur / 64) * 64;
+    float r = 0.0f;
+    for (int i = first; i < std::min(first + 64, b.n); ++i) if (b.lanes[i].gen_wave >= g) r += __uint_as_float(static_cast<unsigned>(b.lanes[i].slot[par][0]));
+    return (b.cur - first) == 63 ? r : -12345.0f;   // poison the other lanes so misuse shows up in the parity tests
+}
 inline float wave_shift_up1(float v) {
     const unsigned lane = lane_id();
     const float up = __uint_as_float(static_cast<unsigned>(sim_exchange(__float_as_uint(v), static_cast<int>((lane + 63u) % 64u))));

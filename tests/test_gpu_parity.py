@@ -108,6 +108,23 @@ def test_partial_tiles_sh_degrees_antialiasing(hip_backend, oracle, w, h, K, aa)
     assert helpers.rel_inf(dens.cpu().numpy(), dens_o) < 1e-4
 
 
+@pytest.mark.parametrize('variant', [0, 1])
+def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant):
+    """Both formulations of K11 (0 systolic lane=Gaussian, 1 strip lane=pixel) against the oracle on a deep scene."""
+    p, v = make_s0(seed=11, n=1500)
+    p['means'][:, :2] *= 0.3
+    hip_backend.lib.fgs_debug_set_backward_variant(variant)
+    try:
+        res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+        gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32)
+        g = oracle.backward(f, S, gi)
+        grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                     dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+        _grads_close(grads, g)
+    finally:
+        hip_backend.lib.fgs_debug_set_backward_variant(1)
+
+
 def test_large_footprints_and_long_lists(hip_backend, oracle):
     p, v = make_s0(seed=7, n=200)
     p['scales'] = p['scales'] + 2.3

@@ -84,6 +84,17 @@ def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     assert (f['ranges'][:, 1] - f['ranges'][:, 0]).max() > 400
 
 
+def test_systolic_backward_variant(sim_backend, oracle):
+    """The default is the strip formulation; the systolic one stays selectable and must give the same gradients."""
+    sim_backend.lib.fgs_debug_set_backward_variant(0)
+    try:
+        p, v = make_s0(seed=11, n=600)
+        p['means'][:, :2] *= 0.3
+        _run(sim_backend, oracle, p, v)
+    finally:
+        sim_backend.lib.fgs_debug_set_backward_variant(1)
+
+
 def test_empty_and_fully_culled(sim_backend, oracle):
     params, view = make_s0(n=32)
     S, RS = helpers.settings_pair(view, bg=(0.1, 0.2, 0.3))
