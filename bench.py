@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark of the MI355X FasterGS hot path (contract: see the task statement / DESIGN.md 'Measurement').
 
 One "step" = one full training iteration of the reference (Trainer.py:170-199): lr update -> diff_rasterize forward ->
-L1 loss -> backward -> FusedAdam.step -> zero_grad, on one 1920x1080 view of the synthetic garden-like scene
+0.8*L1 + 0.2*DSSIM loss -> backward -> FusedAdam.step -> zero_grad, on one 1920x1080 view of the synthetic garden-like scene
 (scene S2 = 3 M Gaussians by default). With N GPUs every rank renders a different orbit view of the
 same replicated scene and gradients are summed over ranks with one RCCL all-reduce per step (view-parallel, weak scaling).
 
@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / fused side measurements')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
+    ap.add_argument('--dp-mode', default='zero1', choices=['zero1', 'allreduce'], help='gradient exchange of the view-parallel step (N > 1)')
     return ap.parse_args()
 
 
@@ -97,14 +98,13 @@ def main():
     import torch.distributed as dist
     from FasterGSCudaBackend import FusedRasterizerOptimizer
     from FasterGSCudaBackend._backend import default_backend
-    from FasterGSCudaBackend import rasterization as R
     from harness import trainer as T
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         dist.init_process_group('nccl', device_id=device)
     be = default_backend()
     if 'FGS_BACKWARD_VARIANT' in os.environ:      # A/B switch of the blend-backward formulation (debug)
@@ -135,25 +135,23 @@ def main():
             del res
         del pert
 
-    # view-parallel gradient exchange: all six gradients live in ONE contiguous arena -> one RCCL all-reduce per step
-    hook = None
-    if world > 1:
-        sizes = [p.numel() for p in g.tensors()]
-        arena = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-        offs = np.cumsum([0] + sizes)
-        views_of = [arena[offs[i]:offs[i + 1]].view(p.shape) for i, p in enumerate(g.tensors())]
-        R.set_gradient_buffers(lambda: views_of)
-
-        def hook():
-            if all(p.grad is not None and p.grad.data_ptr() == v_.data_ptr() for p, v_ in zip(g.tensors(), views_of)):
-                dist.all_reduce(arena)
-            else:   # autograd copied a gradient: exchange tensor by tensor
-                for p in g.tensors():
-                    dist.all_reduce(p.grad)
+    # N > 1 (or any torch.distributed.run launch): view-parallel step of harness/distributed.py -- parameters and gradients live
+    # in ONE contiguous arena each, so a step costs one reduce-scatter + one all-gather (zero1: Adam on 1/N of the arena per
+    # rank) or one all-reduce. The rasterizer is called through the backend directly (no autograd copies of the 708 MB arena).
+    launched_distributed = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    vp = None
+    if launched_distributed:
+        from harness.distributed import ViewParallelTrainer
+        lr = T.GARDEN_LR
+        vp = ViewParallelTrainer(be, {k: getattr(g, k).detach() for k in T.PARAM_ORDER},
+                                 {'means': lr['means_init'] * 5.0, **{k: lr[k] for k in T.PARAM_ORDER[1:]}}, mode=args.dp_mode)
 
     def step(i: int) -> None:
         v = my_views[i % len(my_views)]
-        T.training_iteration(g, v, targets[id(v)], i, loss_scale=1.0 / world, before_step=hook)
+        if vp is None:
+            T.training_iteration(g, v, targets[id(v)], i)
+        else:
+            vp.step(T.extract_settings(v, g.active_sh_bases, v.background_color), targets[id(v)])
 
     def fence():
         if world > 1:
@@ -199,6 +197,7 @@ def main():
         'preprocess_backward': 4.0 * n + 128.0 * V + 56.0 * n,           # + every one of the 14 small gradients written once
         'sh_rest_backward': 24.0 * K_ * V + 12.0 * (K_ - 1) * n,         # + the [N,K-1,3] gradient written once
         'adam': 1652.0 * n,
+        'l1_dssim_loss': (24.0 + 36.0 + 48.0) * P_,       # fwd: x,y in + 3 maps out; bwd: 3 maps + x,y in, grad out (3 channels)
     }
     kernel_of = {'preprocess': 'preprocess_kernel<false>', 'blend_backward': 'blend_backward_kernel', 'adam': 'adam_kernel',
                  'blend_forward': 'blend_kernel<true>', 'create_instances': 'create_instances_kernel<u16>',
@@ -213,8 +212,8 @@ def main():
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': workload + '; full training iteration fwd+bwd+Adam (BASELINE.json configs[2]), L1 loss, '
-                               'densification_info updated', 'parallelism': f'view-parallel dp{world}' if world > 1 else 'single GPU',
+        'config': {'workload': workload + '; full training iteration fwd+loss+bwd+Adam (BASELINE.json configs[2]), loss 0.8*L1+0.2*DSSIM, '
+                               'densification_info updated', 'parallelism': f'view-parallel dp{world} ({args.dp_mode})' if vp is not None else 'single GPU',
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_},
         'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_kernel_ms': dom_s * 1e3,
@@ -245,7 +244,7 @@ def main():
                                       [1.6e-4 * 5.0, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3])
         tgt = targets[id(v)]
         S = T.extract_settings(v, g.active_sh_bases, v.background_color)
-        grad_fn = lambda img: torch.sign(img - tgt) / img.numel()
+        grad_fn = lambda img: be.l1_dssim(img, tgt, 0.8, 0.2)[1]
         for _ in range(2):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
@@ -267,7 +266,7 @@ def main():
             out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {exc}'}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -188,6 +188,22 @@ class Backend:
                                                  (C.c_double * k)(*[float(x) for x in lrs]), float(beta1), float(beta2), float(eps),
                                                  _stream_of(device)), 'fgs_adam_step_multi')
 
+    def l1_dssim(self, image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2,
+                 with_grad: bool = True):
+        """Fused photometric loss (Loss.py:15-16): returns (loss 0-dim tensor, dloss/dimage or None, (l1, ssim) tensor)."""
+        device = self._check_params((image, target), ('image', 'target'))
+        if image.dim() != 3 or image.shape[0] != 3 or image.shape != target.shape:
+            raise RuntimeError('l1_dssim expects two [3,H,W] tensors')
+        _, h, w = image.shape
+        sums = torch.empty(2, dtype=torch.float32, device=device)
+        grad = torch.empty_like(image) if with_grad else None
+        scratch = torch.empty(int(self.lib.fgs_l1_dssim_scratch_bytes(w, h)), dtype=torch.uint8, device=device)
+        self._check(self.lib.fgs_l1_dssim_loss(image.data_ptr(), target.data_ptr(), w, h, float(lambda_l1), float(lambda_dssim),
+                                               sums.data_ptr(), _ptr(grad), scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_loss')
+        means = sums / float(image.numel())
+        loss = lambda_l1 * means[0] + lambda_dssim * (1.0 - means[1])
+        return loss, grad, means
+
     def profile_enable(self, enable: bool) -> None:
         self.lib.fgs_profile_enable(int(enable))
 

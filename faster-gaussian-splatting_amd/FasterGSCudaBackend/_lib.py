@@ -58,6 +58,8 @@ _SIGNATURES = {
     'fgs_backward_adam_fused': (C.c_int32, [_P] * 2 + [C.POINTER(_P)] * 3 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState),
                                             _I32, C.POINTER(_F64), _F64, _F64, _F64, _P]),
     'fgs_blob_layout': (C.c_int32, [_I32] * 6 + [C.POINTER(BlobEntry), _I32]),
+    'fgs_l1_dssim_scratch_bytes': (C.c_size_t, [_I32, _I32]),
+    'fgs_l1_dssim_loss': (C.c_int32, [_P, _P, _I32, _I32, C.c_float, C.c_float, _P, _P, _P, _P]),
     'fgs_profile_enable': (C.c_int32, [_I32]),
     'fgs_profile_read': (C.c_int32, [C.POINTER(StageTime), _I32]),
     'fgs_debug_wave_selftest': (C.c_int32, [_P, _P]),

@@ -37,10 +37,10 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-stage timing with HIP events recorded on the caller's stream (fgs_profile_enable / fgs_profile_read) ----
 enum Stage { ST_PREPROCESS, ST_DEPTH_SORT, ST_OFFSETS_SCAN, ST_CREATE_INSTANCES, ST_TILE_SORT, ST_RANGES, ST_BUCKET_SCAN,
-             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_COUNT };
+             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_scan", "create_instances", "tile_sort", "extract_ranges",
                                            "bucket_scan", "blend_forward", "stage_pixels", "blend_backward", "preprocess_backward",
-                                           "sh_rest_backward", "adam"};
+                                           "sh_rest_backward", "adam", "l1_dssim_loss"};
 struct StageRecord { int stage; hipEvent_t start, stop; };
 struct Profiler {
     bool enabled = false;
@@ -478,6 +478,24 @@ int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int3
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown buffer %d", which);
     }
     return c.n < max_entries ? c.n : max_entries;
+}
+
+size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height) {
+    if (width <= 0 || height <= 0) return 0;
+    return sizeof(float) * (9 * static_cast<size_t>(width) * static_cast<size_t>(height) + l1_dssim_partials(width, height));
+}
+
+int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
+                          float* sums, float* grad_image, void* scratch, void* stream_) {
+    if (!image || !target || !sums || !scratch || width <= 0 || height <= 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t plane3 = 3 * static_cast<size_t>(width) * static_cast<size_t>(height);
+    LossArgs a{};
+    a.image = image; a.target = target; a.sums = sums; a.grad = grad_image;
+    a.d_mu = static_cast<float*>(scratch); a.d_m11 = a.d_mu + plane3; a.d_m12 = a.d_m11 + plane3; a.partials = a.d_m12 + plane3;
+    a.width = width; a.height = height; a.lambda_l1 = lambda_l1; a.lambda_dssim = lambda_dssim;
+    { StageScope t(ST_LOSS, stream); FGS_HIP(launch_l1_dssim(a, stream)); }
+    return FGS_OK;
 }
 
 int32_t fgs_profile_enable(int32_t enable) {

@@ -2,6 +2,7 @@
 // stage ids K0..K13 refer to SURVEY.md section 2.1.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include "fgs_config.h"
@@ -90,6 +91,18 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
 struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
 struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);   // K13, all groups in one launch
+
+struct LossArgs {                       // fused L1 + DSSIM loss and its image gradient (loss.hip)
+    const float* image; const float* target;   // [3,H,W]
+    float* sums;                                 // [0] sum |x-y|, [1] sum SSIM   (zeroed by the host before the launch)
+    float* grad;                                 // [3,H,W] or nullptr
+    float* d_mu; float* d_m11; float* d_m12;     // scratch derivative maps, [3,H,W] each
+    float* partials;                             // scratch: 2 floats per workgroup of the forward kernel
+    int width, height;
+    float lambda_l1, lambda_dssim;
+};
+size_t l1_dssim_partials(int width, int height);   // number of floats in LossArgs::partials
+hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s);
 
 extern int g_backward_variant;                                  // 0 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);

@@ -3,8 +3,9 @@
 * `Gaussians`        -- the six nn.Parameters + FusedAdam groups/learning rates of Model.py:51-121, 232-260
 * `extract_settings` -- View -> RasterizerSettings, field for field as Renderer.py:19-43
 * `training_iteration` -- the per-iteration call order of Trainer.py:170-199
-Learning rates are the garden configuration's (fastergs_garden.yaml:102-110). The loss is L1 only: the reference's
-0.8*L1 + 0.2*DSSIM needs `fused_dssim`, which lives in NeRFICG, not in the reference repository.
+Learning rates are the garden configuration's (fastergs_garden.yaml:102-110). The loss is the reference's
+0.8*L1 + 0.2*DSSIM (Trainer.py:52-53) through the fused HIP kernels of harness/loss.py (`fused_dssim` itself lives in the
+un-vendored NeRFICG framework; see csrc/loss.hip for what is implemented instead).
 """
 from __future__ import annotations
 
@@ -82,13 +83,19 @@ def l1_loss(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return (image - target).abs().mean()
 
 
+def photometric_loss(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """LAMBDA_L1 * L1 + LAMBDA_DSSIM * DSSIM with the garden weights 0.8 / 0.2 (fastergs_garden.yaml:98-99, Loss.py:15-16)."""
+    from .loss import l1_dssim_loss
+    return l1_dssim_loss(image, target, 0.8, 0.2)
+
+
 def training_iteration(g: Gaussians, view: View, target: torch.Tensor, iteration: int, *, densification_end: int = 14_900,
-                       loss_scale: float = 1.0, before_step=None) -> torch.Tensor:
+                       loss_scale: float = 1.0, before_step=None, loss_fn=photometric_loss) -> torch.Tensor:
     """One optimisation step in the reference's order (Trainer.py:170-199): lr update -> render -> loss -> backward ->
     optimizer.step -> zero_grad. `before_step` (if given) runs between backward and step (gradient exchange hook)."""
     g.update_learning_rate(iteration + 1)
     image = render_image_training(g, view, update_densification_info=iteration < densification_end, bg_color=view.background_color)
-    loss = l1_loss(image, target) * loss_scale
+    loss = loss_fn(image, target) * loss_scale
     loss.backward()
     if before_step is not None:
         before_step()

@@ -221,3 +221,16 @@ def adam_step(grad: np.ndarray, param: np.ndarray, exp_avg: np.ndarray, exp_avg_
         assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
     lib().orc_adam_step(_p(grad), _p(param), _p(exp_avg), _p(exp_avg_sq), C.c_longlong(param.size), int(step),
                         C.c_double(lr), C.c_double(beta1), C.c_double(beta2), C.c_double(eps))
+
+
+def l1_dssim(image: np.ndarray, target: np.ndarray, lambda_l1: float = 0.8, lambda_dssim: float = 0.2, with_grad: bool = True):
+    """Loss of Trainer.py:190-193 / Loss.py:15-16 (restated SSIM, see fgs_oracle.c). Returns (loss, l1, ssim, grad or None)."""
+    L = lib()
+    L.orc_l1_dssim.restype = C.c_float
+    image, target = _f32(image), _f32(target)
+    _, H, W = image.shape
+    grad = np.zeros_like(image) if with_grad else None
+    l1, ssim = C.c_float(0), C.c_float(0)
+    loss = L.orc_l1_dssim(_p(image), _p(target), H, W, C.c_float(lambda_l1), C.c_float(lambda_dssim),
+                          _p(grad) if with_grad else None, C.byref(l1), C.byref(ssim))
+    return float(loss), float(l1.value), float(ssim.value), grad

@@ -44,7 +44,7 @@ struct Block {
     std::vector<Lane> lanes;
     std::vector<char> stacks;
     int n = 0, cur = 0;
-    unsigned block_idx = 0, block_dim = 0, grid_dim = 0;
+    unsigned block_idx = 0, block_idy = 0, block_idz = 0, block_dim = 0, grid_dim = 0, grid_dimy = 1, grid_dimz = 1;
     ucontext_t main_ctx;
     std::function<void()> body;
     unsigned long progress = 0;
@@ -117,16 +117,21 @@ inline int next_parity(bool wave) { Lane& L = me(); return static_cast<int>(((wa
 
 struct Idx3 { unsigned x, y, z; };
 template <class F> inline void launch(dim3 grid, dim3 block, F f) {
-    if (getenv("FGS_SIM_TRACE")) fprintf(stderr, "[sim] launch grid=%u block=%u\n", grid.x, block.x);
-    for (unsigned bi = 0; bi < grid.x; ++bi) run_block(bi, block.x, grid.x, f);
+    if (getenv("FGS_SIM_TRACE")) fprintf(stderr, "[sim] launch grid=%ux%ux%u block=%u\n", grid.x, grid.y, grid.z, block.x);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bi = 0; bi < grid.x; ++bi) {
+                blk().block_idy = by; blk().block_idz = bz; blk().grid_dimy = grid.y; blk().grid_dimz = grid.z;
+                run_block(bi, block.x, grid.x, f);
+            }
 }
 
 }  // namespace sim
 
 #define threadIdx (sim::Idx3{sim::tid(), 0u, 0u})
-#define blockIdx (sim::Idx3{sim::blk().block_idx, 0u, 0u})
+#define blockIdx (sim::Idx3{sim::blk().block_idx, sim::blk().block_idy, sim::blk().block_idz})
 #define blockDim (sim::Idx3{sim::blk().block_dim, 1u, 1u})
-#define gridDim (sim::Idx3{sim::blk().grid_dim, 1u, 1u})
+#define gridDim (sim::Idx3{sim::blk().grid_dim, sim::blk().grid_dimy, sim::blk().grid_dimz})
 
 template <class K, class... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {

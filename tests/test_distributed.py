@@ -55,7 +55,7 @@ def _worker(rank, world, mode, port, out_dir):
 def _single_process_reference():
     _setup_paths()
     import helpers
-    from harness.distributed import SEGMENTS, ViewParallelTrainer, l1_grad
+    from harness.distributed import SEGMENTS, ViewParallelTrainer
     params, settings, targets = _scene()
     be = helpers.sim_backend()
     tr = ViewParallelTrainer(be, params, LRS)          # world 1: used for its arena / Adam plumbing only
@@ -64,7 +64,7 @@ def _single_process_reference():
         tr.step_count += 1
         total = torch.zeros_like(tr.grad_arena)
         for s, t in zip(settings, targets):
-            tr._render_backward(s, lambda img: l1_grad(img, t, 0.5), True)
+            tr._render_backward(s, lambda img: 0.5 * tr.image_gradient(img, t), True)
             total += tr.grad_arena
         tr.grad_arena.copy_(total)
         tr._adam(0, tr.param_arena.numel(), 0)
