@@ -98,6 +98,10 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     float4 init_next = s_init[wv][0];
     const uint32_t* my_last = &s_last[wv][kWave - lane];   // slot of pixel (i - lane) at step i is my_last[i]
     uint32_t last_next = my_last[0];
+    // The step body is branch-free (contributions are gated by selects, not by `continue`) and unrolled twice: the only
+    // loop-carried dependence is the 4-value pixel state, so the scheduler can overlap step i+1's exponent / alpha with
+    // step i's gradient arithmetic -- the kernel is bound by that dependency chain, not by HBM.
+#pragma unroll 2
     for (int i = 0; i < kTilePixels + kWave - 1; ++i) {
         // shift the 4 mutable values one lane up (kb:383-393) and inject pixel i at lane 0 (kb:401-410)
         s0 = wave_shift_up1(s0); s1 = wave_shift_up1(s1); s2 = wave_shift_up1(s2); sT = wave_shift_up1(sT);
@@ -106,15 +110,16 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
         init_next = s_init[wv][i + 1 < kTilePixels ? i + 1 : kTilePixels - 1];   // wave-uniform address: LDS broadcast
         last_next = my_last[i + 1];
         s0 = lane0 ? init.x : s0; s1 = lane0 ? init.y : s1; s2 = lane0 ? init.z : s2; sT = lane0 ? init.w : sT;
-        if (tp >= last) continue;                                                              // kb:412
         const int idx = i - static_cast<int>(lane);                        // pixel handled by this lane in this step
         const float dx = mx - (x0 + static_cast<float>(idx & (kTileW - 1)));
         const float dy = my - (y0 + static_cast<float>(idx >> 4));
         const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-        const float gauss = __expf(fminf(power, 0.0f));
-        const float alpha = op * gauss;
-        if (alpha < kMinAlphaThreshold) continue;
-        const float4 g = s_grad[wv][idx];
+        const float gauss_raw = __expf(fminf(power, 0.0f));
+        const float alpha_raw = op * gauss_raw;
+        const bool contrib = tp < last && alpha_raw >= kMinAlphaThreshold;                     // kb:412,419-421
+        if (wave_ballot(contrib) == 0) continue;                                               // wave-uniform: nothing to do this step
+        const float alpha = contrib ? alpha_raw : 0.0f, gauss = contrib ? gauss_raw : 0.0f;
+        const float4 g = s_grad[wv][min(max(idx, 0), kTilePixels - 1)];
         const float T = sT;
         const float w = T * alpha;
         d_c0 += w * g.x * f0; d_c1 += w * g.y * f1; d_c2 += w * g.z * f2;                      // kb:426-427

@@ -278,9 +278,11 @@ __global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t cj = c0 + static_cast<uint32_t>(j);               // 0..5: first pair while < 3
-            const PairGrad& q = cj < 3u ? q0 : q1;
-            const uint32_t c = cj < 3u ? cj : cj - 3u;
-            g[j] = q.b * (c == 0u ? q.c[0] : (c == 1u ? q.c[1] : q.c[2]));
+            const bool in_first = cj < 3u;                                   // scalar selects only: a pointer/reference select
+            const uint32_t c = in_first ? cj : cj - 3u;                      // between q0 and q1 sends both structs to scratch
+            const float qb = in_first ? q0.b : q1.b;
+            const float qc0 = in_first ? q0.c[0] : q1.c[0], qc1 = in_first ? q0.c[1] : q1.c[1], qc2 = in_first ? q0.c[2] : q1.c[2];
+            g[j] = qb * (c == 0u ? qc0 : (c == 1u ? qc1 : qc2));
         }
         if (full) {
             if (!FUSED) {
