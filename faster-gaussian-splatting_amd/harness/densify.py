@@ -1,0 +1,141 @@
+"""Caller-side maintenance of the Gaussian set, restated from the reference's Model.py with plain
+device-side torch ops: adaptive density control (clone / split / prune), opacity reset, Morton re-ordering, SH degree
+schedule -- including the Adam-state surgery that NeRFICG's `Optim.adam_utils` helpers perform in the reference
+(`extend_param_groups`, `prune_param_groups`, `sort_param_groups`, `replace_param_group_data`; not vendored, semantics as in
+the original 3DGS code base: new entries start with zero moments, pruned/sorted entries keep theirs, replaced data resets
+its moments).
+
+Runs every 100 iterations, not per iteration (Trainer.py:120-139), so it is not a hot-path kernel; it consumes the
+`densification_info[2,N]` statistics that the backward pass accumulates (kernels_backward.cuh:194-201).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .scenes import morton_order
+from .trainer import PARAM_ORDER, Gaussians
+
+GARDEN_SCHEDULE = {  # fastergs_garden.yaml:66-70 / Trainer.py:16-67
+    'densification_start': 600, 'densification_end': 14_900, 'densification_interval': 100, 'grad_threshold': 2.0e-4,
+    'percent_dense': 0.01, 'opacity_reset_interval': 3_000, 'morton_interval': 5_000, 'morton_end': 15_000, 'sh_interval': 1_000,
+}
+
+
+def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
+    q = q / q.norm(dim=1, keepdim=True)
+    r, x, y, z = q.unbind(dim=1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+
+
+def _rebind(g: Gaussians, new: dict, state_fn) -> None:
+    """Replaces the six parameters (and their optimizer state via state_fn(old_state_tensor, name)) in place."""
+    opt = g.optimizer
+    for group in (opt.param_groups if opt is not None else []):
+        name = group['name']
+        old = group['params'][0]
+        param = torch.nn.Parameter(new[name].contiguous())
+        state = opt.state.pop(old, None)
+        if state:
+            opt.state[param] = {'step': state['step'], 'exp_avg': state_fn(state['exp_avg'], name).contiguous(),
+                                'exp_avg_sq': state_fn(state['exp_avg_sq'], name).contiguous()}
+        group['params'][0] = param
+        setattr(g, name, param)
+    if opt is None:
+        for name in PARAM_ORDER:
+            setattr(g, name, torch.nn.Parameter(new[name].contiguous()))
+
+
+def extend(g: Gaussians, extra: dict) -> None:
+    """extend_param_groups: append new Gaussians, their Adam moments start at zero."""
+    new = {k: torch.cat([getattr(g, k).detach(), extra[k]]) for k in PARAM_ORDER}
+    _rebind(g, new, lambda s, k: torch.cat([s, torch.zeros_like(extra[k])]))
+
+
+def prune(g: Gaussians, prune_mask: torch.Tensor) -> None:
+    """Model.py:275-291."""
+    keep = ~prune_mask
+    _rebind(g, {k: getattr(g, k).detach()[keep] for k in PARAM_ORDER}, lambda s, k: s[keep])
+    if g.densification_info is not None:
+        g.densification_info = g.densification_info[:, keep].contiguous()
+
+
+def sort(g: Gaussians, ordering: torch.Tensor) -> None:
+    """Model.py:293-306."""
+    _rebind(g, {k: getattr(g, k).detach()[ordering] for k in PARAM_ORDER}, lambda s, k: s[ordering])
+    if g.densification_info is not None:
+        g.densification_info = g.densification_info[:, ordering].contiguous()
+
+
+def apply_morton_ordering(g: Gaussians) -> None:
+    """Model.py:459-463 (CudaUtils.MortonEncoding replaced by harness.scenes.morton_order)."""
+    sort(g, morton_order(g.means.detach().cpu()).to(g.means.device))
+
+
+def reset_densification_info(g: Gaussians) -> None:
+    g.densification_info = torch.zeros((2, g.means.shape[0]), dtype=torch.float32, device=g.means.device)   # Model.py:308-310
+
+
+def reset_opacities(g: Gaussians) -> None:
+    """Model.py:262-273 (3D filter off): clamp to sigmoid^-1(0.01) and reset the opacity group's moments."""
+    new_op = g.opacities.detach().clamp_max(-4.595119953155518)
+    new = {k: getattr(g, k).detach() for k in PARAM_ORDER}
+    new['opacities'] = new_op
+    _rebind(g, new, lambda s, k: torch.zeros_like(s) if k == 'opacities' else s)
+
+
+def adaptive_density_control(g: Gaussians, grad_threshold: float, min_opacity: float, prune_large_gaussians: bool,
+                             percent_dense: float = 0.01, generator: torch.Generator | None = None) -> dict:
+    """Model.py:312-366: clone small / split large Gaussians whose mean screen-space gradient exceeds the threshold, then prune."""
+    info = g.densification_info
+    extent = g.extent
+    means, scales, rotations = g.means.detach(), g.scales.detach(), g.rotations.detach()
+    opacities, sh0, sh_rest = g.opacities.detach(), g.sh_coefficients_0.detach(), g.sh_coefficients_rest.detach()
+    densification_mask = info[1] >= grad_threshold * info[0].clamp_min(1.0)
+    is_small = scales.max(dim=1).values <= math.log(percent_dense * extent)
+
+    duplicate_mask = densification_mask & is_small
+    split_mask = densification_mask & ~is_small
+    split_scales = scales[split_mask].exp().expand(2, -1, -1).flatten(end_dim=1)
+    split_rotations = rotations[split_mask].expand(2, -1, -1).flatten(end_dim=1)
+    noise = torch.randn(split_scales.shape, generator=generator, device=split_scales.device if generator is None or generator.device.type != 'cpu' else 'cpu').to(split_scales.device)
+    offsets = (quaternion_to_rotation_matrix(split_rotations) @ (split_scales * noise)[..., None])[..., 0]
+    extra = {
+        'means': torch.cat([means[duplicate_mask], means[split_mask].expand(2, -1, -1).flatten(end_dim=1) + offsets]),
+        'sh_coefficients_0': torch.cat([sh0[duplicate_mask], sh0[split_mask].expand(2, -1, -1, -1).flatten(end_dim=1)]),
+        'sh_coefficients_rest': torch.cat([sh_rest[duplicate_mask], sh_rest[split_mask].expand(2, -1, -1, -1).flatten(end_dim=1)]),
+        'opacities': torch.cat([opacities[duplicate_mask], opacities[split_mask].expand(2, -1, -1).flatten(end_dim=1)]),
+        'scales': torch.cat([scales[duplicate_mask], split_scales.mul(0.625).log()]),       # 1 / 1.6 = 0.625
+        'rotations': torch.cat([rotations[duplicate_mask], split_rotations]),
+    }
+    n_new = extra['means'].shape[0]
+    extend(g, extra)
+    g.densification_info = None                                                            # Model.py:353-355
+
+    prune_mask = torch.cat([split_mask, torch.zeros(n_new, dtype=torch.bool, device=means.device)])
+    prune_mask |= g.opacities.detach().flatten() < math.log(min_opacity / (1 - min_opacity))
+    prune_mask |= g.rotations.detach().square().sum(dim=1) < 1e-8
+    if prune_large_gaussians:
+        prune_mask |= g.scales.detach().max(dim=1).values > math.log(0.1 * extent)
+    prune(g, prune_mask)
+    return {'cloned': int(duplicate_mask.sum()), 'split': int(split_mask.sum()), 'pruned': int(prune_mask.sum()), 'total': g.means.shape[0]}
+
+
+def run_callbacks(g: Gaussians, iteration: int, schedule: dict = GARDEN_SCHEDULE, generator: torch.Generator | None = None) -> dict | None:
+    """The per-iteration schedule of Trainer.py:114-165 in priority order (SH degree 110, densify 100, Morton 99, opacity
+    reset 90); call BEFORE training_iteration(iteration) like the reference's callback dispatcher does."""
+    s, out = schedule, None
+    if iteration >= s['sh_interval'] and iteration % s['sh_interval'] == 0:
+        g.increase_used_sh_degree()
+    if s['densification_start'] <= iteration <= s['densification_end'] and (iteration - s['densification_start']) % s['densification_interval'] == 0:
+        out = adaptive_density_control(g, s['grad_threshold'], 0.005, iteration > s['opacity_reset_interval'], s['percent_dense'], generator)
+        if iteration < s['densification_end']:
+            reset_densification_info(g)
+    if iteration <= s['morton_end'] and iteration % s['morton_interval'] == 0:
+        apply_morton_ordering(g)
+    if s['opacity_reset_interval'] <= iteration <= s['densification_end'] and iteration % s['opacity_reset_interval'] == 0:
+        reset_opacities(g)
+    return out

@@ -1,0 +1,88 @@
+"""Adaptive density control / pruning / sorting with Adam-state surgery (reference Model.py:262-366).
+CPU tests of the tensor semantics; the GPU end-to-end run is tests/test_gpu_training.py."""
+import math
+
+import torch
+
+import helpers  # noqa: F401  (sets up import paths)
+from harness import densify as D
+from harness.scenes import make_s0
+from harness.trainer import PARAM_ORDER, Gaussians
+
+
+def _gaussians(n=200):
+    params, _ = make_s0(n=n)
+    g = Gaussians(params, 'cpu')
+    g.training_setup(training_cameras_extent=4.0)
+    for group in g.optimizer.param_groups:           # give every parameter a recognisable optimizer state
+        p = group['params'][0]
+        g.optimizer.state[p] = {'step': 7, 'exp_avg': torch.full_like(p, 0.5), 'exp_avg_sq': torch.full_like(p, 0.25)}
+    return g
+
+
+def test_adaptive_density_control_clone_split_prune():
+    g = _gaussians()
+    n = g.means.shape[0]
+    info = torch.zeros(2, n)
+    info[0] = 10.0
+    info[1, :30] = 10.0 * 1e-3            # mean gradient 1e-3 >= 2e-4: densify the first 30
+    g.densification_info = info
+    with torch.no_grad():
+        g.scales[:10] = math.log(0.5)     # large (> percent_dense * extent = 0.04): split
+        g.scales[10:30] = math.log(0.01)  # small: clone
+        g.opacities[100:105] = -10.0      # nearly transparent: pruned
+        g.rotations[110] = 0.0            # degenerate quaternion: pruned
+    before = {k: getattr(g, k).detach().clone() for k in PARAM_ORDER}
+    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0))
+    assert stats['cloned'] == 20 and stats['split'] == 10
+    assert g.means.shape[0] == n + 20 + 2 * 10 - 10 - 5 - 1 == stats['total']
+    # clones are exact copies; split children are shrunk by 1/1.6 and displaced
+    kept_original = n - 10 - 5 - 1
+    clones = g.means[kept_original:kept_original + 20]
+    assert torch.equal(clones, before['means'][10:30])
+    children = g.scales[kept_original + 20:]
+    assert torch.allclose(children.exp(), torch.full_like(children, 0.5 * 0.625))
+    # Adam state: survivors keep theirs, new entries start at zero, step is preserved
+    for group in g.optimizer.param_groups:
+        st = g.optimizer.state[group['params'][0]]
+        assert st['step'] == 7 and st['exp_avg'].shape == group['params'][0].shape
+        assert torch.all(st['exp_avg'][:kept_original] == 0.5) and torch.all(st['exp_avg'][kept_original:] == 0.0)
+        assert torch.all(st['exp_avg_sq'][:kept_original] == 0.25) and torch.all(st['exp_avg_sq'][kept_original:] == 0.0)
+    assert g.densification_info is None
+    D.reset_densification_info(g)
+    assert g.densification_info.shape == (2, g.means.shape[0])
+
+
+def test_opacity_reset_and_morton_sort():
+    g = _gaussians(64)
+    D.reset_opacities(g)
+    assert float(g.opacities.max()) <= -4.595119953155518 + 1e-6
+    op_state = g.optimizer.state[g.opacities]
+    assert torch.all(op_state['exp_avg'] == 0) and torch.all(g.optimizer.state[g.means]['exp_avg'] == 0.5)
+    means_before = g.means.detach().clone()
+    tag = torch.arange(64, dtype=torch.float32)
+    g.optimizer.state[g.means]['exp_avg'][:, 0] = tag
+    D.apply_morton_ordering(g)
+    perm = g.optimizer.state[g.means]['exp_avg'][:, 0].long()
+    assert sorted(perm.tolist()) == list(range(64)) and torch.equal(g.means.detach(), means_before[perm])
+
+
+def test_callback_schedule_matches_trainer():
+    fired = {'densify': [], 'morton': [], 'reset': [], 'sh': []}
+    g = _gaussians(32)
+    g.active_sh_degree = 0
+    orig = (D.adaptive_density_control, D.apply_morton_ordering, D.reset_opacities)
+    D.adaptive_density_control = lambda *a, **k: fired['densify'].append(cur) or {'total': 0}
+    D.apply_morton_ordering = lambda g_: fired['morton'].append(cur)
+    D.reset_opacities = lambda g_: fired['reset'].append(cur)
+    try:
+        for cur in range(0, 16_001, 100):
+            deg = g.active_sh_degree
+            D.run_callbacks(g, cur)
+            if g.active_sh_degree != deg:
+                fired['sh'].append(cur)
+    finally:
+        D.adaptive_density_control, D.apply_morton_ordering, D.reset_opacities = orig
+    assert fired['densify'][0] == 600 and fired['densify'][-1] == 14_900 and len(fired['densify']) == 144   # Trainer.py:120
+    assert fired['morton'] == [0, 5_000, 10_000, 15_000] and fired['reset'] == [3_000, 6_000, 9_000, 12_000]   # :141,:156
+    assert fired['sh'] == [1_000, 2_000, 3_000]                                                               # :114
