@@ -120,6 +120,20 @@ class Backend:
             return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
         return image
 
+    def pruning_scores(self, scores, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings) -> None:
+        """Accumulates the Speedy-Splat importance scores of one view into `scores` [N] (rasterization.py:159-178)."""
+        device = self._check_params((scores, means, scales, rotations, opacities, sh0, sh_rest),
+                                    ('scores', 'means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest'))
+        if scores.numel() != means.shape[0]:
+            raise RuntimeError('scores must have one entry per Gaussian')
+        keep: list = []
+        S = self._settings(settings, sh_rest.shape[1] if sh_rest.dim() == 3 else 0, device, keep)
+        buffers, cb = self._make_resizer(device, 4)
+        st = _lib.ForwardState()
+        self._check(self.lib.fgs_pruning_scores(_ptr(scores), _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0),
+                                                _ptr(sh_rest), means.shape[0], C.byref(S), cb, None, C.byref(st), _stream_of(device)),
+                    'fgs_pruning_scores')
+
     def _scratch(self, n: int, settings: RasterizerSettings, device: torch.device) -> torch.Tensor:
         nbytes = int(self.lib.fgs_backward_scratch_bytes(n, int(settings.width), int(settings.height)))
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
@@ -203,6 +217,42 @@ class Backend:
         means = sums / float(image.numel())
         loss = lambda_l1 * means[0] + lambda_dssim * (1.0 - means[1])
         return loss, grad, means
+
+    # -- the remaining exported operators (reference torch_bindings/filter3d.py, densification.py) ---------------------------
+    def update_3d_filter(self, positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
+                         near_plane, clipping_tolerance, distance2filter) -> None:
+        device = self._check_params((positions, filter_3d), ('positions', 'filter_3d'))
+        if visibility_mask.dtype != torch.bool or not visibility_mask.is_contiguous() or visibility_mask.device != device:
+            raise RuntimeError('visibility_mask must be a contiguous bool tensor on the same device')
+        w = w2c.to(device=device, dtype=torch.float32).contiguous()
+        self._check(self.lib.fgs_update_3d_filter(_ptr(positions), w.data_ptr(), _ptr(filter_3d), _ptr(visibility_mask), positions.shape[0],
+                                                  int(width), int(height), float(focal_x), float(focal_y), float(center_x), float(center_y),
+                                                  float(near_plane), float(clipping_tolerance), float(distance2filter), _stream_of(device)),
+                    'fgs_update_3d_filter')
+
+    def relocation_adjustment(self, old_opacities, old_scales, n_samples_per_primitive):
+        device = old_opacities.device
+        op = old_opacities.to(torch.float32).contiguous()
+        sc = old_scales.to(torch.float32).contiguous()
+        ns = n_samples_per_primitive.to(device=device, dtype=torch.int64).contiguous()
+        table = getattr(self, '_relocation_table', {}).get(device)
+        if table is None:
+            host = (C.c_float * 2500)()
+            self._check(self.lib.fgs_relocation_table(host), 'fgs_relocation_table')
+            table = torch.tensor(list(host), dtype=torch.float32, device=device)
+            self._relocation_table = {**getattr(self, '_relocation_table', {}), device: table}
+        n = op.shape[0]
+        new_op = torch.empty((n, 1), dtype=torch.float32, device=device)
+        new_sc = torch.empty((n, 3), dtype=torch.float32, device=device)
+        self._check(self.lib.fgs_relocation_adjustment(_ptr(op), _ptr(sc), _ptr(ns), table.data_ptr(), _ptr(new_op), _ptr(new_sc), n,
+                                                       _stream_of(device)), 'fgs_relocation_adjustment')
+        return new_op, new_sc
+
+    def add_noise(self, raw_scales, raw_rotations, raw_opacities, random_samples, means, current_lr: float) -> None:
+        device = self._check_params((raw_scales, raw_rotations, raw_opacities, random_samples, means),
+                                    ('raw_scales', 'raw_rotations', 'raw_opacities', 'random_samples', 'means'))
+        self._check(self.lib.fgs_add_noise(_ptr(raw_scales), _ptr(raw_rotations), _ptr(raw_opacities), _ptr(random_samples), _ptr(means),
+                                           means.shape[0], float(current_lr), _stream_of(device)), 'fgs_add_noise')
 
     def profile_enable(self, enable: bool) -> None:
         self.lib.fgs_profile_enable(int(enable))

@@ -68,3 +68,13 @@ def rasterize(means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor
     _require_gpu(means)
     return default_backend().inference(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest,
                                        rasterizer_settings, to_chw, clamp_output)
+
+
+def update_pruning_scores(scores: torch.Tensor, means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor,
+                          opacities: torch.Tensor, sh_coefficients_0: torch.Tensor, sh_coefficients_rest: torch.Tensor,
+                          rasterizer_settings: RasterizerSettings) -> None:
+    """Speedy-Splat importance scores of one view, accumulated into `scores` (reference rasterization.py:159-178,
+    called per training view from Renderer.py:141-156)."""
+    _require_gpu(means)
+    default_backend().pruning_scores(scores, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest,
+                                     rasterizer_settings)

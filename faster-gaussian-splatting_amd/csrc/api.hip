@@ -207,11 +207,15 @@ AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps
 }
 
 // shared by fgs_forward (training) and fgs_inference
-int run_forward(bool training, const float* means, const float* scales, const float* rotations, const float* opacities,
+enum ForwardMode { MODE_TRAINING, MODE_INFERENCE, MODE_SCORES };
+
+int run_forward(ForwardMode mode, const float* means, const float* scales, const float* rotations, const float* opacities,
                 const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
-                int to_chw, int clamp_output, fgs_resize_fn resize, void* user, fgs_forward_state* state_out, void* stream_) {
+                int to_chw, int clamp_output, fgs_resize_fn resize, void* user, fgs_forward_state* state_out, void* stream_,
+                float* scores = nullptr) {
+    const bool training = mode == MODE_TRAINING;
     if (int rc = check_settings(settings)) return rc;
-    if (n_primitives < 0 || !image || !resize || !state_out) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_primitives=%d)", n_primitives);
+    if (n_primitives < 0 || (!image && mode != MODE_SCORES) || (!scores && mode == MODE_SCORES) || !resize || !state_out) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_primitives=%d)", n_primitives);
     if (n_primitives > 0 && (!means || !scales || !rotations || !opacities || !sh0 || (settings->total_sh_bases_rest > 0 && !sh_rest)))
         return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter tensor");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -286,7 +290,8 @@ int run_forward(bool training, const float* means, const float* scales, const fl
         ba.bucket_offsets = tb.bucket_offsets; ba.final_T = tb.final_T; ba.n_processed = tb.n_processed;
         ba.max_n_processed = tb.max_n_processed; ba.bucket_tile = bb.tile_index; ba.ckpt = bb.ckpt;
     }
-    { StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_blend(training, ba, stream)); }   // K10 (fwd:239)
+    if (mode == MODE_SCORES) { ba.scores = scores; StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_pruning_scores(ba, stream)); }
+    else { StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_blend(training, ba, stream)); }   // K10 (fwd:239)
 
     state_out->n_visible = static_cast<int32_t>(n_visible);
     state_out->n_instances = static_cast<int32_t>(n_instances);
@@ -344,7 +349,7 @@ int32_t fgs_forward(const float* means, const float* scales, const float* rotati
                     const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
                     const fgs_settings* settings, float* image, fgs_resize_fn resize, void* resize_user,
                     fgs_forward_state* state_out, void* stream) {
-    return run_forward(true, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+    return run_forward(MODE_TRAINING, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
                        image, 1, 0, resize, resize_user, state_out, stream);
 }
 
@@ -352,8 +357,15 @@ int32_t fgs_inference(const float* means, const float* scales, const float* rota
                       const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
                       const fgs_settings* settings, float* image, int32_t to_chw, int32_t clamp_output,
                       fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream) {
-    return run_forward(false, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+    return run_forward(MODE_INFERENCE, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
                        image, to_chw, clamp_output, resize, resize_user, state_out, stream);
+}
+
+int32_t fgs_pruning_scores(float* scores, const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                           const fgs_settings* settings, fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream) {
+    return run_forward(MODE_SCORES, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+                       nullptr, 1, 0, resize, resize_user, state_out, stream, scores);
 }
 
 size_t fgs_backward_scratch_bytes(int32_t n_primitives, int32_t width, int32_t height) {
@@ -478,6 +490,46 @@ int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int3
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown buffer %d", which);
     }
     return c.n < max_entries ? c.n : max_entries;
+}
+
+int32_t fgs_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int32_t n_points,
+                             int32_t width, int32_t height, float focal_x, float focal_y, float center_x, float center_y,
+                             float near_plane, float clipping_tolerance, float distance2filter, void* stream) {
+    if (n_points < 0 || (n_points > 0 && (!positions || !w2c || !filter_3d || !visibility_mask))) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    // host-side frustum bounds exactly as filter3d.cu:55-66
+    const float bounds_factor = clipping_tolerance + 0.5f;
+    const float width_f = static_cast<float>(width), height_f = static_cast<float>(height);
+    const float max_x = bounds_factor * width_f, max_y = bounds_factor * height_f;
+    const float off_x = center_x - 0.5f * width_f, off_y = center_y - 0.5f * height_f;
+    const float left = (-max_x - off_x) / focal_x, right = (max_x - off_x) / focal_x;
+    const float top = (-max_y - off_y) / focal_y, bottom = (max_y - off_y) / focal_y;
+    FGS_HIP(launch_update_3d_filter(positions, w2c, filter_3d, visibility_mask, n_points, left, right, top, bottom, near_plane,
+                                    distance2filter, static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
+int32_t fgs_relocation_table(float* table_host_2500) {
+    if (!table_host_2500) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL table");
+    relocation_coefficients(table_host_2500);
+    return FGS_OK;
+}
+
+int32_t fgs_relocation_adjustment(const float* old_opacities, const float* old_scales, const int64_t* n_samples_per_primitive,
+                                  const float* table_device, float* new_opacities, float* new_scales, int32_t n_primitives, void* stream) {
+    if (n_primitives < 0 || (n_primitives > 0 && (!old_opacities || !old_scales || !n_samples_per_primitive || !table_device || !new_opacities || !new_scales)))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    FGS_HIP(launch_relocation(old_opacities, old_scales, n_samples_per_primitive, table_device, new_opacities, new_scales,
+                              static_cast<unsigned>(n_primitives), static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
+int32_t fgs_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
+                      float* means, int32_t n_primitives, float current_lr, void* stream) {
+    if (n_primitives < 0 || (n_primitives > 0 && (!raw_scales || !raw_rotations || !raw_opacities || !random_samples || !means)))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    FGS_HIP(launch_add_noise(raw_scales, raw_rotations, raw_opacities, random_samples, means, static_cast<unsigned>(n_primitives), current_lr,
+                             static_cast<hipStream_t>(stream)));
+    return FGS_OK;
 }
 
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height) {

@@ -126,6 +126,96 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
     }
 }
 
+// Speedy-Splat pruning scores (kernels_pruning_scores.cuh:348-505): the tile list is blended twice -- pass 1
+// for the final colour / transmittance, pass 2 re-walks it with dL/dC = 1 and adds (opacity * dL/dalpha)^2 of every blended
+// (pixel, Gaussian) pair to scores[primitive]. Same wave64 strip / two-sub-tile cull as blend_kernel. The reference issues
+// one atomicAdd per (pixel, Gaussian) pair (kp:490); here the 64 lanes of a wave evaluate the SAME Gaussian, so their
+// scores are summed with 6 DPP adds and leave through one atomic per (Gaussian, wave).
+__global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const BlendArgs a) {
+    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
+    const unsigned tile = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    if (tile >= a.n_tiles) return;
+    const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
+    const unsigned lx = half * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
+    const unsigned px = tile_x * kTileW + lx, py = tile_y * kTileH + ly;
+    const bool inside = px < a.width && py < a.height;
+    const float pxf = static_cast<float>(px) + 0.5f, pyf = static_cast<float>(py) + 0.5f;
+    const unsigned sub_y0 = tile_y * kTileH + wave * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
+    const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
+    const uint2 range = a.ranges[tile];
+    const unsigned n_total = range.y - range.x;
+
+    __shared__ float4 s_a[kBlendBlock], s_b[kBlendBlock], s_c[kBlendBlock];
+    __shared__ uint32_t s_prim[kBlendBlock];
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, T = 1.0f, galpha = 0.0f;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) { galpha = T * -(a.bg[0] + a.bg[1] + a.bg[2]); T = 1.0f; }                 // kp:441-444
+        bool done = !inside;
+        for (unsigned batch_start = 0; batch_start < n_total; batch_start += kBlendBlock) {
+            if (__syncthreads_and(done ? 1 : 0)) break;
+            const unsigned batch = min(static_cast<unsigned>(kBlendBlock), n_total - batch_start);
+            if (tid < batch) {
+                const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
+                const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+                s_a[tid] = r[0]; s_b[tid] = r[1]; s_c[tid] = r[2]; s_prim[tid] = prim;
+            }
+            __syncthreads();
+            for (unsigned chunk = 0; chunk < batch; chunk += kWave) {
+                bool in_l = false, in_r = false;
+                const unsigned j = chunk + lane;
+                if (j < batch) {
+                    const uint32_t bx = __float_as_uint(s_c[j].y), by = __float_as_uint(s_c[j].z);
+                    const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
+                    const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
+                    in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
+                    in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
+                }
+                const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
+                const uint64_t mine = half ? mask_r : mask_l;
+                uint64_t pending = mask_l | mask_r;
+                if (wave_ballot(!done) == 0) pending = 0;
+                while (pending != 0) {
+                    const int k = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+                    pending &= pending - 1;
+                    const unsigned jj = chunk + static_cast<unsigned>(k);
+                    const float4 ga = s_a[jj], gb = s_b[jj];
+                    const float col2 = s_c[jj].x;
+                    const float dx = ga.x - pxf, dy = ga.y - pyf;
+                    const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                    const float alpha = gb.y * __expf(fminf(power, 0.0f));
+                    const bool contrib = !done && ((mine >> k) & 1ull) && alpha >= kMinAlphaThreshold;
+                    float score = 0.0f;
+                    if (contrib) {
+                        const float w = T * alpha;
+                        if (pass == 0) { c0 += w * gb.z; c1 += w * gb.w; c2 += w * col2; }
+                        else {
+                            c0 -= w * gb.z; c1 -= w * gb.w; c2 -= w * col2;                          // kp:477
+                            const float rcp = fast_rcp(fmaxf(1.0f - alpha, kOneMinusAlphaEps));
+                            const float dl_dalpha = ((T * gb.z - c0 * rcp) + (T * gb.w - c1 * rcp) + (T * col2 - c2 * rcp)) + galpha * rcp;
+                            const float dl_dg = gb.y * dl_dalpha;
+                            score = dl_dg * dl_dg;                                                   // kp:487-488
+                        }
+                        T *= 1.0f - alpha;
+                        if (T < kTransmittanceThreshold) done = true;
+                    }
+                    if (pass == 1 && wave_ballot(contrib) != 0) {                                   // wave-uniform
+                        const float total = wave_sum_to_lane63(score);
+                        if (lane == 63u) unsafeAtomicAdd(a.scores + s_prim[jj], total);             // kp:490, one per (Gaussian, wave)
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_pruning_scores(const BlendArgs& a, hipStream_t s) {
+    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
+    hipLaunchKernelGGL(pruning_scores_kernel, dim3(per_xcd * kXcds), dim3(kBlendBlock), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_blend(bool training, const BlendArgs& a, hipStream_t s) {
     const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
     const dim3 grid(per_xcd * kXcds), block(kBlendBlock);

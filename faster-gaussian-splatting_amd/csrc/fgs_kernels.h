@@ -49,8 +49,10 @@ struct BlendArgs {                      // K10 / inference blend
     uint32_t* bucket_tile; float4* ckpt;                                   // [B], [B][192]
     uint32_t width, height, grid_w, n_tiles;
     int to_chw, clamp_output;
+    float* scores;                        // pruning-score mode: accumulated per primitive [N]
 };
 hipError_t launch_blend(bool training, const BlendArgs& a, hipStream_t s);
+hipError_t launch_pruning_scores(const BlendArgs& a, hipStream_t s);   // kernels_pruning_scores.cuh:348-505
 
 struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const uint2* ranges; const uint32_t* bucket_offsets; const uint32_t* inst_prims; const PrimRec* rec;
@@ -103,6 +105,15 @@ struct LossArgs {                       // fused L1 + DSSIM loss and its image g
 };
 size_t l1_dssim_partials(int width, int height);   // number of floats in LossArgs::partials
 hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s);
+
+// aux_ops.hip: the reference's remaining exported operators
+hipError_t launch_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int n,
+                                   float left, float right, float top, float bottom, float near_plane, float distance2filter, hipStream_t s);
+void relocation_coefficients(float* out /*[50*50] host*/);
+hipError_t launch_relocation(const float* old_opacities, const float* old_scales, const int64_t* n_samples, const float* table_device,
+                             float* new_opacities, float* new_scales, unsigned n, hipStream_t s);
+hipError_t launch_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
+                            float* means, unsigned n, float current_lr, hipStream_t s);
 
 extern int g_backward_variant;                                  // 0 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);

@@ -95,6 +95,12 @@ int32_t fgs_inference(const float* means, const float* scales, const float* rota
                       const fgs_settings* settings, float* image, int32_t to_chw, int32_t clamp_output,
                       fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
 
+/* replaces _C.pruning_scores (rasterization_api.cu:250-309 -> rasterization/src/pruning_scores.cu):
+ * accumulates the Speedy-Splat importance score of every primitive for one view into scores[N]. */
+int32_t fgs_pruning_scores(float* scores, const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                           const fgs_settings* settings, fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
+
 /* replaces _C.adam_step (adam/src/adam.cu:36-71): in-place Adam on one tensor, bias corrections in double on the host. */
 int32_t fgs_adam_step(const float* grad, float* param, float* exp_avg, float* exp_avg_sq, int64_t n_elements,
                       int32_t step, double lr, double beta1, double beta2, double eps, void* stream);
@@ -120,6 +126,20 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
 typedef struct fgs_blob_entry { const char* name; size_t offset; size_t bytes; } fgs_blob_entry;
 int32_t fgs_blob_layout(int32_t which, int32_t n_primitives, int32_t width, int32_t height, int32_t n_instances,
                         int32_t n_buckets, fgs_blob_entry* entries, int32_t max_entries);
+
+/* replaces _C.update_3d_filter (filter3d/src/filter3d.cu:40-83). visibility_mask: one byte per point (torch.bool). */
+int32_t fgs_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int32_t n_points,
+                             int32_t width, int32_t height, float focal_x, float focal_y, float center_x, float center_y,
+                             float near_plane, float clipping_tolerance, float distance2filter, void* stream);
+/* replaces _C.relocation_adjustment (densification/src/densification_api.cu:9-31, kernels_mcmc.cuh:28-59). The binomial table of
+ * Eq. (9) (the reference's __constant__ array, kernels_mcmc.cuh:10-26) is produced on the host by fgs_relocation_table
+ * (2500 floats) and passed in as a device buffer. */
+int32_t fgs_relocation_table(float* table_host_2500);
+int32_t fgs_relocation_adjustment(const float* old_opacities, const float* old_scales, const int64_t* n_samples_per_primitive,
+                                  const float* table_device, float* new_opacities, float* new_scales, int32_t n_primitives, void* stream);
+/* replaces _C.add_noise (densification_api.cu:33-58, kernels_mcmc.cuh:69-127); random_samples ~ N(0,1) [N,3] from the caller. */
+int32_t fgs_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
+                      float* means, int32_t n_primitives, float current_lr, void* stream);
 
 /* "Next" row: the loss between forward and backward of every iteration,
  *   loss = lambda_l1 * mean|image - target| + lambda_dssim * (1 - SSIM(image, target))        (Loss.py:15-16, Trainer.py:52-53)

@@ -819,3 +819,62 @@ float orc_l1_dssim(const float* image, const float* target, int H, int W, float 
     free(d_mu); free(d_m11); free(d_m12);
     return lambda_l1 * l1 + lambda_dssim * (1.0f - ssim);
 }
+
+
+/* ---- "next" row: Speedy-Splat pruning scores, kernels_pruning_scores.cuh:348-505 ----
+ * Same pipeline as inference (colour clamped at store, kp = ki up to the blend); per pixel the tile list is blended twice:
+ * pass 1 gives the final colour / transmittance, pass 2 re-walks it with dL/dC = (1,1,1) and adds (opacity * dL/dalpha)^2 of
+ * every blended (pixel, Gaussian) pair to scores[primitive] (kp:470-494). Accumulates into `scores` (Renderer.py:141-156). */
+void orc_pruning_scores(const uint* ranges, const uint* inst_prims, const uint16_t* screen_bounds, const float* mean2d,
+                        const float* conic_opacity, const float* color, const orc_settings* S, int N, float* scores) {
+    const int W = S->width, H = S->height;
+    const int grid_w = (W + TILE_W - 1) / TILE_W, grid_h = (H + TILE_H - 1) / TILE_H;
+    const int T = grid_w * grid_h;
+    double* acc = (double*)calloc((size_t)N, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        const int tyi = tile / grid_w, txi = tile % grid_w;
+        const uint r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        const int n_total = (int)(r1 - r0);
+        for (int local = 0; local < BLOCK_BLEND; local++) {
+            const int px = txi * TILE_W + local % TILE_W, py = tyi * TILE_H + local / TILE_W;
+            if (px >= W || py >= H) continue;
+            const int sx0 = txi * TILE_W + ((local % TILE_W) / SUBTILE_W) * SUBTILE_W, sx1 = sx0 + SUBTILE_W;
+            const int sy0 = tyi * TILE_H + ((local / TILE_W) / SUBTILE_H) * SUBTILE_H, sy1 = sy0 + SUBTILE_H;
+            const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+            float after[3] = {0.0f, 0.0f, 0.0f}, Tr = 1.0f;
+            for (int pass = 0; pass < 2; pass++) {
+                float galpha = 0.0f;
+                if (pass == 1) { galpha = Tr * -(S->bg[0] + S->bg[1] + S->bg[2]); Tr = 1.0f; }         /* kp:441-444 */
+                int done = 0;
+                for (int j = 0; j < n_total && !done; j++) {
+                    const uint p = inst_prims[r0 + j];
+                    const uint16_t* sb = screen_bounds + 4 * (size_t)p;
+                    if (!(sb[0] < sx1 && sx0 < sb[1] && sb[2] < sy1 && sy0 < sb[3])) continue;
+                    const float* co = conic_opacity + 4 * (size_t)p;
+                    const float dx = mean2d[2 * (size_t)p] - pxf, dy = mean2d[2 * (size_t)p + 1] - pyf;
+                    const float expo = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const float alpha = co[3] * expf(fminf(expo, 0.0f));
+                    if (alpha < MIN_ALPHA_THRESHOLD) continue;
+                    const float* col = color + 3 * (size_t)p;
+                    const float w = Tr * alpha;
+                    if (pass == 0) { after[0] += w * col[0]; after[1] += w * col[1]; after[2] += w * col[2]; }
+                    else {
+                        after[0] -= w * col[0]; after[1] -= w * col[1]; after[2] -= w * col[2];         /* kp:477 */
+                        const float oma = 1.0f - alpha;
+                        const float rcp = 1.0f / fmaxf(oma, ONE_MINUS_ALPHA_EPS);
+                        const float dLda = ((Tr * col[0] - after[0] * rcp) + (Tr * col[1] - after[1] * rcp) + (Tr * col[2] - after[2] * rcp))
+                                           + galpha * rcp;                                               /* kp:480-484 */
+                        const float dLdg = co[3] * dLda;
+#pragma omp atomic
+                        acc[p] += (double)(dLdg * dLdg);                                                 /* kp:487-490 */
+                    }
+                    Tr *= 1.0f - alpha;
+                    if (Tr < TRANSMITTANCE_THRESHOLD) done = 1;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < N; i++) scores[i] += (float)acc[i];
+    free(acc);
+}

@@ -234,3 +234,80 @@ def l1_dssim(image: np.ndarray, target: np.ndarray, lambda_l1: float = 0.8, lamb
     loss = L.orc_l1_dssim(_p(image), _p(target), H, W, C.c_float(lambda_l1), C.c_float(lambda_dssim),
                           _p(grad) if with_grad else None, C.byref(l1), C.byref(ssim))
     return float(loss), float(l1.value), float(ssim.value), grad
+
+
+def pruning_scores(scores: np.ndarray, means, scales, rotations, opacities, sh0, sh_rest, settings: Settings) -> dict:
+    """update_pruning_scores (rasterization.py:159-178 -> pruning_scores.cu): accumulates into `scores` [N] in place."""
+    assert scores.dtype == np.float32 and scores.flags['C_CONTIGUOUS']
+    f = forward(means, scales, rotations, opacities, sh0, sh_rest, settings, inference=True)
+    S = settings.to_c(np.asarray(sh_rest).reshape(f['N'], -1, 3).shape[1] if f['N'] else 0)
+    inst = np.ascontiguousarray(f['inst_prims']) if f['I'] > 0 else np.zeros(1, np.uint32)
+    lib().orc_pruning_scores(_p(f['ranges']), _p(inst), _p(f['screen_bounds']), _p(f['mean2d']), _p(f['conic_opacity']),
+                             _p(f['color']), C.byref(S), f['N'], _p(scores))
+    return f
+
+
+# ---- the three small exported operators (SURVEY.md 8f rank 4), restated in numpy fp32 ------------------------------------
+def update_3d_filter(positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
+                     near_plane, clipping_tolerance, distance2filter) -> None:
+    """filter3d/src/filter3d.cu:9-83; filter_3d / visibility_mask are updated in place."""
+    f = np.float32
+    p, w = _f32(positions), _f32(w2c).reshape(-1)[:12]
+    bounds = f(clipping_tolerance) + f(0.5)
+    wf, hf = f(width), f(height)
+    mx, my = bounds * wf, bounds * hf
+    ox, oy = f(center_x) - f(0.5) * wf, f(center_y) - f(0.5) * hf
+    left, right = (-mx - ox) / f(focal_x), (mx - ox) / f(focal_x)
+    top, bottom = (-my - oy) / f(focal_y), (my - oy) / f(focal_y)
+    z = (w[8] * p[:, 0] + w[9] * p[:, 1] + w[10] * p[:, 2]) + w[11]
+    xc = (w[0] * p[:, 0] + w[1] * p[:, 1] + w[2] * p[:, 2]) + w[3]
+    yc = (w[4] * p[:, 0] + w[5] * p[:, 1] + w[6] * p[:, 2]) + w[7]
+    ok = (z >= f(near_plane)) & ~((xc < left * z) | (xc > right * z)) & ~((yc < top * z) | (yc > bottom * z))
+    new = f(distance2filter) * z
+    upd = ok & ~(filter_3d < new)
+    filter_3d[upd] = new[upd]
+    visibility_mask[upd] = True
+
+
+def relocation_adjustment(old_opacities, old_scales, n_samples_per_primitive):
+    """densification/include/kernels_mcmc.cuh:10-59 (Eq. 9 of 3DGS-MCMC), max 50 samples."""
+    f = np.float32
+    op, sc = _f32(old_opacities).reshape(-1), _f32(old_scales).reshape(-1, 3)
+    ns = np.clip(np.asarray(n_samples_per_primitive).astype(np.int64), 1, 50)
+    table = np.zeros((50, 50), np.float32)
+    for n in range(50):
+        binom, sign = 1.0, 1.0
+        for k in range(n + 1):
+            table[n, k] = f(binom * sign / np.sqrt(float(k + 1)))
+            binom *= (n - k) / (k + 1)
+            sign = -sign
+    new_op = (f(1.0) - np.power(f(1.0) - op, f(1.0) / ns.astype(np.float32))).astype(np.float32)
+    new_sc = np.zeros_like(sc)
+    for i in range(op.shape[0]):
+        den = f(0.0)
+        for n in range(int(ns[i])):
+            power = new_op[i]
+            for k in range(n + 1):
+                den = f(den + table[n, k] * power)
+                power = f(power * new_op[i])
+        new_sc[i] = (op[i] / den) * sc[i]
+    return new_op.reshape(-1, 1), new_sc
+
+
+def add_noise(raw_scales, raw_rotations, raw_opacities, random_samples, means, current_lr) -> None:
+    """densification/include/kernels_mcmc.cuh:69-127; `means` [N,3] float32 is updated in place."""
+    f = np.float32
+    s, q, o, r = _f32(raw_scales), _f32(raw_rotations), _f32(raw_opacities).reshape(-1), _f32(random_samples)
+    var = np.exp(f(2.0) * s)
+    rr, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    nsq = rr * rr + x * x + y * y + z * z
+    ok = nsq >= f(1e-8)
+    inv = f(1.0) / np.where(ok, nsq, f(1.0))
+    R = np.stack([f(1) - f(2) * (y * y + z * z) * inv, f(2) * (x * y - rr * z) * inv, f(2) * (x * z + rr * y) * inv,
+                  f(2) * (x * y + rr * z) * inv, f(1) - f(2) * (x * x + z * z) * inv, f(2) * (y * z - rr * x) * inv,
+                  f(2) * (x * z - rr * y) * inv, f(2) * (y * z + rr * x) * inv, f(1) - f(2) * (x * x + y * y) * inv], 1).reshape(-1, 3, 3)
+    cov = (R * var[:, None, :]) @ R.transpose(0, 2, 1)
+    t = np.einsum('nij,nj->ni', cov, r).astype(np.float32)
+    opacity = f(1.0) / (f(1.0) + np.exp(-o))
+    factor = f(current_lr) * (f(1.0) / (f(1.0) + np.exp(f(100.0) * opacity - f(0.5))))
+    means[ok] += (factor[:, None] * t)[ok]

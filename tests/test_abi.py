@@ -78,5 +78,5 @@ def test_cpu_tensors_are_rejected_by_the_public_operators(hip_lib):
         B.diff_rasterize(*[params[k] for k in helpers.NAMES], torch.empty(0), RS)
     with pytest.raises(RuntimeError, match='no CPU implementation'):
         B.rasterize(*[params[k] for k in helpers.NAMES], RS, True)
-    with pytest.raises(NotImplementedError, match='8f'):
-        B.update_pruning_scores()
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        B.add_noise(params['scales'], params['rotations'], params['opacities'], params['means'], 1e-3)

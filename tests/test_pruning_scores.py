@@ -1,0 +1,40 @@
+"""update_pruning_scores (reference kernels_pruning_scores.cuh:348-505, Renderer.py:141-156)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from harness.scenes import View, make_s0
+
+
+def _case(seed, n, w=128, h=128, bg=(0.2, 0.4, 0.1)):
+    p, v = make_s0(seed=seed, n=n)
+    v = View(v.w2c, v.position, w, h, float(w), float(w), w / 2.0, h / 2.0, 0.2, 1e4, torch.tensor(bg))
+    return p, v
+
+
+@pytest.mark.parametrize('seed,n,w,h', [(0, 600, 128, 128), (4, 300, 50, 30)])
+def test_sim_pruning_scores_match_oracle(sim_backend, oracle, seed, n, w, h):
+    p, v = _case(seed, n, w, h)
+    S, RS = helpers.settings_pair(v)
+    ref = np.full(n, 0.5, np.float32)                         # accumulates on top of existing values
+    oracle.pruning_scores(ref, *helpers.np_params(p), S)
+    scores = torch.full((n,), 0.5)
+    sim_backend.pruning_scores(scores, *[p[k] for k in helpers.NAMES], RS)
+    assert helpers.rel_inf(scores.numpy() - 0.5, ref - 0.5) < 1e-5
+    assert (ref > 0.5).sum() > n // 2 and np.all(ref >= 0.5)
+
+
+@pytest.mark.gpu
+def test_gpu_pruning_scores_match_oracle(hip_backend, oracle):
+    from FasterGSCudaBackend import update_pruning_scores
+    p, v = _case(2, 2000, 333, 211)
+    S, RS = helpers.settings_pair(v, device='cuda')
+    ref = np.zeros(2000, np.float32)
+    oracle.pruning_scores(ref, *helpers.np_params(p), S)
+    scores = torch.zeros(2000, device='cuda')
+    for _ in range(2):                                        # two views accumulate (Renderer.py:144-155)
+        update_pruning_scores(scores, *[p[k].cuda() for k in helpers.NAMES], RS)
+    got = scores.cpu().numpy()
+    assert helpers.rel_inf(got, 2.0 * ref) < 1e-3             # (opacity*dL/dalpha)^2 amplifies the fp32 blend differences
+    assert helpers.outlier_fraction(got, 2.0 * ref, 1e-3, 1e-6 * ref.max()) < 1e-2
