@@ -209,14 +209,12 @@ class Backend:
         if image.dim() != 3 or image.shape[0] != 3 or image.shape != target.shape:
             raise RuntimeError('l1_dssim expects two [3,H,W] tensors')
         _, h, w = image.shape
-        sums = torch.empty(2, dtype=torch.float32, device=device)
+        sums = torch.empty(3, dtype=torch.float32, device=device)
         grad = torch.empty_like(image) if with_grad else None
         scratch = torch.empty(int(self.lib.fgs_l1_dssim_scratch_bytes(w, h)), dtype=torch.uint8, device=device)
         self._check(self.lib.fgs_l1_dssim_loss(image.data_ptr(), target.data_ptr(), w, h, float(lambda_l1), float(lambda_dssim),
                                                sums.data_ptr(), _ptr(grad), scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_loss')
-        means = sums / float(image.numel())
-        loss = lambda_l1 * means[0] + lambda_dssim * (1.0 - means[1])
-        return loss, grad, means
+        return sums[2], grad, sums[:2]      # loss and the (l1, ssim) means are formed on the device by the reduce kernel
 
     # -- the remaining exported operators (reference torch_bindings/filter3d.py, densification.py) ---------------------------
     def update_3d_filter(self, positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,

@@ -229,7 +229,6 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     if (!tile_blob && tile_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(tile, %zu) returned NULL", tile_size.total());
     Carver tile_c(tile_blob);
     TileBuffers tb = TileBuffers::carve(tile_c, geo.n_tiles, training);
-    FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));
 
     // primitive buffers + K1 (fwd:58-98)
     Carver prim_size(nullptr);
@@ -242,7 +241,8 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     PreprocessArgs pa;
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
-    pa.n = n; pa.cam = camera_of(*settings, geo);
+    pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles;
+    if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
     // the one host read of the pass: V and I (fwd:99-102)

@@ -17,6 +17,7 @@ struct PreprocessArgs {                 // K1
     uint32_t* depth_keys; uint32_t* prim_idx;     // compacted (unsorted) visible list
     uint32_t* counters;                            // [0] n_visible, [1] n_instances (one packed 64-bit word), [2] K5 work list, [3] huge list
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
+    uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
     uint32_t n;
     CameraArgs cam;
 };

@@ -96,7 +96,12 @@ __global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, cons
     for (unsigned b = threadIdx.x; b < n_blocks; b += 256u) { l1 += a.partials[2 * b]; ss += a.partials[2 * b + 1]; }
     const float tl = block_sum_256(l1, s_red[0]);
     const float ts = block_sum_256(ss, s_red[1]);
-    if (threadIdx.x == 255) { a.sums[0] = tl; a.sums[1] = ts; }
+    if (threadIdx.x == 255) {
+        const float n_total = 3.0f * static_cast<float>(a.width) * static_cast<float>(a.height);
+        const float l1 = tl / n_total, ssim = ts / n_total;
+        a.sums[0] = l1; a.sums[1] = ssim;                                         // means, and the scalar loss itself:
+        a.sums[2] = a.lambda_l1 * l1 + a.lambda_dssim * (1.0f - ssim);           // no framework-side arithmetic kernels
+    }
 }
 
 __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, const GaussWindow gw) {

@@ -24,6 +24,8 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
     bool active = gid < a.n;
     const unsigned idx = active ? gid : a.n - 1;
+    // K0 (fwd:54): clear the per-tile ranges here instead of a separate memset launch (tiles without instances stay (0,0))
+    for (unsigned t = gid; t < a.n_tiles; t += gridDim.x * kPreprocessBlock) a.ranges[t] = make_uint2(0u, 0u);
 
     float m[3];
     m[0] = a.means[3 * (size_t)idx]; m[1] = a.means[3 * (size_t)idx + 1]; m[2] = a.means[3 * (size_t)idx + 2];

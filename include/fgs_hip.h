@@ -143,12 +143,12 @@ int32_t fgs_add_noise(const float* raw_scales, const float* raw_rotations, const
 
 /* "Next" row: the loss between forward and backward of every iteration,
  *   loss = lambda_l1 * mean|image - target| + lambda_dssim * (1 - SSIM(image, target))        (Loss.py:15-16, Trainer.py:52-53)
- * replacing torch.nn.functional.l1_loss + NeRFICG's fused_dssim (Optim/Losses/DSSIM.py, not vendored). Writes
- * sums[0] = sum|x-y| and sums[1] = sum SSIM over the 3*H*W entries (the caller forms the scalar on the device, no sync) and,
- * if grad_image != NULL, dloss/dimage [3,H,W]. scratch: fgs_l1_dssim_scratch_bytes(width, height) bytes. */
+ * replacing torch.nn.functional.l1_loss + NeRFICG's fused_dssim (Optim/Losses/DSSIM.py, not vendored). Writes three device
+ * floats out[0] = mean|x-y|, out[1] = mean SSIM, out[2] = the loss (no host sync) and, if grad_image != NULL,
+ * dloss/dimage [3,H,W]. scratch: fgs_l1_dssim_scratch_bytes(width, height) bytes. */
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height);
 int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
-                          float* sums, float* grad_image, void* scratch, void* stream);
+                          float* out3, float* grad_image, void* scratch, void* stream);
 
 /* Optional per-stage timing. While enabled, every pipeline stage is bracketed by hipEvents recorded on the caller's stream;
  * fgs_profile_read() waits for them, returns accumulated milliseconds + launch counts per stage since the last read and
