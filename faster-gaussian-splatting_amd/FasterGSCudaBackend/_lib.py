@@ -69,6 +69,7 @@ _SIGNATURES = {
     'fgs_profile_read': (C.c_int32, [C.POINTER(StageTime), _I32]),
     'fgs_debug_wave_selftest': (C.c_int32, [_P, _P]),
     'fgs_debug_set_backward_variant': (C.c_int32, [_I32]),
+    'fgs_debug_set_option': (C.c_int32, [_I32, _I32]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -575,6 +575,16 @@ int32_t fgs_debug_set_backward_variant(int32_t variant) {
     return FGS_OK;
 }
 
+int32_t fgs_debug_set_option(int32_t key, int32_t value) {
+    switch (key) {
+        case 0: return fgs_debug_set_backward_variant(value);
+        case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
+                fgs::g_adam_unroll = value; return FGS_OK;
+        case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
+        default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
+    }
+}
+
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {
     if (!out_device_256) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL output");
     FGS_HIP(launch_wave_selftest(out_device_256, static_cast<hipStream_t>(stream)));

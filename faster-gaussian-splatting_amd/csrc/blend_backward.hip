@@ -63,7 +63,11 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
         for (int c = 0; c < kTilePixels / kWave; ++c) {
             const unsigned p = static_cast<unsigned>(c) * kWave + lane;
             const float4 g = pix[2 * p], cst = pix[2 * p + 1], k = ck[p];
-            s_init[wv][p] = make_float4(cst.x - k.x, cst.y - k.y, cst.z - k.z, k.w);               // kb:371-374
+            // A pixel that finished before this bucket never wrote its checkpoint (kf:436): that slot is uninitialised memory.
+            // Such pixels are gated out of every update below, but the step body is branch-free (0 * NaN != 0), so they enter
+            // the pipeline with a clean zero state instead of whatever the allocator left there.
+            const bool live = __float_as_uint(cst.w) > tb * kBucket;
+            s_init[wv][p] = live ? make_float4(cst.x - k.x, cst.y - k.y, cst.z - k.z, k.w) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // kb:371-374
             s_grad[wv][p] = g;
             s_last[wv][kWave + p] = __float_as_uint(cst.w);
         }

@@ -116,6 +116,8 @@ hipError_t launch_relocation(const float* old_opacities, const float* old_scales
 hipError_t launch_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
                             float* means, unsigned n, float current_lr, hipStream_t s);
 
+extern int g_adam_nontemporal;                                  // 0 | 1
+extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
 extern int g_backward_variant;                                  // 0 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 

@@ -72,6 +72,17 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// 16-byte non-temporal global accesses for data streamed exactly once per kernel (Adam state)
+typedef float fgs_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_float4_nt(const float* p) {
+    const fgs_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fgs_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_float4_nt(float* p, const float4 v) {
+    fgs_f32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<fgs_f32x4*>(p));
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 
 // One step of the backward pixel pipeline for NV per-pixel values:

@@ -327,36 +327,66 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
     return hipGetLastError();
 }
 
-// ---- K13: Adam for all parameter groups in one launch (adam.cu:10-34), float4-vectorised ----------------------------
+// ---- K13: Adam for all parameter groups in one launch (adam.cu:10-34), float4-vectorised, U pieces per thread ----------
+int g_adam_unroll = 1;   // 16-byte pieces per thread (fgs_debug_set_option(1, u)); measured on MI355X: 1, 2 and 4 are within 2 %
+int g_adam_nontemporal = 1;   // fgs_debug_set_option(2, 0|1): non-temporal loads / stores (state is streamed once per step: +2.3 % measured)
+
+template <bool NT> __device__ __forceinline__ float4 load4(const float* p) { return NT ? load_float4_nt(p) : *reinterpret_cast<const float4*>(p); }
+template <bool NT> __device__ __forceinline__ void store4(float* p, const float4 v) {
+    if (NT) store_float4_nt(p, v);
+    else *reinterpret_cast<float4*>(p) = v;
+}
+
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
     int gidx = 0;
 #pragma unroll
     for (int j = 1; j < 8; ++j) if (j < a.n_groups && blockIdx.x >= a.g[j].first_block) gidx = j;
     const AdamGroup& G = a.g[gidx];
-    const int64_t base = ((int64_t)(blockIdx.x - G.first_block) * 256 + threadIdx.x) * 4;
-    if (base >= G.n) return;
-    if (base + 4 <= G.n) {
-        const float4 g4 = *reinterpret_cast<const float4*>(G.grad + base);
-        float4 p4 = *reinterpret_cast<float4*>(G.param + base);
-        float4 m4 = *reinterpret_cast<float4*>(G.exp_avg + base);
-        float4 v4 = *reinterpret_cast<float4*>(G.exp_avg_sq + base);
-        adam_update(p4.x, m4.x, v4.x, g4.x, G.h); adam_update(p4.y, m4.y, v4.y, g4.y, G.h);
-        adam_update(p4.z, m4.z, v4.z, g4.z, G.h); adam_update(p4.w, m4.w, v4.w, g4.w, G.h);
-        *reinterpret_cast<float4*>(G.param + base) = p4;
-        *reinterpret_cast<float4*>(G.exp_avg + base) = m4;
-        *reinterpret_cast<float4*>(G.exp_avg_sq + base) = v4;
-    } else {
-        for (int64_t e = base; e < G.n; ++e) {
-            float pp = G.param[e], mm = G.exp_avg[e], vv = G.exp_avg_sq[e];
-            adam_update(pp, mm, vv, G.grad[e], G.h);
-            G.param[e] = pp; G.exp_avg[e] = mm; G.exp_avg_sq[e] = vv;
+    const int64_t block_base = (int64_t)(blockIdx.x - G.first_block) * (256 * 4 * U);
+    float4 g4[U], p4[U], m4[U], v4[U];
+    bool full[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                       // all loads of the thread are issued before any arithmetic
+        const int64_t base = block_base + ((int64_t)u * 256 + threadIdx.x) * 4;
+        full[u] = base + 4 <= G.n;
+        if (full[u]) {
+            g4[u] = load4<NT>(G.grad + base);
+            p4[u] = load4<NT>(G.param + base);
+            m4[u] = load4<NT>(G.exp_avg + base);
+            v4[u] = load4<NT>(G.exp_avg_sq + base);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t base = block_base + ((int64_t)u * 256 + threadIdx.x) * 4;
+        if (full[u]) {
+            adam_update(p4[u].x, m4[u].x, v4[u].x, g4[u].x, G.h); adam_update(p4[u].y, m4[u].y, v4[u].y, g4[u].y, G.h);
+            adam_update(p4[u].z, m4[u].z, v4[u].z, g4[u].z, G.h); adam_update(p4[u].w, m4[u].w, v4[u].w, g4[u].w, G.h);
+            store4<NT>(G.param + base, p4[u]);
+            store4<NT>(G.exp_avg + base, m4[u]);
+            store4<NT>(G.exp_avg_sq + base, v4[u]);
+        } else {
+            for (int64_t e = base; e < G.n && e < base + 4; ++e) {
+                float pp = G.param[e], mm = G.exp_avg[e], vv = G.exp_avg_sq[e];
+                adam_update(pp, mm, vv, G.grad[e], G.h);
+                G.param[e] = pp; G.exp_avg[e] = mm; G.exp_avg_sq[e] = vv;
+            }
         }
     }
 }
 
-hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
-    if (a.total_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(adam_kernel, dim3(a.total_blocks), dim3(256), 0, s, a);
+hipError_t launch_adam(const AdamArgs& a_in, hipStream_t s) {
+    AdamArgs a = a_in;
+    const int u = g_adam_nontemporal ? 1 : (g_adam_unroll == 2 || g_adam_unroll == 4 ? g_adam_unroll : 1);
+    uint32_t blocks = 0;                                  // first_block / total_blocks depend on the elements per workgroup
+    for (int k = 0; k < a.n_groups; ++k) { a.g[k].first_block = blocks; blocks += static_cast<uint32_t>((a.g[k].n + 1024 * u - 1) / (1024 * u)); }
+    a.total_blocks = blocks;
+    if (blocks == 0) return hipSuccess;
+    if (g_adam_nontemporal) hipLaunchKernelGGL((adam_kernel<1, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (u == 1) hipLaunchKernelGGL((adam_kernel<1, false>), dim3(blocks), dim3(256), 0, s, a);
+    else if (u == 2) hipLaunchKernelGGL((adam_kernel<2, false>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((adam_kernel<4, false>), dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

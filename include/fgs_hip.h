@@ -164,6 +164,9 @@ int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
 /* Selects the blend-backward formulation: 0 = systolic (lane = Gaussian), 1 = strip (lane = pixel, default). A/B switch for
  * tests and bench; both must give the same gradients. */
 int32_t fgs_debug_set_backward_variant(int32_t variant);
+/* Tuning switches for A/B measurements inside one process: key 0 = blend-backward variant, key 1 = Adam float4 pieces per
+ * thread (1, 2, 4). Results never depend on them. */
+int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -147,3 +147,26 @@ def check_forward_against_oracle(dec: dict, f: dict, exact_floats: bool, width: 
     else:
         assert outlier_fraction(image, f['image'], 1e-4, 1e-5) < 1e-3, outlier_fraction(image, f['image'], 1e-4, 1e-5)
         assert np.abs(image - f['image']).max() < 5e-3
+
+
+def poisoned(be):
+    """A Backend whose scratch buffers arrive filled with 0xFF bytes (= NaN floats / huge integers): nothing the kernels
+    read may depend on the previous contents of freshly (re)sized scratch memory."""
+    _lib, _backend = backend_modules()
+
+    class Poisoned(_backend.Backend):
+        @staticmethod
+        def _make_resizer(device, n_buffers):
+            buffers = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+
+            def resize(_user, which, nbytes):
+                buffers[which].resize_(int(nbytes))
+                buffers[which].fill_(255)
+                return buffers[which].data_ptr() if nbytes else 0
+            return buffers, _lib.RESIZE_FN(resize)
+
+        def _scratch(self, n, settings, device):
+            t = super()._scratch(n, settings, device)
+            t.fill_(255)
+            return t
+    return Poisoned(be.lib)

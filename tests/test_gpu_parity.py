@@ -122,7 +122,28 @@ def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant)
                                      dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
         _grads_close(grads, g)
     finally:
-        hip_backend.lib.fgs_debug_set_backward_variant(1)
+        hip_backend.lib.fgs_debug_set_backward_variant(0)
+
+
+def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
+    """Same as the simulation test: 0xFF-poisoned scratch must not reach any output (NaN checkpoints of finished pixels)."""
+    p, v = make_s0(seed=11, n=1500)
+    p['means'][:, :2] *= 0.15
+    p['opacities'] -= 2.5
+    p['means'][:50, 2] = -10.0
+    be = helpers.poisoned(hip_backend)
+    res, f, dp, RS, S = _forward_check(be, oracle, p, v)
+    gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32)
+    g = oracle.backward(f, S, gi)
+    for variant in (0, 1):
+        be.lib.fgs_debug_set_backward_variant(variant)
+        try:
+            grads = be.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+            assert all(bool(torch.isfinite(t).all()) for t in grads)
+            _grads_close(grads, g)
+        finally:
+            be.lib.fgs_debug_set_backward_variant(0)
 
 
 def test_large_footprints_and_long_lists(hip_backend, oracle):

@@ -84,15 +84,31 @@ def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     assert (f['ranges'][:, 1] - f['ranges'][:, 0]).max() > 400
 
 
-def test_systolic_backward_variant(sim_backend, oracle):
-    """The default is the strip formulation; the systolic one stays selectable and must give the same gradients."""
-    sim_backend.lib.fgs_debug_set_backward_variant(0)
+def test_strip_backward_variant(sim_backend, oracle):
+    """The default is the systolic formulation; the strip one stays selectable and must give the same gradients."""
+    sim_backend.lib.fgs_debug_set_backward_variant(1)
     try:
         p, v = make_s0(seed=11, n=600)
         p['means'][:, :2] *= 0.3
         _run(sim_backend, oracle, p, v)
     finally:
-        sim_backend.lib.fgs_debug_set_backward_variant(1)
+        sim_backend.lib.fgs_debug_set_backward_variant(0)
+
+
+def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
+    """Scratch buffers pre-filled with 0xFF (NaN): checkpoints of finished pixels, records of invisible primitives etc. are
+    never written by the forward pass and must never leak into a result (regression: 0 * NaN in the branch-free K11)."""
+    p, v = make_s0(seed=11, n=1500)
+    p['means'][:, :2] *= 0.15
+    p['opacities'] -= 2.5
+    p['means'][:50, 2] = -10.0                      # invisible primitives: their records stay poisoned
+    be = helpers.poisoned(sim_backend)
+    for variant in (0, 1):
+        be.lib.fgs_debug_set_backward_variant(variant)
+        try:
+            _run(be, oracle, p, v)
+        finally:
+            be.lib.fgs_debug_set_backward_variant(0)
 
 
 def test_empty_and_fully_culled(sim_backend, oracle):
