@@ -269,9 +269,9 @@ __global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs 
         const bool full = e0 + 4u <= n_elems;
         float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), m4 = p4, v4 = p4;
         if (FUSED && full) {                     // request the 48 bytes of state before the gradient is rebuilt
-            p4 = *reinterpret_cast<const float4*>(a.p + e0);
-            m4 = *reinterpret_cast<const float4*>(a.m + e0);
-            v4 = *reinterpret_cast<const float4*>(a.v + e0);
+            p4 = load_float4_nt(a.p + e0);                 // streamed once per step: non-temporal like the Adam kernel
+            m4 = load_float4_nt(a.m + e0);
+            v4 = load_float4_nt(a.v + e0);
         }
         const PairGrad q0 = pair_gradient<RT>(a, p0, n_pairs), q1 = pair_gradient<RT>(a, p0 + 1u, n_pairs);
         float g[4];
@@ -290,9 +290,9 @@ __global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs 
             } else {
                 adam_update(p4.x, m4.x, v4.x, g[0], a.h); adam_update(p4.y, m4.y, v4.y, g[1], a.h);
                 adam_update(p4.z, m4.z, v4.z, g[2], a.h); adam_update(p4.w, m4.w, v4.w, g[3], a.h);
-                *reinterpret_cast<float4*>(a.p + e0) = p4;
-                *reinterpret_cast<float4*>(a.m + e0) = m4;
-                *reinterpret_cast<float4*>(a.v + e0) = v4;
+                store_float4_nt(a.p + e0, p4);
+                store_float4_nt(a.m + e0, m4);
+                store_float4_nt(a.v + e0, v4);
             }
         } else {
             for (uint32_t j = 0; e0 + j < n_elems; ++j) {
