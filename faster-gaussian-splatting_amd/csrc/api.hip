@@ -570,7 +570,7 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
 }
 
 int32_t fgs_debug_set_backward_variant(int32_t variant) {
-    if (variant != 0 && variant != 1) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic) or 1 (strip)");
+    if (variant < 0 || variant > 2) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip) or 2 (systolic, global dL/dC)");
     fgs::g_backward_variant = variant;
     return FGS_OK;
 }

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
     a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1] = c;
 }
 
+template <bool GLOBAL_GRAD>
 __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward_kernel(const BlendBackwardArgs a) {
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const unsigned bucket = blockIdx.x * kBackwardWavesPerBlock + wv;
@@ -52,7 +53,9 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
 
     // ---- stage this bucket's 192 pixels in the wave's private LDS slice (kb:349-380): 36 B per pixel ----
     __shared__ float4 s_init[kBackwardWavesPerBlock][kTilePixels];   // C_final - T_final*bg - C_ckpt (rgb), T_ckpt: injected at lane 0
-    __shared__ float4 s_grad[kBackwardWavesPerBlock][kTilePixels];   // dL/dC rgb, T_final * -(dL/dC . bg): read by lane l at pixel i-l
+    // dL/dC rgb, T_final * -(dL/dC . bg): read by lane l at pixel i-l. GLOBAL_GRAD reads it from the tile-major staging record
+    // (L1/L2-resident, shared by the tile's buckets) instead, which frees 3 KB of LDS per wave -> 32 instead of 21 waves per CU
+    __shared__ float4 s_grad[kBackwardWavesPerBlock][GLOBAL_GRAD ? 1 : kTilePixels];
     // last contributor, padded by one wave width on both sides: slots outside the tile read 0, so `tp < last` is the only
     // per-step validity test (no range compare, no index clamp)
     __shared__ uint32_t s_last[kBackwardWavesPerBlock][kWave + kTilePixels + kWave];
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
             // the pipeline with a clean zero state instead of whatever the allocator left there.
             const bool live = __float_as_uint(cst.w) > tb * kBucket;
             s_init[wv][p] = live ? make_float4(cst.x - k.x, cst.y - k.y, cst.z - k.z, k.w) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // kb:371-374
-            s_grad[wv][p] = g;
+            if (!GLOBAL_GRAD) s_grad[wv][p] = g;
             s_last[wv][kWave + p] = __float_as_uint(cst.w);
         }
         s_last[wv][lane] = 0u;
@@ -102,19 +105,24 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     float4 init_next = s_init[wv][0];
     const uint32_t* my_last = &s_last[wv][kWave - lane];   // slot of pixel (i - lane) at step i is my_last[i]
     uint32_t last_next = my_last[0];
-    // The step body is branch-free (contributions are gated by selects, not by `continue`) and unrolled twice: the only
-    // loop-carried dependence is the 4-value pixel state, so the scheduler can overlap step i+1's exponent / alpha with
-    // step i's gradient arithmetic -- the kernel is bound by that dependency chain, not by HBM.
+    const float4* __restrict__ gpix = a.pixrec + (size_t)tile * kTilePixels * 2;
+    float4 g_next = GLOBAL_GRAD ? gpix[2 * min(max(0 - static_cast<int>(lane), 0), kTilePixels - 1)] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // The step body is branch-free (contributions are gated by selects, not by `continue`) and unrolled (the compiler turns
+    // `unroll 2` of the 255 constant-trip steps into 85-step straight-line blocks): the only loop-carried dependence is the
+    // 4-value pixel state, so the scheduler overlaps step i+1's exponent / alpha with step i's gradient arithmetic. Measured
+    // in-process on MI355X (tools/ab_backward.py, S2): unrolled 0.69 ms, rolled 0.73 ms, dL/dC in LDS 0.73 ms, strip variant 0.85 ms.
 #pragma unroll 2
     for (int i = 0; i < kTilePixels + kWave - 1; ++i) {
         // shift the 4 mutable values one lane up (kb:383-393) and inject pixel i at lane 0 (kb:401-410)
         s0 = wave_shift_up1(s0); s1 = wave_shift_up1(s1); s2 = wave_shift_up1(s2); sT = wave_shift_up1(sT);
         const float4 init = init_next;
         const uint32_t last = last_next;
+        const float4 g_cur = g_next;
         init_next = s_init[wv][i + 1 < kTilePixels ? i + 1 : kTilePixels - 1];   // wave-uniform address: LDS broadcast
         last_next = my_last[i + 1];
-        s0 = lane0 ? init.x : s0; s1 = lane0 ? init.y : s1; s2 = lane0 ? init.z : s2; sT = lane0 ? init.w : sT;
         const int idx = i - static_cast<int>(lane);                        // pixel handled by this lane in this step
+        if (GLOBAL_GRAD) g_next = gpix[2 * min(max(idx + 1, 0), kTilePixels - 1)];   // prefetched one step ahead
+        s0 = lane0 ? init.x : s0; s1 = lane0 ? init.y : s1; s2 = lane0 ? init.z : s2; sT = lane0 ? init.w : sT;
         const float dx = mx - (x0 + static_cast<float>(idx & (kTileW - 1)));
         const float dy = my - (y0 + static_cast<float>(idx >> 4));
         const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
         const bool contrib = tp < last && alpha_raw >= kMinAlphaThreshold;                     // kb:412,419-421
         if (wave_ballot(contrib) == 0) continue;                                               // wave-uniform: nothing to do this step
         const float alpha = contrib ? alpha_raw : 0.0f, gauss = contrib ? gauss_raw : 0.0f;
-        const float4 g = s_grad[wv][min(max(idx, 0), kTilePixels - 1)];
+        const float4 g = GLOBAL_GRAD ? g_cur : s_grad[wv][min(max(idx, 0), kTilePixels - 1)];
         const float T = sT;
         const float w = T * alpha;
         d_c0 += w * g.x * f0; d_c1 += w * g.y * f1; d_c2 += w * g.z * f2;                      // kb:426-427
@@ -278,7 +286,7 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
     }
 }
 
-int g_backward_variant = 0;   // 0: systolic (lane = Gaussian, default: 0.70 ms at S2), 1: strip (lane = pixel: 0.85 ms, the 81
+int g_backward_variant = 2;   // 2 (default): systolic (lane = Gaussian), dL/dC prefetched from global memory (0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel: 0.85 ms, the 81
                               // reduction instructions per (Gaussian, strip) pair outweigh the culled pairs); fgs_debug_set_backward_variant()
 
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
@@ -293,7 +301,8 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
-    hipLaunchKernelGGL(blend_backward_kernel, grid, block, 0, s, a);
+    if (g_backward_variant == 2) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -108,7 +108,7 @@ def test_partial_tiles_sh_degrees_antialiasing(hip_backend, oracle, w, h, K, aa)
     assert helpers.rel_inf(dens.cpu().numpy(), dens_o) < 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant):
     """Both formulations of K11 (0 systolic lane=Gaussian, 1 strip lane=pixel) against the oracle on a deep scene."""
     p, v = make_s0(seed=11, n=1500)
@@ -122,7 +122,7 @@ def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant)
                                      dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
         _grads_close(grads, g)
     finally:
-        hip_backend.lib.fgs_debug_set_backward_variant(0)
+        hip_backend.lib.fgs_debug_set_backward_variant(2)
 
 
 def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
@@ -135,7 +135,7 @@ def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
     res, f, dp, RS, S = _forward_check(be, oracle, p, v)
     gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32)
     g = oracle.backward(f, S, gi)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             grads = be.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
@@ -143,7 +143,7 @@ def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
             assert all(bool(torch.isfinite(t).all()) for t in grads)
             _grads_close(grads, g)
         finally:
-            be.lib.fgs_debug_set_backward_variant(0)
+            be.lib.fgs_debug_set_backward_variant(2)
 
 
 def test_large_footprints_and_long_lists(hip_backend, oracle):
