@@ -86,3 +86,23 @@ def test_callback_schedule_matches_trainer():
     assert fired['densify'][0] == 600 and fired['densify'][-1] == 14_900 and len(fired['densify']) == 144   # Trainer.py:120
     assert fired['morton'] == [0, 5_000, 10_000, 15_000] and fired['reset'] == [3_000, 6_000, 9_000, 12_000]   # :141,:156
     assert fired['sh'] == [1_000, 2_000, 3_000]                                                               # :114
+
+
+def test_ply_round_trip(tmp_path):
+    """Model.py:511-542 layout: channel-major SH, raw opacity / scale, normalised quaternion; save -> load is lossless."""
+    from harness import ply
+    g = _gaussians(37)
+    d = ply.as_ply_dict(g)
+    v = d['vertex']
+    assert v.dtype.names[:6] == ('x', 'y', 'z', 'f_dc_0', 'f_dc_1', 'f_dc_2') and v.dtype.names[-4:] == ('rot_0', 'rot_1', 'rot_2', 'rot_3')
+    assert len(v.dtype.names) == 3 + 3 + 45 + 1 + 3 + 4
+    # f_rest is channel-major: f_rest_0..14 = red coefficients of bases 1..15
+    assert torch.allclose(torch.from_numpy(v['f_rest_1'].copy()), g.sh_coefficients_rest[:, 1, 0]) \
+        and torch.allclose(torch.from_numpy(v['f_rest_15'].copy()), g.sh_coefficients_rest[:, 0, 1])
+    ply.save_ply(g, tmp_path / 'g.ply')
+    back = ply.load_ply(tmp_path / 'g.ply')
+    for k in PARAM_ORDER:
+        ref = getattr(g, k).detach()
+        if k == 'rotations':
+            ref = ref / ref.norm(dim=1, keepdim=True)
+        assert back[k].shape == ref.shape and torch.allclose(back[k], ref, atol=1e-7), k
