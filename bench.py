@@ -3,8 +3,10 @@
 
 One "step" = one full training iteration of the reference (Trainer.py:170-199): lr update -> diff_rasterize forward ->
 0.8*L1 + 0.2*DSSIM loss -> backward -> FusedAdam.step -> zero_grad, on one 1920x1080 view of the synthetic garden-like scene
-(scene S2 = 3 M Gaussians by default). With N GPUs every rank renders a different orbit view of the
-same replicated scene and gradients are summed over ranks with one RCCL all-reduce per step (view-parallel, weak scaling).
+(scene S2 = 3 M Gaussians by default). With N GPUs every rank renders a different orbit view per step (weak
+scaling). Default exchange (--dp-mode sharded, harness/sharded.py): every rank OWNS N/G Gaussians, projects them for the G views
+and ships 56-byte projected records to the renderers, which return 36-byte pixel-space gradient accumulators; K12 + Adam run
+on the owner's shard. --dp-mode zero1|allreduce: replicated parameters, the 236-B/Gaussian gradient crosses xGMI instead.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S1|S2|S3] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -39,7 +41,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / fused side measurements')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
-    ap.add_argument('--dp-mode', default='zero1', choices=['zero1', 'allreduce'], help='gradient exchange of the view-parallel step (N > 1)')
+    ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'zero1', 'allreduce'],
+                    help="N > 1: 'sharded' = every rank owns N/G Gaussians, 56-B records / 36-B accumulators cross xGMI (harness/sharded.py); "
+                         "'zero1' / 'allreduce' = replicated parameters, 236-B gradients cross xGMI (harness/distributed.py)")
     return ap.parse_args()
 
 
@@ -140,18 +144,29 @@ def main():
     # rank) or one all-reduce. The rasterizer is called through the backend directly (no autograd copies of the 708 MB arena).
     launched_distributed = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
     vp = None
+    sharded = launched_distributed and args.dp_mode == 'sharded'
     if launched_distributed:
-        from harness.distributed import ViewParallelTrainer
         lr = T.GARDEN_LR
-        vp = ViewParallelTrainer(be, {k: getattr(g, k).detach() for k in T.PARAM_ORDER},
-                                 {'means': lr['means_init'] * 5.0, **{k: lr[k] for k in T.PARAM_ORDER[1:]}}, mode=args.dp_mode)
+        lrs = {'means': lr['means_init'] * 5.0, **{k: lr[k] for k in T.PARAM_ORDER[1:]}}
+        full = {k: getattr(g, k).detach() for k in T.PARAM_ORDER}
+        if sharded:
+            # Gaussian-sharded step: rank r owns Gaussians r::G; only projected records and pixel-space accumulators cross xGMI
+            from harness.sharded import ShardedTrainer, shard_of
+            vp = ShardedTrainer(be, shard_of(full, rank, world), lrs)
+        else:
+            from harness.distributed import ViewParallelTrainer
+            vp = ViewParallelTrainer(be, full, lrs, mode=args.dp_mode)
+    settings_of = {id(v): T.extract_settings(v, g.active_sh_bases, v.background_color) for v in views}
 
     def step(i: int) -> None:
         v = my_views[i % len(my_views)]
         if vp is None:
             T.training_iteration(g, v, targets[id(v)], i)
+        elif sharded:       # every rank names the same global batch: view (i*G + r) is rendered by rank r
+            batch = [views[((i % len(my_views)) * world + r) % len(views)] for r in range(world)]
+            vp.step([settings_of[id(b)] for b in batch], targets[id(v)])
         else:
-            vp.step(T.extract_settings(v, g.active_sh_bases, v.background_color), targets[id(v)])
+            vp.step(settings_of[id(v)], targets[id(v)])
 
     def fence():
         if world > 1:
@@ -196,7 +211,7 @@ def main():
         'blend_backward': 76.0 * I + 3076.0 * B,
         'preprocess_backward': 4.0 * n + 128.0 * V + 56.0 * n,           # + every one of the 14 small gradients written once
         'sh_rest_backward': 24.0 * K_ * V + 12.0 * (K_ - 1) * n,         # + the [N,K-1,3] gradient written once
-        'adam': 1652.0 * n,
+        'adam': 1652.0 * n / (world if (vp is not None and args.dp_mode != 'allreduce') else 1),     # zero1 / sharded: Adam on 1/G
         'l1_dssim_loss': (24.0 + 36.0 + 48.0) * P_,       # fwd: x,y in + 3 maps out; bwd: 3 maps + x,y in, grad out (3 channels)
     }
     kernel_of = {'preprocess': 'preprocess_kernel<false>', 'blend_backward': 'blend_backward_kernel', 'adam': 'adam_kernel',
@@ -204,7 +219,7 @@ def main():
                  'tile_sort': 'rocprim radix_sort_onesweep (u16 keys)', 'sh_rest_backward': 'sh_rest_backward_kernel<false>',
                  'preprocess_backward': 'preprocess_backward_kernel<false>', 'depth_sort': 'rocprim radix_sort_onesweep (u32 keys)'}
     per_launch = {k: (v_[0] / max(v_[1], 1)) * (v_[1] / args.steps) for k, v_ in prof.items() if v_[1] > 0}   # ms per step
-    dom = max(per_launch, key=per_launch.get)
+    dom = max((k for k in per_launch if k in stage_bytes), key=per_launch.get)
     dom_s = per_launch[dom] * 1e-3
     achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
     bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_

@@ -216,6 +216,91 @@ class Backend:
                                                sums.data_ptr(), _ptr(grad), scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_loss')
         return sums[2], grad, sums[:2]      # loss and the (l1, ssim) means are formed on the device by the reduce kernel
 
+    # -- Gaussian-sharded multi-GPU path (include/fgs_hip.h, "Gaussian-sharded multi-GPU path") --------------------------------
+    def _settings_array(self, views: Sequence[RasterizerSettings], total_sh_rest: int, device: torch.device, keep: list):
+        arr = (_lib.Settings * len(views))()
+        for i, v in enumerate(views):
+            arr[i] = self._settings(v, total_sh_rest, device, keep)
+        return arr
+
+    def shard_preprocess(self, means, scales, rotations, opacities, sh0, sh_rest, views: Sequence[RasterizerSettings],
+                         records: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+        """K1 over this rank's shard for all views of the step. `records`: uint8 [len(views), N, 56] (view v: the first
+        counts[v, 0] records are filled), `counts`: int32 [len(views), 2] device tensor receiving (n_visible, n_instances).
+        Returns the primitive buffer to hand to `shard_backward`."""
+        device = self._check_params((means, scales, rotations, opacities, sh0, sh_rest),
+                                    ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest'))
+        n, k = means.shape[0], len(views)
+        if records.dtype != torch.uint8 or records.numel() < k * n * _lib.SPLAT_RECORD_BYTES or counts.dtype != torch.int32 \
+                or counts.numel() < 2 * k or records.device != device or counts.device != device or not records.is_contiguous() \
+                or not counts.is_contiguous():
+            raise RuntimeError('records must be uint8 [views, N, 56] and counts int32 [views, 2] on the parameters\' device')
+        keep: list = []
+        S = self._settings_array(views, sh_rest.shape[1] if sh_rest.dim() == 3 else 0, device, keep)
+        buffers, cb = self._make_resizer(device, 4)
+        self._check(self.lib.fgs_shard_preprocess(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest), n, k,
+                                                  S, _ptr(records), counts.data_ptr(), cb, None, _stream_of(device)), 'fgs_shard_preprocess')
+        return buffers[0]
+
+    def forward_from_records(self, records: torch.Tensor, n_records: int, n_instances: int, settings: RasterizerSettings,
+                             total_sh_rest: int) -> ForwardResult:
+        device = records.device
+        if records.dtype != torch.uint8 or not records.is_contiguous() or records.numel() < n_records * _lib.SPLAT_RECORD_BYTES:
+            raise RuntimeError('records must be a contiguous uint8 tensor of n_records * 56 bytes')
+        keep: list = []
+        S = self._settings(settings, total_sh_rest, device, keep)
+        image = torch.empty((3, settings.height, settings.width), dtype=torch.float32, device=device)
+        buffers, cb = self._make_resizer(device, 4)
+        st = _lib.ForwardState()
+        self._check(self.lib.fgs_forward_from_records(_ptr(records), int(n_records), int(n_instances), C.byref(S), image.data_ptr(), cb, None,
+                                                      C.byref(st), _stream_of(device)), 'fgs_forward_from_records')
+        return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
+
+    def backward_to_records(self, grad_image, image, buffers, settings: RasterizerSettings, state, total_sh_rest: int,
+                            out: torch.Tensor | None = None) -> torch.Tensor:
+        """K11 of a view rendered by `forward_from_records` -> float32 [n_records, 9] accumulator records."""
+        device = image.device
+        n = int(state[0])
+        keep: list = []
+        S = self._settings(settings, total_sh_rest, device, keep)
+        grad_image = grad_image.to(dtype=torch.float32).contiguous()
+        acc = out if out is not None else torch.empty((n, 9), dtype=torch.float32, device=device)
+        if acc.dtype != torch.float32 or acc.numel() < 9 * n or not acc.is_contiguous() or acc.device != device:
+            raise RuntimeError('accumulator records must be contiguous float32 [n_records, 9]')
+        scratch = self._scratch(n, settings, device)
+        st = _lib.ForwardState(*state)
+        self._check(self.lib.fgs_backward_to_records(_ptr(grad_image), _ptr(image), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]),
+                                                     _ptr(buffers[3]), scratch.data_ptr(), _ptr(acc), n, C.byref(S), C.byref(st),
+                                                     _stream_of(device)), 'fgs_backward_to_records')
+        return acc
+
+    def shard_backward(self, acc_records: torch.Tensor, n_visible: Sequence[int], primitive_buffer: torch.Tensor, densification_info, means,
+                       scales, rotations, opacities, sh_rest, views: Sequence[RasterizerSettings], out: tuple) -> tuple:
+        """K12 on the shard, gradients summed over `views`; `acc_records`: float32 [sum(n_visible), 9] in view order;
+        `out` = the six gradient tensors (means, scales, rotations, opacities, sh0, sh_rest), every element written."""
+        device = self._check_params((means, scales, rotations, opacities, sh_rest) + tuple(out),
+                                    ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_rest') + ('grad',) * 6)
+        n, k = means.shape[0], len(views)
+        total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
+        shapes = ((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3))
+        for g, sh in zip(out, shapes):
+            if tuple(g.shape) != sh:
+                raise RuntimeError(f'preallocated gradient has shape {tuple(g.shape)}, expected {sh}')
+        total = int(sum(n_visible))
+        if len(n_visible) != k or (total > 0 and (acc_records.dtype != torch.float32 or acc_records.numel() < 9 * total
+                                                  or not acc_records.is_contiguous() or acc_records.device != device)):
+            raise RuntimeError('acc_records must be contiguous float32 [sum(n_visible), 9] and n_visible one entry per view')
+        keep: list = []
+        S = self._settings_array(views, total_rest, device, keep)
+        dens = densification_info if densification_info is not None and densification_info.numel() > 0 else None
+        scratch = torch.empty(max(int(self.lib.fgs_shard_backward_scratch_bytes(n, k)), 1), dtype=torch.uint8, device=device)
+        counts = (C.c_int32 * k)(*[int(x) for x in n_visible])
+        self._check(self.lib.fgs_shard_backward(_ptr(acc_records) if total > 0 else None, counts, _ptr(primitive_buffer), _ptr(means),
+                                                _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh_rest), _ptr(out[0]), _ptr(out[1]),
+                                                _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(out[5]), _ptr(dens), scratch.data_ptr(), n, k,
+                                                S, _stream_of(device)), 'fgs_shard_backward')
+        return out
+
     # -- the remaining exported operators (reference torch_bindings/filter3d.py, densification.py) ---------------------------
     def update_3d_filter(self, positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
                          near_plane, clipping_tolerance, distance2filter) -> None:

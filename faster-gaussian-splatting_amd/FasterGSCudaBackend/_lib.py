@@ -41,6 +41,8 @@ class BlobEntry(C.Structure):
     _fields_ = [('name', C.c_char_p), ('offset', C.c_size_t), ('bytes', C.c_size_t)]
 
 
+SPLAT_RECORD_BYTES, ACC_RECORD_BYTES = 56, 36        # FGS_SPLAT_RECORD_BYTES / FGS_ACC_RECORD_BYTES
+
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t)
 
 _P, _I32, _I64, _F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -58,6 +60,11 @@ _SIGNATURES = {
     'fgs_adam_step_multi': (C.c_int32, [_I32] + [C.POINTER(_P)] * 4 + [C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _F64, _F64, _F64, _P]),
     'fgs_backward_adam_fused': (C.c_int32, [_P] * 2 + [C.POINTER(_P)] * 3 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState),
                                             _I32, C.POINTER(_F64), _F64, _F64, _F64, _P]),
+    'fgs_shard_preprocess': (C.c_int32, [_P] * 6 + [_I32, _I32, C.POINTER(Settings), _P, _P, RESIZE_FN, _P, _P]),
+    'fgs_forward_from_records': (C.c_int32, [_P, _I32, _I32, C.POINTER(Settings), _P, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
+    'fgs_backward_to_records': (C.c_int32, [_P] * 2 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
+    'fgs_shard_backward_scratch_bytes': (C.c_size_t, [_I32, _I32]),
+    'fgs_shard_backward': (C.c_int32, [_P, C.POINTER(_I32), _P] + [_P] * 5 + [_P] * 6 + [_P, _P, _I32, _I32, C.POINTER(Settings), _P]),
     'fgs_blob_layout': (C.c_int32, [_I32] * 6 + [C.POINTER(BlobEntry), _I32]),
     'fgs_update_3d_filter': (C.c_int32, [_P] * 4 + [_I32, _I32, _I32] + [C.c_float] * 7 + [_P]),
     'fgs_relocation_table': (C.c_int32, [C.POINTER(C.c_float)]),
@@ -100,6 +107,6 @@ def library() -> C.CDLL:
             _LIB = bind(path)
         except OSError as exc:          # e.g. libamdhip64.so missing
             raise ExtensionError(f'failed to load {path}: {exc}') from exc
-        if _LIB.fgs_abi_version() != 1:
-            raise ExtensionError(f'{path} has ABI version {_LIB.fgs_abi_version()}, expected 1')
+        if _LIB.fgs_abi_version() != 2:
+            raise ExtensionError(f'{path} has ABI version {_LIB.fgs_abi_version()}, expected 2')
     return _LIB

@@ -37,10 +37,10 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-stage timing with HIP events recorded on the caller's stream (fgs_profile_enable / fgs_profile_read) ----
 enum Stage { ST_PREPROCESS, ST_DEPTH_SORT, ST_OFFSETS_SCAN, ST_CREATE_INSTANCES, ST_TILE_SORT, ST_RANGES, ST_BUCKET_SCAN,
-             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_COUNT };
+             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_RECORDS, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_scan", "create_instances", "tile_sort", "extract_ranges",
                                            "bucket_scan", "blend_forward", "stage_pixels", "blend_backward", "preprocess_backward",
-                                           "sh_rest_backward", "adam", "l1_dssim_loss"};
+                                           "sh_rest_backward", "adam", "l1_dssim_loss", "shard_records"};
 struct StageRecord { int stage; hipEvent_t start, stop; };
 struct Profiler {
     bool enabled = false;
@@ -165,6 +165,23 @@ struct BackwardScratch {
     }
 };
 
+int g_atomic_policy = 1;               // K11: 1 = lanes whose nine sums are all zero issue no atomics (fgs_debug_set_option key 4)
+int g_acc_records = 0;                 // 0: accumulators planar [9][N]; 1: one 36-byte record per primitive (fgs_debug_set_option key 3)
+uint32_t acc_es(uint32_t n) { return g_acc_records ? 1u : n; }
+uint32_t acc_ps() { return g_acc_records ? 9u : 1u; }
+
+// Record j of the renderer's pipeline lives at primitive index (j * spread_multiplier(n)) mod n: K1 appends the shard's
+// huge-footprint Gaussians -- the heavy hitters of K11's atomics, thousands of tiles each -- as ONE run at the end of its
+// compact list, and 32 neighbours in index share a 128-byte line of every accumulator plane (measured: K11 0.71 -> 0.97 ms
+// on the views with ~200 such Gaussians). The multiplier puts neighbours 132 bytes apart.
+uint32_t spread_multiplier(uint32_t n) {
+    if (n < 64) return 1;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+    uint32_t m = 33;
+    while (gcd(m, n) != 1) m += 2;
+    return m;
+}
+
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
 }
@@ -178,6 +195,18 @@ CameraArgs camera_of(const fgs_settings& s, const Geometry& g) {
     c.active_sh_bases = s.active_sh_bases; c.total_sh_rest = s.total_sh_bases_rest;
     c.grid_w = g.grid_w; c.grid_h = g.grid_h;
     return c;
+}
+
+BackwardView backward_view(const fgs_settings& s, const Geometry& g, const uint32_t* n_touched, const uint32_t* slot, const float* acc,
+                           uint32_t es, uint32_t ps, float* view_dir) {
+    BackwardView v;
+    v.cam = camera_of(s, g); v.n_touched = n_touched; v.slot = slot; v.acc = acc; v.acc_es = es; v.acc_ps = ps; v.view_dir = view_dir;
+    return v;
+}
+ShRestView sh_rest_view(const BackwardView& b) {
+    ShRestView v;
+    v.view_dir = b.view_dir; v.n_touched = b.n_touched; v.slot = b.slot; v.acc = b.acc; v.acc_es = b.acc_es; v.acc_ps = b.acc_ps;
+    return v;
 }
 
 int check_settings(const fgs_settings* s) {
@@ -209,6 +238,10 @@ AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps
 // shared by fgs_forward (training) and fgs_inference
 enum ForwardMode { MODE_TRAINING, MODE_INFERENCE, MODE_SCORES };
 
+int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
+                 uint32_t n_instances, const fgs_settings* settings, float* image, int to_chw, int clamp_output, fgs_resize_fn resize,
+                 void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores);
+
 int run_forward(ForwardMode mode, const float* means, const float* scales, const float* rotations, const float* opacities,
                 const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
                 int to_chw, int clamp_output, fgs_resize_fn resize, void* user, fgs_forward_state* state_out, void* stream_,
@@ -238,7 +271,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     Carver prim_c(prim_blob);
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
     FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
-    PreprocessArgs pa;
+    PreprocessArgs pa{};
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
     pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles;
@@ -252,6 +285,15 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     FGS_HIP(hipStreamSynchronize(stream));
     const uint32_t n_visible = host[0], n_instances = host[1];
 
+    return forward_tail(mode, pb, tb, geo, n_visible, n_instances, settings, image, to_chw, clamp_output, resize, user, state_out, stream, scores);
+}
+
+// K2..K10 over a filled primitive buffer (rec, n_touched, unsorted depth keys + indices of the n_visible visible entries)
+int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
+                 uint32_t n_instances, const fgs_settings* settings, float* image, int to_chw, int clamp_output, fgs_resize_fn resize,
+                 void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores) {
+    const bool training = mode == MODE_TRAINING;
+    PrimitiveBuffers pb = pb_in;
     // K2-K4 (fwd:104-127)
     int depth_sel = 0;
     { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
@@ -328,9 +370,10 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
     a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
+    a.acc_es = acc_es(static_cast<uint32_t>(n_primitives)); a.acc_ps = acc_ps();
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
-    a.proper_aa = settings->proper_antialiasing ? 1 : 0;
+    a.proper_aa = settings->proper_antialiasing ? 1 : 0; a.atomic_policy = g_atomic_policy;
     { StageScope t(ST_STAGE_PIXELS, stream); FGS_HIP(launch_stage_pixels(a, stream)); }
     { StageScope t(ST_BLEND_BACKWARD, stream); FGS_HIP(launch_blend_backward(a, stream)); }     // K11 (bwd:56)
     return FGS_OK;
@@ -394,15 +437,16 @@ int32_t fgs_backward(const float* grad_image, const float* image,
 
     PreprocessBackwardArgs a{};
     a.means = means; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.sh_rest = sh_coefficients_rest;
-    a.n_touched = P.pb.n_touched; a.acc = P.sc.acc; a.view_dir = P.sc.view_dir;
+    a.n_views = 1;
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, acc_es(static_cast<uint32_t>(n_primitives)), acc_ps(), P.sc.view_dir);
     a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
     a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
-    a.n = static_cast<uint32_t>(n_primitives); a.cam = camera_of(*settings, P.geo);
+    a.n = static_cast<uint32_t>(n_primitives);
     { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }   // K12 (bwd:94)
     if (settings->total_sh_bases_rest > 0) {
         if (!grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
         ShRestArgs s{};
-        s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc; s.grad_sh_rest = grad_sh_coefficients_rest;
+        s.n_views = 1; s.view[0] = sh_rest_view(a.view[0]); s.grad_sh_rest = grad_sh_coefficients_rest;
         s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
         { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, s, stream)); }
     }
@@ -430,8 +474,10 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
     // API group order (Model.py:238-245): 0 means, 1 sh0, 2 sh_rest, 3 opacities, 4 scales, 5 rotations
     PreprocessBackwardArgs a{};
     a.means = params[0]; a.scales = params[4]; a.rotations = params[5]; a.opacities = params[3]; a.sh_rest = params[2];
-    a.n_touched = P.pb.n_touched; a.acc = P.sc.acc; a.view_dir = P.sc.view_dir; a.densification_info = densification_info;
-    a.n = static_cast<uint32_t>(n_primitives); a.cam = camera_of(*settings, P.geo);
+    a.densification_info = densification_info;
+    a.n_views = 1;
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, acc_es(static_cast<uint32_t>(n_primitives)), acc_ps(), P.sc.view_dir);
+    a.n = static_cast<uint32_t>(n_primitives);
     const int map[5] = {0, 1, 3, 4, 5};     // kernel group order: means, sh0, opacities, scales, rotations
     for (int k = 0; k < 5; ++k) {
         a.p[k] = params[map[k]]; a.m[k] = exp_avgs[map[k]]; a.v[k] = exp_avg_sqs[map[k]];
@@ -442,10 +488,162 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
     { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(true, a, stream)); }
     if (settings->total_sh_bases_rest > 0) {
         ShRestArgs s{};
-        s.view_dir = P.sc.view_dir; s.n_touched = P.pb.n_touched; s.acc = P.sc.acc;
+        s.n_views = 1; s.view[0] = sh_rest_view(a.view[0]);
         s.p = params[2]; s.m = exp_avgs[2]; s.v = exp_avg_sqs[2]; s.h = adam_hyper(step, lrs[2], beta1, beta2, eps);
         s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
         { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(true, s, stream)); }
+    }
+    return FGS_OK;
+}
+
+// ---- Gaussian-sharded multi-GPU path (shard_exchange.hip; no reference counterpart, the reference is single-GPU) ----
+
+int32_t fgs_shard_preprocess(const float* means, const float* scales, const float* rotations, const float* opacities,
+                             const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                             int32_t n_views, const fgs_settings* settings, void* records_out, uint32_t* counts_out,
+                             fgs_resize_fn resize, void* resize_user, void* stream_) {
+    if (n_views < 1 || !settings) return fail(FGS_ERR_INVALID_ARGUMENT, "n_views %d / settings", n_views);
+    for (int v = 0; v < n_views; ++v) {
+        if (int rc = check_settings(settings + v)) return rc;
+        if (settings[v].width != settings[0].width || settings[v].height != settings[0].height || settings[v].total_sh_bases_rest != settings[0].total_sh_bases_rest)
+            return fail(FGS_ERR_INVALID_ARGUMENT, "all views of a step must share the image size and SH layout");
+    }
+    if (n_primitives < 0 || !counts_out || !resize || (n_primitives > 0 && !records_out)) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_primitives=%d)", n_primitives);
+    if (n_primitives > 0 && (!means || !scales || !rotations || !opacities || !sh_coefficients_0 || (settings->total_sh_bases_rest > 0 && !sh_coefficients_rest)))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint32_t n = static_cast<uint32_t>(n_primitives);
+    const Geometry geo = geometry_of(settings->width, settings->height);
+    Carver one(nullptr);
+    PrimitiveBuffers::carve(one, n);
+    const size_t per_view = one.total();
+    char* prim_blob = static_cast<char*>(resize(resize_user, FGS_BUF_PRIMITIVE, per_view * n_views));
+    if (!prim_blob && per_view > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", per_view * n_views);
+    for (int v0 = 0; v0 < n_views; v0 += kMaxBatchViews) {
+        PreprocessBatch pb{};
+        PackRecordsBatch rb{};
+        pb.n_views = rb.n_views = n_views - v0 < kMaxBatchViews ? n_views - v0 : kMaxBatchViews;
+        rb.capacity = n;
+        for (int k = 0; k < pb.n_views; ++k) {
+            const int v = v0 + k;
+            Carver c(prim_blob + per_view * v);
+            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
+            FGS_HIP(hipMemsetAsync(b.counters, 0, 4 * sizeof(uint32_t), stream));
+            PreprocessArgs& pa = pb.v[k];
+            pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
+            pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets;
+            pa.slot = b.keys[1];                   // the second depth-key buffer is free on this path (no sort on the owner)
+            pa.n = n; pa.cam = camera_of(settings[v], geo); pa.ranges = nullptr; pa.n_tiles = 0;   // the tile ranges belong to the renderer of the view
+            rb.v[k] = PackRecordsView{b.rec, b.n_touched, b.keys[0], b.prims[0], b.counters,
+                                      static_cast<uint32_t*>(records_out) + (size_t)v * n * kSplatRecordWords, counts_out + 2 * v};
+        }
+        if (n == 0) { FGS_HIP(hipMemsetAsync(counts_out + 2 * v0, 0, 2 * sizeof(uint32_t) * pb.n_views, stream)); continue; }
+        { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess_batch(pb, stream)); }
+        { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_splat_records(rb, stream)); }
+    }
+    return FGS_OK;
+}
+
+int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t n_instances, const fgs_settings* settings, float* image,
+                                 fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream_) {
+    if (int rc = check_settings(settings)) return rc;
+    if (n_records < 0 || n_instances < 0 || !image || !resize || !state_out || (n_records > 0 && !records))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_records=%d, n_instances=%d)", n_records, n_instances);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint32_t n = static_cast<uint32_t>(n_records);
+    const Geometry geo = geometry_of(settings->width, settings->height);
+    Carver tile_size(nullptr);
+    TileBuffers::carve(tile_size, geo.n_tiles, true);
+    void* tile_blob = resize(resize_user, FGS_BUF_TILE, tile_size.total());
+    if (!tile_blob && tile_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(tile, %zu) returned NULL", tile_size.total());
+    Carver tile_c(tile_blob);
+    TileBuffers tb = TileBuffers::carve(tile_c, geo.n_tiles, true);
+    Carver prim_size(nullptr);
+    PrimitiveBuffers::carve(prim_size, n);
+    void* prim_blob = resize(resize_user, FGS_BUF_PRIMITIVE, prim_size.total());
+    if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
+    Carver prim_c(prim_blob);
+    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
+    FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
+    { StageScope t(ST_RECORDS, stream);
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, spread_multiplier(n), pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, stream)); }
+    return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
+}
+
+int32_t fgs_backward_to_records(const float* grad_image, const float* image,
+                                void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                void* scratch, float* acc_records_out, int32_t n_records,
+                                const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
+    BackwardPlan P;
+    if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_records, settings, state)) return rc;
+    if (!grad_image || !image) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL image / grad_image");
+    if (n_records == 0) return FGS_OK;
+    if (!acc_records_out) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL acc_records_out");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream)) return rc;
+    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, acc_es(static_cast<uint32_t>(n_records)), acc_ps(), static_cast<uint32_t>(n_records),
+                                                            spread_multiplier(static_cast<uint32_t>(n_records)), acc_records_out, stream)); }
+    return FGS_OK;
+}
+
+size_t fgs_shard_backward_scratch_bytes(int32_t n_primitives, int32_t n_views) {
+    if (n_primitives < 0 || n_views < 1) return 0;
+    return ((size_t)n_primitives * 3 * sizeof(float) + 255) / 256 * 256 * (size_t)n_views + 256;     // one view-direction array per view
+}
+
+int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                           const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh_coefficients_rest,
+                           float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                           float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                           float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                           const fgs_settings* settings, void* stream_) {
+    if (n_views < 1 || !settings || !n_visible) return fail(FGS_ERR_INVALID_ARGUMENT, "n_views %d / settings / n_visible", n_views);
+    int64_t total_visible = 0;
+    for (int v = 0; v < n_views; ++v) {
+        if (int rc = check_settings(settings + v)) return rc;
+        if (n_visible[v] < 0 || n_visible[v] > n_primitives) return fail(FGS_ERR_INVALID_ARGUMENT, "view %d: n_visible %d of %d primitives", v, n_visible[v], n_primitives);
+        total_visible += n_visible[v];
+    }
+    if (n_primitives < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "n_primitives %d", n_primitives);
+    if (n_primitives == 0) return FGS_OK;
+    if (!primitive_buffers || !scratch || (total_visible > 0 && !acc_records)) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (!means || !scales || !rotations || !opacities || !grad_means || !grad_scales || !grad_rotations || !grad_opacities || !grad_sh_coefficients_0)
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter / gradient tensor");
+    if (settings->total_sh_bases_rest > 0 && !grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint32_t n = static_cast<uint32_t>(n_primitives);
+    const Geometry geo = geometry_of(settings->width, settings->height);
+    Carver one(nullptr);
+    PrimitiveBuffers::carve(one, n);
+    const size_t per_view = one.total();
+    const size_t dir_stride = ((size_t)n * 3 * sizeof(float) + 255) / 256 * 256;
+    char* const dir_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~static_cast<uintptr_t>(255));
+    size_t first_record = 0;
+    for (int v0 = 0; v0 < n_views; v0 += kMaxBatchViews) {
+        PreprocessBackwardArgs a{};
+        ShRestArgs sh{};
+        a.means = means; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.sh_rest = sh_coefficients_rest;
+        a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
+        a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
+        a.n = n; a.accumulate = v0 > 0 ? 1 : 0;           // gradients of a batch of views are summed in registers; later batches add
+        a.n_views = sh.n_views = n_views - v0 < kMaxBatchViews ? n_views - v0 : kMaxBatchViews;
+        for (int k = 0; k < a.n_views; ++k) {
+            const int v = v0 + k;
+            Carver c(const_cast<char*>(static_cast<const char*>(primitive_buffers)) + per_view * v);
+            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
+            // accumulator records are read in place through the slot table K1 left behind: no scatter pass, no dense copy
+            a.view[k] = backward_view(settings[v], geo, b.n_touched, b.keys[1], acc_records + first_record * kAccRecordWords, 1u,
+                                      static_cast<uint32_t>(kAccRecordWords), reinterpret_cast<float*>(dir_base + dir_stride * v));
+            sh.view[k] = sh_rest_view(a.view[k]);
+            first_record += static_cast<size_t>(n_visible[v]);
+        }
+        { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }
+        if (settings->total_sh_bases_rest > 0) {
+            sh.grad_sh_rest = grad_sh_coefficients_rest;
+            sh.n = n; sh.total_sh_rest = settings->total_sh_bases_rest; sh.active_sh_bases = settings->active_sh_bases; sh.accumulate = a.accumulate;
+            { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, sh, stream)); }
+        }
     }
     return FGS_OK;
 }
@@ -581,6 +779,8 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
+        case 3: g_acc_records = value ? 1 : 0; return FGS_OK;
+        case 4: g_atomic_policy = value ? 1 : 0; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }

@@ -19,9 +19,14 @@ struct PreprocessArgs {                 // K1
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
     uint32_t n;
+    uint32_t* slot;                                // sharded path: slot[i] = position of visible primitive i in the compacted list (else nullptr)
     CameraArgs cam;
 };
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s);
+// sharded path: the same Gaussians projected for up to kMaxBatchViews cameras in ONE launch (grid.y = view); a shard is too
+// small to fill the chip per view (3 M / 8 Gaussians = 733 workgroups) and 8 back-to-back launches measured 2.2x the time
+struct PreprocessBatch { int n_views; PreprocessArgs v[kMaxBatchViews]; };
+hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s);
 
 // K2-K4: depth sort of the visible list + exclusive scan of per-primitive tile counts in depth order
 size_t depth_sort_temp_bytes(uint32_t n);
@@ -61,33 +66,43 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const float* final_T; const uint32_t* n_processed; const uint32_t* max_n_processed;
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
-    float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    float* acc;                           // 9 sums per primitive: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    uint32_t acc_es, acc_ps;              // element k of primitive i lives at acc[k * acc_es + i * acc_ps]: planar (N, 1) or records (1, 9)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
+    int atomic_policy;                    // 0: one atomic per lane and sum; 1: lanes whose sums are all zero stay silent
 };
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s);      // per-pixel staging pass
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);    // K11 proper
 
 struct AdamHyper { float step_size, beta1, beta2, eps, bc2_sqrt_rcp; };
 
+struct BackwardView {                   // what K12 needs per camera view (one on the single-GPU path, up to kMaxBatchViews on the sharded path)
+    CameraArgs cam;
+    const uint32_t* n_touched;            // [N] tile count of the view, 0 = invisible
+    const uint32_t* slot;                 // sharded path: accumulator record of visible primitive i is slot[i]; nullptr: i itself
+    const float* acc; uint32_t acc_es, acc_ps;   // element k of accumulator record r lives at acc[k * acc_es + r * acc_ps]
+    float* view_dir;                      // [N][3] scratch: unit view direction of visible primitives, consumed by the SH-rest pass
+};
 struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for the 14 non-SH-rest floats
     const float* means; const float* scales; const float* rotations; const float* opacities; const float* sh_rest;
-    const uint32_t* n_touched; const float* acc;
-    float* view_dir;                      // [N][3] scratch: unit view direction of visible primitives, consumed by the SH-rest pass
     float* grad_means; float* grad_scales; float* grad_rotations; float* grad_opacities; float* grad_sh0;
     float* densification_info;
     uint32_t n;
-    CameraArgs cam;
-    // fused mode (grad_* unused): parameters and moments updated in place, order means, sh0, opacities, scales, rotations
+    int accumulate;                       // unfused only: add into grad_* for visible primitives instead of writing every element
+    int n_views; BackwardView view[kMaxBatchViews];   // gradients are summed over the views in registers
+    // fused mode (grad_* unused, one view): parameters and moments updated in place, order means, sh0, opacities, scales, rotations
     float* p[5]; float* m[5]; float* v[5]; AdamHyper h[5];
 };
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s);
 
+struct ShRestView { const float* view_dir; const uint32_t* n_touched; const uint32_t* slot; const float* acc; uint32_t acc_es, acc_ps; };
 struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload, streamed flat and fully coalesced
-    const float* view_dir; const uint32_t* n_touched; const float* acc;
+    int n_views; ShRestView view[kMaxBatchViews];
     float* grad_sh_rest;                  // unfused: [N][K-1][3] written for every primitive
-    float* p; float* m; float* v; AdamHyper h;   // fused
+    float* p; float* m; float* v; AdamHyper h;   // fused (one view)
     uint32_t n; uint32_t total_sh_rest; uint32_t active_sh_bases;
+    int accumulate;                       // unfused only: grad_sh_rest += (sharded path, view batches after the first)
 };
 hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s);
 
@@ -106,6 +121,15 @@ struct LossArgs {                       // fused L1 + DSSIM loss and its image g
 };
 size_t l1_dssim_partials(int width, int height);   // number of floats in LossArgs::partials
 hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s);
+
+// shard_exchange.hip: record (un)packing either side of the two exchanges of the Gaussian-sharded multi-GPU path
+struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const uint32_t* depth_keys; const uint32_t* prim_idx;
+                         const uint32_t* counters; uint32_t* out; uint32_t* counts_out; };
+struct PackRecordsBatch { int n_views; uint32_t capacity; PackRecordsView v[kMaxBatchViews]; };
+hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
+hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, uint32_t spread, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s);
+hipError_t launch_pack_acc(const float* acc, uint32_t acc_es, uint32_t acc_ps, uint32_t n, uint32_t spread, float* out, hipStream_t s);
 
 // aux_ops.hip: the reference's remaining exported operators
 hipError_t launch_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int n,

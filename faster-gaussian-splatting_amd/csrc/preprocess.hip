@@ -18,7 +18,7 @@ __device__ __forceinline__ int float_to_int_floor(float x) { return static_cast<
 __device__ __forceinline__ int float_to_int_ceil(float x) { return static_cast<int>(ceilf(fminf(fmaxf(x, -1.0e9f), 1.0e9f))); }
 
 template <bool INFERENCE>
-__global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const PreprocessArgs a) {
+__device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     const Camera cam = load_camera(a.cam);
     const unsigned gid = blockIdx.x * kPreprocessBlock + threadIdx.x;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
@@ -161,12 +161,17 @@ __global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const Prep
         for (unsigned w = 0; w < wave; ++w) off += s_vis[w];
         a.depth_keys[off] = __float_as_uint(depth);
         a.prim_idx[off] = idx;
+        if (a.slot != nullptr) a.slot[idx] = off;
     }
 }
 
+template <bool INFERENCE>
+__global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE>(a); }
+__global__ void __launch_bounds__(kPreprocessBlock) preprocess_batch_kernel(const PreprocessBatch b) { preprocess_body<false>(b.v[blockIdx.y]); }
+
 // Exact tile count + compaction for the few screen-filling footprints: one 256-thread workgroup per Gaussian, 256 candidate
 // tiles per step (kernel_utils.cuh:117-180 with the whole workgroup cooperating instead of one warp).
-__global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessArgs a) {
+__device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
     __shared__ unsigned s_cnt[4];
     const Camera cam = load_camera(a.cam);
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
@@ -195,11 +200,14 @@ __global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessAr
                 const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
                 a.depth_keys[off] = __float_as_uint(depth);
                 a.prim_idx[off] = idx;
+                if (a.slot != nullptr) a.slot[idx] = off;
             }
         }
         __syncthreads();
     }
 }
+__global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessArgs a) { preprocess_huge_body(a); }
+__global__ void __launch_bounds__(256) preprocess_huge_batch_kernel(const PreprocessBatch b) { preprocess_huge_body(b.v[blockIdx.y]); }
 
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
@@ -207,6 +215,15 @@ hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_
     if (inference) hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, s, a);
     hipLaunchKernelGGL(preprocess_huge_kernel, dim3(a.n < 1024u ? a.n : 1024u), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s) {
+    const uint32_t n = b.v[0].n;
+    if (n == 0 || b.n_views <= 0) return hipSuccess;
+    const dim3 grid((n + kPreprocessBlock - 1) / kPreprocessBlock, static_cast<unsigned>(b.n_views)), block(kPreprocessBlock);
+    hipLaunchKernelGGL(preprocess_batch_kernel, grid, block, 0, s, b);
+    hipLaunchKernelGGL(preprocess_huge_batch_kernel, dim3(n < 256u ? n : 256u, static_cast<unsigned>(b.n_views)), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -35,11 +35,14 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, const 
 constexpr int kGroupWidth[5] = {3, 3, 1, 3, 4};
 constexpr int kGroupOffset[5] = {0, 3, 6, 7, 10};
 
-template <bool FUSED>
+// MULTI: the sharded path's owner sums the gradient of its Gaussians over the views of the step in registers (one launch,
+// every gradient element written once) instead of one launch and one read-modify-write of the gradients per view.
+template <bool MULTI> __device__ __forceinline__ void sum_into(float& dst, const float v) { dst = MULTI ? dst + v : v; }
+
+template <bool FUSED, bool MULTI>
 __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
     const unsigned i = blockIdx.x * kPreprocessBackwardBlock + threadIdx.x;
     if (i >= a.n) return;
-    const Camera cam = load_camera(a.cam);
     const size_t n = a.n;
     float g_mean[3] = {0.0f, 0.0f, 0.0f}, g_scale[3] = {0.0f, 0.0f, 0.0f}, g_rot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float g_op[1] = {0.0f}, g_sh0[3] = {0.0f, 0.0f, 0.0f};
@@ -54,27 +57,36 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
             }
     }
 
-    if (a.n_touched[i] != 0) {                                                         // kb:45
-        float m[3], s[3], q[4];
+    bool visible = false;
+    float m[3] = {0.0f, 0.0f, 0.0f}, s[3] = {0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int n_views = MULTI ? a.n_views : 1;
+    for (int vw = 0; vw < n_views; ++vw) {
+        const BackwardView& V = a.view[MULTI ? vw : 0];
+        if (V.n_touched[i] == 0) continue;                                             // kb:45
+        if (!visible) {                                                                // parameters: once, whatever the number of views
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            m[k] = FUSED ? st_p[0 + k] : a.means[3 * (size_t)i + k];
-            s[k] = FUSED ? st_p[7 + k] : a.scales[3 * (size_t)i + k];
+            for (int k = 0; k < 3; ++k) {
+                m[k] = FUSED ? st_p[0 + k] : a.means[3 * (size_t)i + k];
+                s[k] = FUSED ? st_p[7 + k] : a.scales[3 * (size_t)i + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = FUSED ? st_p[10 + k] : a.rotations[4 * (size_t)i + k];
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = FUSED ? st_p[10 + k] : a.rotations[4 * (size_t)i + k];
-        const float gcol[3] = {a.acc[6 * n + i], a.acc[7 * n + i], a.acc[8 * n + i]};
+        visible = true;
+        const Camera cam = load_camera(V.cam);
+        const float* const accp = V.acc + (size_t)(V.slot != nullptr ? V.slot[i] : i) * V.acc_ps; const size_t es = V.acc_es;
+        const float gcol[3] = {accp[6 * es], accp[7 * es], accp[8 * es]};
 
         // ---- SH backward w.r.t. sh0 and the view direction (sh_utils.cuh:84-153) ----
 #pragma unroll
-        for (int c = 0; c < 3; ++c) g_sh0[c] = kC0 * gcol[c];
+        for (int c = 0; c < 3; ++c) sum_into<MULTI>(g_sh0[c], kC0 * gcol[c]);
         float dpos[3] = {0.0f, 0.0f, 0.0f};
         const unsigned active = static_cast<unsigned>(cam.active_sh_bases);
         if (active > 1) {
             const float xr = m[0] - cam.pos[0], yr = m[1] - cam.pos[1], zr = m[2] - cam.pos[2];
             const float inv = 1.0f / sqrtf(xr * xr + yr * yr + zr * zr);
             const float x = xr * inv, y = yr * inv, z = zr * inv;
-            a.view_dir[3 * (size_t)i] = x; a.view_dir[3 * (size_t)i + 1] = y; a.view_dir[3 * (size_t)i + 2] = z;
+            V.view_dir[3 * (size_t)i] = x; V.view_dir[3 * (size_t)i + 1] = y; V.view_dir[3 * (size_t)i + 2] = z;
             const float* k = a.sh_rest + (size_t)i * cam.total_sh_rest * 3;
             float gdx[3], gdy[3], gdz[3];
 #pragma unroll
@@ -118,16 +130,17 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         const float aa = ea * ea, bb = eb * eb, cc = ec * ec, ac = ea * ec, ab = ea * eb, bc = eb * ec;
         const float det = ac - bb;
         const float det_rcp_sq = 1.0f / (det * det);
-        const float gcx = a.acc[2 * n + i], gcy = a.acc[3 * n + i], gcz = a.acc[4 * n + i];
+        const float gcx = accp[2 * es], gcy = accp[3 * es], gcz = accp[4 * es];
         const float dcov_x = det_rcp_sq * (2.0f * bc * gcy - cc * gcx - bb * gcz);     // kb:130-134
         const float dcov_y = det_rcp_sq * (bc * gcx - (ac + bb) * gcy + ab * gcz);
         const float dcov_z = det_rcp_sq * (2.0f * ab * gcy - bb * gcx - aa * gcz);
-        g_op[0] = a.acc[5 * n + i];
+        float d_opacity = accp[5 * es];
         if (cam.proper_aa) {                                                           // kb:137-145 (cov2d branch off, cfg:12)
             const float opacity = sigmoid_f(FUSED ? st_p[6] : a.opacities[i]);
             const float det_raw = P.a_raw * P.c_raw - bb;
-            g_op[0] = g_op[0] * sqrtf(fmaxf(det_raw / det, 0.0f)) * opacity * (1.0f - opacity);
+            d_opacity = d_opacity * sqrtf(fmaxf(det_raw / det, 0.0f)) * opacity * (1.0f - opacity);
         }
+        sum_into<MULTI>(g_op[0], d_opacity);
         const float* j1 = P.jw1; const float* j2 = P.jw2;
         float d3[6];                                                                   // kb:163-170
         d3[0] = j1[0] * j1[0] * dcov_x + 2.0f * j1[0] * j2[0] * dcov_y + j2[0] * j2[0] * dcov_z;
@@ -146,7 +159,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         const float dj22 = cam.r2[0] * djw2[0] + cam.r2[1] * djw2[1] + cam.r2[2] * djw2[2];
         const float dj13 = cam.r3[0] * djw1[0] + cam.r3[1] * djw1[1] + cam.r3[2] * djw1[2];
         const float dj23 = cam.r3[0] * djw2[0] + cam.r3[1] * djw2[1] + cam.r3[2] * djw2[2];
-        const float gm2x = a.acc[i], gm2y = a.acc[n + i];
+        const float gm2x = accp[0], gm2y = accp[es];
         if (a.densification_info != nullptr) {                                         // kb:194-201
             a.densification_info[i] += 1.0f;
             const float nx = 0.5f * (gm2x * cam.width), ny = 0.5f * (gm2y * cam.height);
@@ -164,13 +177,13 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         dcam[2] += (P.j11 * (fxm * P.x_clipped * dj13 - dj11) + P.j22 * (fym * P.y_clipped * dj23 - dj22)) / P.depth;
 #pragma unroll
         for (int k = 0; k < 3; ++k)                                                    // kb:220-228
-            g_mean[k] = (cam.r1[k] * dcam[0] + cam.r2[k] * dcam[1] + cam.r3[k] * dcam[2]) + dpos[k];
+            sum_into<MULTI>(g_mean[k], (cam.r1[k] * dcam[0] + cam.r2[k] * dcam[1] + cam.r3[k] * dcam[2]) + dpos[k]);
         const float* R = P.R; const float* G = P.RSS;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                                                  // kb:231-240
             const float dvar = R[k] * R[k] * d3[0] + R[3 + k] * R[3 + k] * d3[3] + R[6 + k] * R[6 + k] * d3[5]
                                + 2.0f * (R[k] * R[3 + k] * d3[1] + R[k] * R[6 + k] * d3[2] + R[3 + k] * R[6 + k] * d3[4]);
-            g_scale[k] = 2.0f * P.var[k] * dvar;
+            sum_into<MULTI>(g_scale[k], 2.0f * P.var[k] * dvar);
         }
         float dR[9];                                                                   // kb:243-253
 #pragma unroll
@@ -179,7 +192,10 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
             dR[3 + k] = 2.0f * (G[0 + k] * d3[1] + G[3 + k] * d3[3] + G[6 + k] * d3[4]);
             dR[6 + k] = 2.0f * (G[0 + k] * d3[2] + G[3 + k] * d3[4] + G[6 + k] * d3[5]);
         }
-        quat_to_rotation_backward(q[0], q[1], q[2], q[3], dR, g_rot);
+        float d_rot[4];
+        quat_to_rotation_backward(q[0], q[1], q[2], q[3], dR, d_rot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum_into<MULTI>(g_rot[k], d_rot[k]);
     }
 
     // group order: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations. Every element is written (zeros if invisible).
@@ -196,8 +212,10 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         for (int k = 0; k < kGroupWidth[grp]; ++k) {
             const size_t e = (size_t)i * kGroupWidth[grp] + k;
             const int o = kGroupOffset[grp] + k;
-            if (!FUSED) outs[grp][e] = grad[o];
-            else {
+            if (!FUSED) {
+                if (!a.accumulate) outs[grp][e] = grad[o];
+                else if (visible) outs[grp][e] += grad[o];
+            } else {
                 adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
                 a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
             }
@@ -207,8 +225,9 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBackwardBlock - 1) / kPreprocessBackwardBlock), block(kPreprocessBackwardBlock);
-    if (fused_adam) hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, s, a);
+    if (fused_adam) hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, 0, s, a);
+    else if (a.n_views == 1) hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -218,16 +237,22 @@ hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardA
 struct PairGrad { float b; float c[3]; };
 
 template <int RT>
-__device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const uint32_t pair_in, const uint32_t n_pairs) {
+__device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShRestView& V, const uint32_t pair_in, const uint32_t n_pairs) {
     // All seven loads are issued unconditionally (one memory round trip instead of a dependent chain); the result is
     // SELECTED to zero for invisible Gaussians / inactive degrees because their view_dir slot is uninitialised scratch.
     const uint32_t pair = pair_in < n_pairs ? pair_in : n_pairs - 1u;
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t gi = pair / R, k = pair - gi * R;
-    const size_t n = a.n;
-    const uint32_t touched = a.n_touched[gi];
-    const float x = a.view_dir[3 * (size_t)gi], y = a.view_dir[3 * (size_t)gi + 1], z = a.view_dir[3 * (size_t)gi + 2];
-    const float c0 = a.acc[6 * n + gi], c1 = a.acc[7 * n + gi], c2 = a.acc[8 * n + gi];
+    const uint32_t touched = V.n_touched[gi];
+    const float x = V.view_dir[3 * (size_t)gi], y = V.view_dir[3 * (size_t)gi + 1], z = V.view_dir[3 * (size_t)gi + 2];
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    if (V.slot == nullptr) {             // dense accumulators: always in bounds, requested together with everything else
+        const float* const accp = V.acc + (size_t)gi * V.acc_ps;
+        c0 = accp[6 * (size_t)V.acc_es]; c1 = accp[7 * (size_t)V.acc_es]; c2 = accp[8 * (size_t)V.acc_es];
+    } else if (touched != 0) {           // sharded path: a record exists only for visible primitives (slot[] of the others is scratch)
+        const float* const accp = V.acc + (size_t)V.slot[gi] * V.acc_ps;
+        c0 = accp[6 * (size_t)V.acc_es]; c1 = accp[7 * (size_t)V.acc_es]; c2 = accp[8 * (size_t)V.acc_es];
+    }
     // coefficient k belongs to degree 1 (k<3), 2 (k<8), 3 (k<15); it receives a gradient only if that degree is active
     const bool degree_on = (k < 3 && a.active_sh_bases > 1) || (k >= 3 && k < 8 && a.active_sh_bases > 4) ||
                            (k >= 8 && k < 15 && a.active_sh_bases > 9);
@@ -245,6 +270,17 @@ __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const uin
     return r;
 }
 
+// gradient of one (Gaussian, basis) pair summed over the views of the launch: out[c] = sum_v basis_k(dir_v) * dL/dcolour_v[c]
+template <int RT>
+__device__ __forceinline__ void pair_gradient_sum(const ShRestArgs& a, const uint32_t pair, const uint32_t n_pairs, float (&out)[3]) {
+    const PairGrad q = pair_gradient<RT>(a, a.view[0], pair, n_pairs);
+    out[0] = q.b * q.c[0]; out[1] = q.b * q.c[1]; out[2] = q.b * q.c[2];
+    for (int vw = 1; vw < a.n_views; ++vw) {
+        const PairGrad w = pair_gradient<RT>(a, a.view[vw], pair, n_pairs);
+        out[0] += w.b * w.c[0]; out[1] += w.b * w.c[1]; out[2] += w.b * w.c[2];
+    }
+}
+
 // Unfused form: one lane per (Gaussian, basis) pair writes its 12 bytes (one basis evaluation per 12 B; the float4 form
 // below needs two per 16 B and measured slower for a pure 540 MB write), two pairs per lane for memory-level parallelism.
 template <int RT>
@@ -252,9 +288,16 @@ __global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs 
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t n_pairs = a.n * R;
     const uint32_t p0 = blockIdx.x * 512u + threadIdx.x, p1 = p0 + 256u;
-    const PairGrad q0 = pair_gradient<RT>(a, p0, n_pairs), q1 = pair_gradient<RT>(a, p1, n_pairs);
-    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = q0.b * q0.c[0]; o[1] = q0.b * q0.c[1]; o[2] = q0.b * q0.c[2]; }
-    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = q1.b * q1.c[0]; o[1] = q1.b * q1.c[1]; o[2] = q1.b * q1.c[2]; }
+    float g0[3], g1[3];
+    pair_gradient_sum<RT>(a, p0, n_pairs, g0);
+    pair_gradient_sum<RT>(a, p1, n_pairs, g1);
+    if (a.accumulate) {                  // view batches after the first: an all-zero gradient adds nothing, skip the read-modify-write
+        if (p0 < n_pairs && ((g0[0] != 0.0f) | (g0[1] != 0.0f) | (g0[2] != 0.0f))) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] += g0[0]; o[1] += g0[1]; o[2] += g0[2]; }
+        if (p1 < n_pairs && ((g1[0] != 0.0f) | (g1[1] != 0.0f) | (g1[2] != 0.0f))) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] += g1[0]; o[1] += g1[1]; o[2] += g1[2]; }
+        return;
+    }
+    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = g0[0]; o[1] = g0[1]; o[2] = g0[2]; }
+    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = g1[0]; o[1] = g1[1]; o[2] = g1[2]; }
 }
 
 template <bool FUSED, int RT>
@@ -273,7 +316,7 @@ __global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs 
             m4 = load_float4_nt(a.m + e0);
             v4 = load_float4_nt(a.v + e0);
         }
-        const PairGrad q0 = pair_gradient<RT>(a, p0, n_pairs), q1 = pair_gradient<RT>(a, p0 + 1u, n_pairs);
+        const PairGrad q0 = pair_gradient<RT>(a, a.view[0], p0, n_pairs), q1 = pair_gradient<RT>(a, a.view[0], p0 + 1u, n_pairs);
         float g[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

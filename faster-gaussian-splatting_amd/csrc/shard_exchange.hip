@@ -1,0 +1,87 @@
+// Gaussian-sharded multi-GPU path: the three small kernels either side of the two xGMI exchanges.
+//
+// The reference is single-GPU (Renderer.py:58-61). With parameters replicated, a data-parallel step has to move the
+// whole 236-B/Gaussian gradient and parameter set over xGMI every iteration (708 MB at 3 M Gaussians).
+// Here every rank OWNS N/G Gaussians (parameters + Adam moments), projects them for all G views of the step (K1), and
+// ships only what the renderer of a view needs: one 56-byte projected record per VISIBLE Gaussian. The renderer sends
+// back the 36-byte pixel-space gradient accumulators, and the owner finishes K12 + Adam on its shard. Wire volume per
+// step drops from 2 x 236 B x N to (56 + 36) B x V.
+//
+//   owner:    K1 on the shard  -> pack_splat_records  ==all-to-all==>  unpack_splat_records -> K2..K10   :renderer
+//   owner:    K12 (reads the records in place through K1's slot table), K13  <==all-to-all==  pack_acc <- K11  :renderer
+#include "fgs_kernels.h"
+
+namespace fgs {
+
+static_assert(kSplatRecordWords == 14 && sizeof(PrimRec) == 48, "a splat record is the 48-byte PrimRec + depth key + tile count");
+
+// One lane per visible Gaussian j of a (shard, view), in the order K1 compacted them; grid.y = view; `counts_out` = (V, I).
+__global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecordsBatch b) {
+    const PackRecordsView& w = b.v[blockIdx.y];
+    const uint32_t n_visible = w.counters[0];
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j == 0) { w.counts_out[0] = n_visible; w.counts_out[1] = w.counters[1]; }
+    if (j >= n_visible) return;
+    const uint32_t i = w.prim_idx[j];
+    const uint4* r = reinterpret_cast<const uint4*>(w.rec + i);
+    const uint4 a = r[0], c = r[1], d = r[2];
+    uint2* o = reinterpret_cast<uint2*>(w.out + (size_t)kSplatRecordWords * j);      // 56-byte records: 8-byte aligned
+    o[0] = make_uint2(a.x, a.y); o[1] = make_uint2(a.z, a.w);
+    o[2] = make_uint2(c.x, c.y); o[3] = make_uint2(c.z, c.w);
+    o[4] = make_uint2(d.x, d.y); o[5] = make_uint2(d.z, d.w);
+    o[6] = make_uint2(w.depth_keys[j], w.n_touched[i]);
+}
+
+// Renderer side: the concatenated records of all shards become the primitives of a pipeline that starts at K2 (record j
+// is primitive j * spread mod n).
+// Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
+__global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, uint32_t spread, PrimRec* __restrict__ rec,
+                                                                   uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
+                                                                   uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t t = j; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+    if (j >= n) return;
+    const uint2* m = reinterpret_cast<const uint2*>(records + (size_t)kSplatRecordWords * j);
+    const uint2 w0 = m[0], w1 = m[1], w2 = m[2], w3 = m[3], w4 = m[4], w5 = m[5], w6 = m[6];
+    const uint32_t d = static_cast<uint32_t>((uint64_t)j * spread % n);          // see spread_multiplier() in api.hip
+    uint4* r = reinterpret_cast<uint4*>(rec + d);
+    r[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
+    r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
+    r[2] = make_uint4(w4.x, w4.y, w5.x, w5.y);
+    depth_keys[j] = w6.x; prim_idx[j] = d; n_touched[d] = w6.y;
+}
+
+// planar accumulators [9][n] (what K11 adds into) -> one 36-byte record per record j, ready to be cut into per-shard segments
+__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t es, uint32_t ps, uint32_t n, uint32_t spread,
+                                                       float* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t d = static_cast<uint32_t>((uint64_t)j * spread % n);
+    float v[kAccRecordWords];
+#pragma unroll
+    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * es + (size_t)d * ps];
+#pragma unroll
+    for (int k = 0; k < kAccRecordWords; ++k) out[(size_t)kAccRecordWords * j + k] = v[k];
+}
+
+hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
+    if (b.n_views <= 0) return hipSuccess;
+    const dim3 grid(b.capacity == 0 ? 1u : (b.capacity + 255u) / 256u, static_cast<unsigned>(b.n_views)), block(256);
+    hipLaunchKernelGGL(pack_splat_records_kernel, grid, block, 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, uint32_t spread, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s) {
+    const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, spread, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_acc(const float* acc, uint32_t es, uint32_t ps, uint32_t n, uint32_t spread, float* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, es, ps, n, spread, out);
+    return hipGetLastError();
+}
+
+}  // namespace fgs

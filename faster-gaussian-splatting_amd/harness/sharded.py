@@ -1,0 +1,216 @@
+"""Gaussian-sharded view-parallel training step: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+
+`ViewParallelTrainer` (distributed.py) replicates the parameters, so every step moves the whole gradient / parameter set
+over xGMI: 2 x 236 B per Gaussian per rank (reduce-scatter + all-gather), 708 MB each way at 3 M Gaussians. xGMI is
+point-to-point (7 links x ~77 GB/s per direction per GPU; TWO ranks share ONE link), so that exchange costs more than the
+whole single-GPU iteration at G = 2 and still ~3 ms at G = 8.
+
+Here rank r OWNS the Gaussians r, r+G, r+2G, ... (parameters, gradients, Adam moments: 1/G of the memory) and the step is
+cut where the per-Gaussian data is small (include/fgs_hip.h, "Gaussian-sharded multi-GPU path"):
+
+    every rank, the G views of the step in one launch: K1 on its shard          -> 56-B records of the visible
+    all-to-all #1                                       records of view v        -> rank v
+    rank v:                                             K2..K10, loss, K11       -> 36-B accumulator per record
+    all-to-all #2                                       accumulators             -> back to the owners
+    every rank, all views in one launch:                K12 on its shard (sums over views), then ONE Adam launch on the shard
+
+Wire volume per rank and step: (56 + 36) B x V x (G-1)/G  (V = visible Gaussians of a view, ~2 M at S2) = ~160 MB at G = 8
+instead of 1 240 MB, spread over all 7 links; K1 and K12 do the same total work as on one GPU, Adam does 1/G of it.
+One host synchronisation per step (the G x G table of record counts).
+
+The per-view loss is averaged over the G views, so the update equals one Adam step on the mean of the per-view losses --
+the same mathematics as `ViewParallelTrainer`, up to fp32 summation order.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+
+from FasterGSCudaBackend import _lib
+from FasterGSCudaBackend._backend import Backend, RasterizerSettings
+
+from .distributed import SEGMENTS, _ALIGN, _BACKWARD_ORDER, l1_grad
+
+
+def shard_of(params: dict, rank: int, world: int) -> dict:
+    """Strided ownership: every shard sees the same spatial distribution, so the per-(shard, view) record counts -- the
+    all-to-all message sizes -- are balanced whatever the memory order (Morton, Model.py:357-366) of the scene."""
+    return {k: v[rank::world].contiguous() for k, v in params.items()}
+
+
+class ShardedTrainer:
+    def __init__(self, backend: Backend, shard_params: dict, lrs: dict, *, group=None, betas=(0.9, 0.999), eps: float = 1e-15,
+                 loss: str = 'l1_dssim') -> None:
+        assert loss in ('l1', 'l1_dssim')
+        self.be, self.group, self.betas, self.eps, self.loss = backend, group, betas, eps, loss
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        device = shard_params['means'].device
+        self.device = device
+        self.n = shard_params['means'].shape[0]
+        self.total_sh_rest = shard_params['sh_coefficients_rest'].shape[1]
+        # one arena each for the shard's parameters, gradients and the two Adam moments -> ONE Adam launch
+        self.layout, off = {}, 0
+        for k in SEGMENTS:
+            self.layout[k] = (off, shard_params[k].numel(), tuple(shard_params[k].shape))
+            off += (shard_params[k].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.param_arena = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad_arena = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        self.params, self.grads = {}, {}
+        for k in SEGMENTS:
+            o, n, shape = self.layout[k]
+            self.params[k] = self.param_arena[o:o + n].view(shape)
+            self.params[k].copy_(shard_params[k])
+            self.grads[k] = self.grad_arena[o:o + n].view(shape)
+        self.lrs = dict(lrs)
+        self.step_count = 0
+        self.densification_info = torch.zeros((2, self.n), dtype=torch.float32, device=device)
+        # send side of exchange #1: the shard's records for each view of the step, and their (V, I) counts
+        self.records = torch.empty((self.world, max(self.n, 1), _lib.SPLAT_RECORD_BYTES), dtype=torch.uint8, device=device)
+        self.counts = torch.zeros((self.world, 2), dtype=torch.int32, device=device)
+        self.last_counts = None       # [G shards, G views, 2] of the last step (host), for reporting
+
+    # ---- exchanges ------------------------------------------------------------------------------------------------
+    def _all_to_all(self, pieces: Sequence[torch.Tensor], recv_rows: Sequence[int]) -> torch.Tensor:
+        """pieces[j] goes to rank j; returns the concatenation of what ranks 0..G-1 sent here (rows along dim 0)."""
+        if self.world == 1:
+            return pieces[0]
+        send = torch.cat(list(pieces), dim=0)
+        recv = torch.empty((sum(recv_rows),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, [int(x) for x in recv_rows], [int(p.shape[0]) for p in pieces], group=self.group)
+        return recv
+
+    def _gather_counts(self) -> torch.Tensor:
+        if self.world == 1:
+            return self.counts.cpu().view(1, 1, 2)
+        table = torch.empty(self.world * self.world * 2, dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(table, self.counts.view(-1), group=self.group)
+        return table.cpu().view(self.world, self.world, 2)       # the one host synchronisation of the step
+
+    def image_gradient(self, image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if self.loss == 'l1':
+            return l1_grad(image, target, 1.0 / self.world)
+        grad = self.be.l1_dssim(image, target, 0.8, 0.2, with_grad=True)[1]
+        return grad if self.world == 1 else grad * (1.0 / self.world)
+
+    # ---- the three compute phases of a step (no communication inside) ------------------------------------------------------
+    def project(self, views: Sequence[RasterizerSettings]) -> torch.Tensor:
+        """Phase A (owner): K1 on the shard for every view (one batched launch); fills self.records / self.counts, returns the
+        primitive buffer of the step."""
+        p = self.params
+        tensors = (p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_0'], p['sh_coefficients_rest'])
+        return self.be.shard_preprocess(*tensors, views, self.records, self.counts)
+
+    def render(self, records: torch.Tensor, n_instances: int, view: RasterizerSettings, target: torch.Tensor):
+        """Phase B (renderer of `view`): K2..K10, loss gradient, K11 -> (image, accumulator records [n_records, 9])."""
+        res = self.be.forward_from_records(records.view(-1), records.shape[0], n_instances, view, self.total_sh_rest)
+        grad_image = self.image_gradient(res.image, target)
+        acc = self.be.backward_to_records(grad_image, res.image, res.buffers, view, res.state, self.total_sh_rest)
+        return res.image, acc
+
+    def finish(self, views: Sequence[RasterizerSettings], prim: torch.Tensor, acc_back: torch.Tensor, sent: Sequence[int],
+               update_densification: bool) -> None:
+        """Phase C (owner): K12 on the shard, gradients summed over the views in registers (one launch), then one Adam launch."""
+        p = self.params
+        grads = tuple(self.grads[k] for k in _BACKWARD_ORDER)
+        dens = self.densification_info if update_densification else None
+        self.be.shard_backward(acc_back, sent, prim, dens, p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_rest'],
+                               views, grads)
+        self.step_count += 1
+        segs = [(k, self.layout[k][0], self.layout[k][0] + self.layout[k][1]) for k in SEGMENTS if self.layout[k][1] > 0]
+        self.be.adam_step_multi([self.grad_arena[a:b] for _, a, b in segs], [self.param_arena[a:b] for _, a, b in segs],
+                                [self.exp_avg[a:b] for _, a, b in segs], [self.exp_avg_sq[a:b] for _, a, b in segs],
+                                [self.step_count] * len(segs), [self.lrs[k] for k, _, _ in segs], self.betas[0], self.betas[1], self.eps)
+
+    # ---- public ---------------------------------------------------------------------------------------------------
+    def step(self, views: Sequence[RasterizerSettings], target: torch.Tensor, *, update_densification: bool = True) -> torch.Tensor:
+        """One optimizer step over the global batch `views` (len == world; view v is rendered by rank v, `target` is the
+        ground truth of views[rank]). Every rank must pass the same `views`."""
+        assert len(views) == self.world
+        G, r = self.world, self.rank
+        prim = self.project(views)
+        table = self._gather_counts()                                        # [shard, view, (V, I)]
+        self.last_counts = table
+        sent = [int(table[r, v, 0]) for v in range(G)]                      # my records per view
+        got = [int(table[s, r, 0]) for s in range(G)]                       # records of my view per shard
+        records = self._all_to_all([self.records[v, :sent[v]] for v in range(G)], got)
+        image, acc = self.render(records, int(table[:, r, 1].sum()), views[r], target)
+        offs = [0]
+        for c in got:
+            offs.append(offs[-1] + c)
+        acc_back = self._all_to_all([acc[offs[s]:offs[s + 1]] for s in range(G)], sent)
+        self.finish(views, prim, acc_back, sent, update_densification)
+        return image
+
+    def gather_parameters(self) -> dict:
+        """All ranks' shards interleaved back into the global order (export / evaluation; not part of a step)."""
+        if self.world == 1:
+            return {k: v.clone() for k, v in self.params.items()}
+        out = {}
+        for k in SEGMENTS:
+            mine = self.params[k]
+            sizes = torch.tensor([mine.shape[0]], dtype=torch.int64, device=self.device)
+            all_sizes = [torch.empty_like(sizes) for _ in range(self.world)]
+            dist.all_gather(all_sizes, sizes, group=self.group)
+            rows = [int(s) for s in all_sizes]
+            pad = max(rows)
+            buf = torch.zeros((pad,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=self.device)
+            buf[:mine.shape[0]] = mine
+            parts = [torch.empty_like(buf) for _ in range(self.world)]
+            dist.all_gather(parts, buf, group=self.group)
+            full = torch.empty((sum(rows),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=self.device)
+            for s in range(self.world):
+                full[s::self.world] = parts[s][:rows[s]]
+            out[k] = full
+        return out
+
+    def set_learning_rates(self, lrs: dict) -> None:
+        self.lrs.update(lrs)
+
+
+class LocalShardGroup:
+    """All G shard owners of a step inside ONE process, exchanging through local copies instead of RCCL: the functional twin of
+    G ranks. Used by the tests (multi-shard logic on a single GPU) and by tools/sharded_emulation.py, which times it to get the
+    per-rank COMPUTE cost of the sharded step (total / G) next to the single-GPU iteration."""
+
+    def __init__(self, backend: Backend, params: dict, lrs: dict, world: int, **kw) -> None:
+        self.world = world
+        self.ranks = [ShardedTrainer(backend, shard_of(params, r, world), lrs, **kw) for r in range(world)]
+        for r, t in enumerate(self.ranks):
+            t.world, t.rank = world, r                      # loss scaling 1/G and record buffers for G views
+            t.records = torch.empty((world, max(t.n, 1), _lib.SPLAT_RECORD_BYTES), dtype=torch.uint8, device=t.device)
+            t.counts = torch.zeros((world, 2), dtype=torch.int32, device=t.device)
+
+    def step(self, views: Sequence[RasterizerSettings], targets: Sequence[torch.Tensor], *, update_densification: bool = True) -> list:
+        G = self.world
+        prims = [t.project(views) for t in self.ranks]
+        table = torch.stack([t.counts for t in self.ranks]).cpu()            # [shard, view, (V, I)]
+        images, accs = [], []
+        for v in range(G):
+            records = torch.cat([self.ranks[s].records[v, :int(table[s, v, 0])] for s in range(G)], dim=0)
+            image, acc = self.ranks[v].render(records, int(table[:, v, 1].sum()), views[v], targets[v])
+            images.append(image)
+            accs.append(acc)
+        for s in range(G):
+            sent = [int(table[s, v, 0]) for v in range(G)]
+            pieces = []
+            for v in range(G):
+                o = int(table[:s, v, 0].sum())
+                pieces.append(accs[v][o:o + sent[v]])
+            self.ranks[s].finish(views, prims[s], torch.cat(pieces, dim=0), sent, update_densification)
+        self.last_counts = table
+        return images
+
+    def gather_parameters(self) -> dict:
+        out = {}
+        for k in SEGMENTS:
+            parts = [t.params[k] for t in self.ranks]
+            full = torch.empty((sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+            for s, p in enumerate(parts):
+                full[s::self.world] = p
+            out[k] = full
+        return out

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FGS_ABI_VERSION 1
+#define FGS_ABI_VERSION 2
 
 typedef enum fgs_status {
     FGS_OK = 0,
@@ -120,6 +120,61 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
                                 float* densification_info, void* scratch,
                                 int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state,
                                 int32_t step, const double* lrs, double beta1, double beta2, double eps, void* stream);
+
+/* ---- Gaussian-sharded multi-GPU path ------------------------------------------------------------------------------
+ * The reference is single-GPU (Renderer.py:58-61, no collective anywhere: SURVEY.md D4 / 8e); these four entry points
+ * are the MI355X-side addition that lets G ranks each OWN N/G Gaussians and still render whole views: the pipeline of
+ * fgs_forward / fgs_backward cut at the two places where per-Gaussian data is small.
+ *
+ *   owner of a shard, all views of the step at once: fgs_shard_preprocess    K1 -> 56-byte projected records of the visible
+ *   -- all-to-all (records of view v go to the rank rendering v) --
+ *   renderer of a view:                            fgs_forward_from_records  K2..K10 over the concatenated records
+ *                                                  fgs_backward_to_records   K11 -> 36-byte accumulator record per record
+ *   -- all-to-all back (segment s returns to the owner of shard s) --
+ *   owner, all views at once:                      fgs_shard_backward        K12 on the shard, summing over views
+ *
+ * A splat record is the private 48-byte projected primitive + its depth key + its tile count; opaque to callers, only
+ * its size is ABI. Records of a (shard, view) keep the order K1 compacted them in; accumulator records come back in
+ * the same order. */
+#define FGS_SPLAT_RECORD_BYTES 56
+#define FGS_ACC_RECORD_BYTES 36
+
+/* K1 over the shard for the n_views cameras of the step in one launch per 8 views. settings: [host] array of n_views
+ * (same image size and SH layout). records_out: n_views x n_primitives records, view-major (view v starts at record
+ * v * n_primitives; its first n_visible[v] are filled). counts_out: n_views x 2 uint32 device words, (n_visible,
+ * n_instances) per view -- read them back for all views at once. Requests FGS_BUF_PRIMITIVE only; keep that buffer until
+ * fgs_shard_backward of the same step. No host synchronisation. */
+int32_t fgs_shard_preprocess(const float* means, const float* scales, const float* rotations, const float* opacities,
+                             const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                             int32_t n_views, const fgs_settings* settings, void* records_out, uint32_t* counts_out,
+                             fgs_resize_fn resize, void* resize_user, void* stream);
+
+/* fgs_forward with K1 replaced by n_records received records (any concatenation order). n_instances MUST be the sum of
+ * the producers' instance counts (their counts_out[1]); it sizes the instance buffer. No host synchronisation. */
+int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t n_instances, const fgs_settings* settings,
+                                 float* image, fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
+
+/* K11 over the buffers of fgs_forward_from_records; acc_records_out[n_records] (36 bytes each, record order).
+ * scratch: fgs_backward_scratch_bytes(n_records, width, height). */
+int32_t fgs_backward_to_records(const float* grad_image, const float* image,
+                                void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                void* scratch, float* acc_records_out, int32_t n_records,
+                                const fgs_settings* settings, const fgs_forward_state* state, void* stream);
+
+/* K12 on the shard for all views of the step: acc_records = the accumulator records returned for the records of
+ * fgs_shard_preprocess, concatenated in view order (n_visible[v] records for view v, [host] array; same order as they
+ * were sent), primitive_buffers = that call's FGS_BUF_PRIMITIVE, settings = the same array. The gradients of each
+ * Gaussian are summed over the views and every gradient element is written once (zeros where no view sees it);
+ * densification_info [2,N] or NULL is accumulated per visible view as in fgs_backward.
+ * scratch: fgs_shard_backward_scratch_bytes(n_primitives, n_views). */
+size_t fgs_shard_backward_scratch_bytes(int32_t n_primitives, int32_t n_views);
+int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                           const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh_coefficients_rest,
+                           float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                           float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                           float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                           const fgs_settings* settings, void* stream);
 
 /* Test/bench introspection: byte offsets of the named sub-arrays inside a scratch buffer, so tests can compare every
  * intermediate with the oracle. Returns the number of entries written (<= max_entries); names are static strings. */

@@ -25,11 +25,13 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipMemcpyDeviceToHost = 2, hipH
 typedef void* hipStream_t;
 
 struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 namespace sim {
 

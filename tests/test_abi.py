@@ -30,7 +30,7 @@ def test_header_symbols_are_exported_and_bound(hip_lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(hip_lib, name) is not None
-    assert hip_lib.fgs_abi_version() == 1
+    assert hip_lib.fgs_abi_version() == 2
     assert b'gfx950' in hip_lib.fgs_build_info()
 
 

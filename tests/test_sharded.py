@@ -1,0 +1,183 @@
+"""CPU tests of the Gaussian-sharded multi-GPU path (include/fgs_hip.h "Gaussian-sharded multi-GPU path",
+harness/sharded.py) on the simulation backend:
+ * the four cut-pipeline entry points, driven by hand for 2 shards in one process, reproduce fgs_forward / fgs_backward;
+ * world_size-2 `gloo` processes running ShardedTrainer end with the parameters a single process gets from the summed
+   two-view gradient (the same reference as tests/test_distributed.py)."""
+import os
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+from test_distributed import LRS, _scene, _setup_paths, _single_process_reference
+
+ORDER = ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest')
+
+
+def _run_sharded_by_hand(be, params, views, grad_images, n_shards, dens=None, dev='cpu'):
+    """All of `views` through shard_preprocess -> forward_from_records -> backward_to_records -> shard_backward, with the two
+    exchanges done by slicing. Returns per view (result, acc) and per shard the six gradients summed over the views."""
+    K = params['sh_coefficients_rest'].shape[1]
+    shards = [{k: v[s::n_shards].contiguous() for k, v in params.items()} for s in range(n_shards)]
+    prim, recs, counts = [], [], []
+    for sh in shards:
+        n = sh['means'].shape[0]
+        rec = torch.zeros((len(views), max(n, 1), 56), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((len(views), 2), dtype=torch.int32, device=dev)
+        prim.append(be.shard_preprocess(*(sh[k] for k in ORDER), views, rec, cnt))
+        recs.append(rec)
+        counts.append(cnt)
+    table = torch.stack(counts).cpu()                                   # [shard, view, (V, I)]
+    rendered = []
+    for v, view in enumerate(views):
+        records = torch.cat([recs[s][v, :int(table[s, v, 0])] for s in range(n_shards)]).contiguous()
+        res = be.forward_from_records(records.view(-1), records.shape[0], int(table[:, v, 1].sum()), view, K)
+        acc = be.backward_to_records(grad_images[v], res.image, res.buffers, view, res.state, K)
+        rendered.append((res, acc))
+    grads = []
+    for s, sh in enumerate(shards):
+        sent = [int(table[s, v, 0]) for v in range(len(views))]
+        pieces = []
+        for v in range(len(views)):
+            o = int(table[:s, v, 0].sum())
+            pieces.append(rendered[v][1][o:o + sent[v]])
+        out = tuple(torch.full_like(sh[k], float('nan')) for k in ORDER)     # every element must be written
+        be.shard_backward(torch.cat(pieces).contiguous(), sent, prim[s], None if dens is None else dens[s], sh['means'], sh['scales'],
+                          sh['rotations'], sh['opacities'], sh['sh_coefficients_rest'], views, out)
+        grads.append(out)
+    return rendered, table, grads
+
+
+@pytest.mark.parametrize('n_shards', [1, 2, 3])
+def test_cut_pipeline_equals_whole_pipeline(n_shards):
+    params, settings, _ = _scene()
+    s = settings[0]
+    be = helpers.poisoned(helpers.sim_backend())      # scratch buffers start as NaN / 0xFF garbage
+    whole = be.forward(*(params[k] for k in ORDER), s)
+    torch.manual_seed(3)
+    grad_image = torch.randn(3, s.height, s.width) * 1e-2
+    n = params['means'].shape[0]
+    info_ref = torch.zeros(2, n)
+    ref = be.backward(info_ref, grad_image, whole.image, params['means'], params['scales'], params['rotations'], params['opacities'],
+                      params['sh_coefficients_rest'], whole.buffers, s, whole.state)
+    dens = [torch.zeros(2, len(range(sh, n, n_shards))) for sh in range(n_shards)]
+    rendered, table, grads = _run_sharded_by_hand(be, params, [s], [grad_image], n_shards, dens)
+    res = rendered[0][0]
+    assert int(table[:, 0, 0].sum()) == whole.state[0] and int(table[:, 0, 1].sum()) == whole.state[1]        # V and I: exact
+    assert res.state[1] == whole.state[1]
+    assert torch.allclose(res.image, whole.image, rtol=0, atol=1e-6)
+    for sh in range(n_shards):
+        for g, r, k in zip(grads[sh], ref, ORDER):
+            assert torch.isfinite(g).all(), k
+            assert torch.allclose(g, r[sh::n_shards], rtol=1e-4, atol=1e-7), (k, (g - r[sh::n_shards]).abs().max())
+        assert torch.allclose(dens[sh], info_ref[:, sh::n_shards], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('n_views', [2, 3, 9])
+def test_shard_backward_sums_over_views(n_views):
+    """K12's in-register sum over the views of a launch (and the accumulate path across launches of 8 views, n_views = 9)."""
+    params, settings, _ = _scene()
+    be = helpers.poisoned(helpers.sim_backend())
+    torch.manual_seed(4)
+    views = [settings[i % 2] for i in range(n_views)]
+    gis = [torch.randn(3, v.height, v.width) * 1e-2 for v in views]
+    n = params['means'].shape[0]
+    dens = [torch.zeros(2, n)]
+    _, _, grads = _run_sharded_by_hand(be, params, views, gis, 1, dens)
+    total, info_ref = None, torch.zeros(2, n)
+    for v, gi in zip(views, gis):
+        whole = be.forward(*(params[k] for k in ORDER), v)
+        ref = be.backward(info_ref, gi, whole.image, params['means'], params['scales'], params['rotations'], params['opacities'],
+                          params['sh_coefficients_rest'], whole.buffers, v, whole.state)
+        total = [r.clone() for r in ref] if total is None else [t + r for t, r in zip(total, ref)]
+    for g, t, k in zip(grads[0], total, ORDER):
+        assert torch.allclose(g, t, rtol=1e-4, atol=1e-7), (k, (g - t).abs().max())
+    assert torch.allclose(dens[0], info_ref, rtol=1e-5, atol=1e-8)
+
+
+def test_empty_shard_and_no_visible():
+    params, settings, _ = _scene()
+    be = helpers.sim_backend()
+    s = settings[0]
+    empty = {k: v[:0].contiguous() for k, v in params.items()}
+    cnt = torch.full((2, 2), 7, dtype=torch.int32)
+    be.shard_preprocess(*(empty[k] for k in ORDER), [s, s], torch.zeros((2, 1, 56), dtype=torch.uint8), cnt)
+    assert cnt.tolist() == [[0, 0], [0, 0]]
+    res = be.forward_from_records(torch.zeros(0, dtype=torch.uint8), 0, 0, s, 15)
+    assert torch.allclose(res.image, s.bg_color.view(3, 1, 1).expand_as(res.image))
+    acc = be.backward_to_records(torch.ones_like(res.image), res.image, res.buffers, s, res.state, 15)
+    assert acc.shape == (0, 9)
+    # a shard none of whose Gaussians is visible still writes all its gradients (zeros)
+    far = {k: v[:20].clone() for k, v in params.items()}
+    far['means'][:, 2] = -50.0
+    cnt = torch.zeros((1, 2), dtype=torch.int32)
+    prim = be.shard_preprocess(*(far[k] for k in ORDER), [s], torch.zeros((1, 20, 56), dtype=torch.uint8), cnt)
+    assert cnt.tolist() == [[0, 0]]
+    out = tuple(torch.full_like(far[k], float('nan')) for k in ORDER)
+    be.shard_backward(torch.zeros((0, 9)), [0], prim, None, far['means'], far['scales'], far['rotations'], far['opacities'],
+                      far['sh_coefficients_rest'], [s], out)
+    assert all(bool((g == 0).all()) for g in out)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _setup_paths()
+        import helpers as h
+        from harness.sharded import ShardedTrainer, shard_of
+        params, settings, targets = _scene()
+        tr = ShardedTrainer(h.sim_backend(), shard_of(params, rank, world), LRS)
+        for _ in range(3):
+            tr.step(settings, targets[rank])
+        full = tr.gather_parameters()
+        torch.save({'shard': {k: v.clone() for k, v in tr.params.items()}, 'full': full, 'info': tr.densification_info.clone(),
+                    'counts': tr.last_counts}, Path(out_dir) / f'sharded_{rank}.pt')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_world2_gloo(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f'sharded_{i}.pt') for i in range(2)]
+    ref_params, ref_info = _single_process_reference()
+    start = _scene()[0]
+    for k in ref_params:
+        assert torch.equal(r[0]['full'][k], r[1]['full'][k]), k
+        assert torch.allclose(r[0]['full'][k], ref_params[k], rtol=0, atol=1e-6), (k, (r[0]['full'][k] - ref_params[k]).abs().max())
+        for i in range(2):
+            assert torch.equal(r[i]['shard'][k], r[0]['full'][k][i::2]), k
+        assert (r[0]['full'][k] - start[k]).abs().max() > 0
+    for i in range(2):      # owners accumulate the densification statistics of BOTH views: no collective needed
+        assert torch.allclose(r[i]['info'], ref_info[:, i::2], rtol=1e-5, atol=1e-7)
+    assert torch.equal(r[0]['counts'], r[1]['counts']) and int(r[0]['counts'][..., 0].sum()) > 0
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_local_shard_group_matches_summed_gradient_reference(world):
+    """G owners in one process (the twin that GPU tests and tools/sharded_emulation.py use): same update as the reference."""
+    from harness.sharded import LocalShardGroup
+    params, settings, targets = _scene()
+    views = [settings[i % 2] for i in range(world)]
+    tg = [targets[i % 2] for i in range(world)]
+    grp = LocalShardGroup(helpers.sim_backend(), params, LRS, world)
+    for _ in range(2):
+        grp.step(views, tg)
+    got = grp.gather_parameters()
+    # reference: replicated parameters, gradients of the `world` views summed (each scaled 1/world), one Adam step
+    from harness.distributed import SEGMENTS, ViewParallelTrainer
+    tr = ViewParallelTrainer(helpers.sim_backend(), params, LRS)
+    for _ in range(2):
+        tr.step_count += 1
+        total = torch.zeros_like(tr.grad_arena)
+        for s, t in zip(views, tg):
+            tr._render_backward(s, lambda img: tr.image_gradient(img, t) * (1.0 / world), False)
+            total += tr.grad_arena
+        tr.grad_arena.copy_(total)
+        tr._adam(0, tr.param_arena.numel(), 0)
+    for k in SEGMENTS:
+        assert torch.allclose(got[k], tr.params[k], rtol=0, atol=1e-6), (k, (got[k] - tr.params[k]).abs().max())
