@@ -165,23 +165,6 @@ struct BackwardScratch {
     }
 };
 
-int g_atomic_policy = 1;               // K11: 1 = lanes whose nine sums are all zero issue no atomics (fgs_debug_set_option key 4)
-int g_acc_records = 0;                 // 0: accumulators planar [9][N]; 1: one 36-byte record per primitive (fgs_debug_set_option key 3)
-uint32_t acc_es(uint32_t n) { return g_acc_records ? 1u : n; }
-uint32_t acc_ps() { return g_acc_records ? 9u : 1u; }
-
-// Record j of the renderer's pipeline lives at primitive index (j * spread_multiplier(n)) mod n: K1 appends the shard's
-// huge-footprint Gaussians -- the heavy hitters of K11's atomics, thousands of tiles each -- as ONE run at the end of its
-// compact list, and 32 neighbours in index share a 128-byte line of every accumulator plane (measured: K11 0.71 -> 0.97 ms
-// on the views with ~200 such Gaussians). The multiplier puts neighbours 132 bytes apart.
-uint32_t spread_multiplier(uint32_t n) {
-    if (n < 64) return 1;
-    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
-    uint32_t m = 33;
-    while (gcd(m, n) != 1) m += 2;
-    return m;
-}
-
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
 }
@@ -197,15 +180,14 @@ CameraArgs camera_of(const fgs_settings& s, const Geometry& g) {
     return c;
 }
 
-BackwardView backward_view(const fgs_settings& s, const Geometry& g, const uint32_t* n_touched, const uint32_t* slot, const float* acc,
-                           uint32_t es, uint32_t ps, float* view_dir) {
+BackwardView backward_view(const fgs_settings& s, const Geometry& g, const uint32_t* n_touched, const uint32_t* slot, const float* acc, float* view_dir) {
     BackwardView v;
-    v.cam = camera_of(s, g); v.n_touched = n_touched; v.slot = slot; v.acc = acc; v.acc_es = es; v.acc_ps = ps; v.view_dir = view_dir;
+    v.cam = camera_of(s, g); v.n_touched = n_touched; v.slot = slot; v.acc = acc; v.view_dir = view_dir;
     return v;
 }
 ShRestView sh_rest_view(const BackwardView& b) {
     ShRestView v;
-    v.view_dir = b.view_dir; v.n_touched = b.n_touched; v.slot = b.slot; v.acc = b.acc; v.acc_es = b.acc_es; v.acc_ps = b.acc_ps;
+    v.view_dir = b.view_dir; v.n_touched = b.n_touched; v.slot = b.slot; v.acc = b.acc;
     return v;
 }
 
@@ -370,10 +352,9 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
     a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
-    a.acc_es = acc_es(static_cast<uint32_t>(n_primitives)); a.acc_ps = acc_ps();
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
-    a.proper_aa = settings->proper_antialiasing ? 1 : 0; a.atomic_policy = g_atomic_policy;
+    a.proper_aa = settings->proper_antialiasing ? 1 : 0;
     { StageScope t(ST_STAGE_PIXELS, stream); FGS_HIP(launch_stage_pixels(a, stream)); }
     { StageScope t(ST_BLEND_BACKWARD, stream); FGS_HIP(launch_blend_backward(a, stream)); }     // K11 (bwd:56)
     return FGS_OK;
@@ -438,7 +419,7 @@ int32_t fgs_backward(const float* grad_image, const float* image,
     PreprocessBackwardArgs a{};
     a.means = means; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.sh_rest = sh_coefficients_rest;
     a.n_views = 1;
-    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, acc_es(static_cast<uint32_t>(n_primitives)), acc_ps(), P.sc.view_dir);
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, P.sc.view_dir);
     a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
     a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
     a.n = static_cast<uint32_t>(n_primitives);
@@ -476,7 +457,7 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
     a.means = params[0]; a.scales = params[4]; a.rotations = params[5]; a.opacities = params[3]; a.sh_rest = params[2];
     a.densification_info = densification_info;
     a.n_views = 1;
-    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, acc_es(static_cast<uint32_t>(n_primitives)), acc_ps(), P.sc.view_dir);
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, P.sc.view_dir);
     a.n = static_cast<uint32_t>(n_primitives);
     const int map[5] = {0, 1, 3, 4, 5};     // kernel group order: means, sh0, opacities, scales, rotations
     for (int k = 0; k < 5; ++k) {
@@ -566,7 +547,7 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
     FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
-      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, spread_multiplier(n), pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, stream)); }
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, stream)); }
     return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
@@ -581,8 +562,7 @@ int32_t fgs_backward_to_records(const float* grad_image, const float* image,
     if (!acc_records_out) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL acc_records_out");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream)) return rc;
-    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, acc_es(static_cast<uint32_t>(n_records)), acc_ps(), static_cast<uint32_t>(n_records),
-                                                            spread_multiplier(static_cast<uint32_t>(n_records)), acc_records_out, stream)); }
+    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), acc_records_out, stream)); }
     return FGS_OK;
 }
 
@@ -633,8 +613,8 @@ int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, c
             Carver c(const_cast<char*>(static_cast<const char*>(primitive_buffers)) + per_view * v);
             const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
             // accumulator records are read in place through the slot table K1 left behind: no scatter pass, no dense copy
-            a.view[k] = backward_view(settings[v], geo, b.n_touched, b.keys[1], acc_records + first_record * kAccRecordWords, 1u,
-                                      static_cast<uint32_t>(kAccRecordWords), reinterpret_cast<float*>(dir_base + dir_stride * v));
+            a.view[k] = backward_view(settings[v], geo, b.n_touched, b.keys[1], acc_records + first_record * kAccRecordWords,
+                                      reinterpret_cast<float*>(dir_base + dir_stride * v));
             sh.view[k] = sh_rest_view(a.view[k]);
             first_record += static_cast<size_t>(n_visible[v]);
         }
@@ -779,8 +759,6 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
-        case 3: g_acc_records = value ? 1 : 0; return FGS_OK;
-        case 4: g_atomic_policy = value ? 1 : 0; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     float d_mx = 0.0f, d_my = 0.0f, d_ca = 0.0f, d_cb = 0.0f, d_cc = 0.0f, d_op = 0.0f, d_c0 = 0.0f, d_c1 = 0.0f, d_c2 = 0.0f;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sT = 0.0f;                      // the pixel state travelling through the lanes
     const bool lane0 = lane == 0;
+    uint64_t ever = 0;                   // lanes whose Gaussian passed the alpha test at least once (scalar registers)
 
     // software-pipelined LDS reads: the values of step i+1 are requested while step i computes. Lanes beyond the bucket's
     // Gaussians carry opacity 0 and fall out at the alpha test, so `tp < last` is the only per-step validity test.
@@ -129,7 +130,9 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
         const float gauss_raw = __expf(fminf(power, 0.0f));
         const float alpha_raw = op * gauss_raw;
         const bool contrib = tp < last && alpha_raw >= kMinAlphaThreshold;                     // kb:412,419-421
-        if (wave_ballot(contrib) == 0) continue;                                               // wave-uniform: nothing to do this step
+        const uint64_t contrib_mask = wave_ballot(contrib);
+        if (contrib_mask == 0) continue;                                                       // wave-uniform: nothing to do this step
+        ever |= contrib_mask;
         const float alpha = contrib ? alpha_raw : 0.0f, gauss = contrib ? gauss_raw : 0.0f;
         const float4 g = GLOBAL_GRAD ? g_cur : s_grad[wv][min(max(idx, 0), kTilePixels - 1)];
         const float T = sT;
@@ -148,22 +151,20 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
         sT = T * oma;
     }
 
-    bool emit = valid_prim;
-    // All nine sums exactly zero <=> the Gaussian never passed the alpha test in this tile: adding them is a no-op, and K11 is
-    // bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles), so silent lanes stay silent.
-    if (a.atomic_policy >= 1)
-        emit = emit && ((d_mx != 0.0f) | (d_my != 0.0f) | (d_ca != 0.0f) | (d_cb != 0.0f) | (d_cc != 0.0f) | (d_op != 0.0f) | (d_c0 != 0.0f) | (d_c1 != 0.0f) | (d_c2 != 0.0f));
-    if (emit) {                                                            // kb:459-470
-        float* const accp = a.acc + (size_t)prim * a.acc_ps; const size_t es = a.acc_es;
-        unsafeAtomicAdd(accp + 0 * es, d_mx);
-        unsafeAtomicAdd(accp + 1 * es, d_my);
-        unsafeAtomicAdd(accp + 2 * es, d_ca);
-        unsafeAtomicAdd(accp + 3 * es, d_cb);
-        unsafeAtomicAdd(accp + 4 * es, d_cc);
-        unsafeAtomicAdd(accp + 5 * es, a.proper_aa ? d_op : op * (1.0f - op) * d_op);
-        unsafeAtomicAdd(accp + 6 * es, d_c0);
-        unsafeAtomicAdd(accp + 7 * es, d_c1);
-        unsafeAtomicAdd(accp + 8 * es, d_c2);
+    // A Gaussian that never passed the alpha test in this tile has nine zero sums: adding them is a no-op, and the kernel's
+    // tail is bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles).
+    const bool silent = ((ever >> lane) & 1ull) == 0;
+    if (valid_prim && !silent) {                                           // kb:459-470
+        const size_t n = a.n;
+        unsafeAtomicAdd(a.acc + prim, d_mx);
+        unsafeAtomicAdd(a.acc + n + prim, d_my);
+        unsafeAtomicAdd(a.acc + 2 * n + prim, d_ca);
+        unsafeAtomicAdd(a.acc + 3 * n + prim, d_cb);
+        unsafeAtomicAdd(a.acc + 4 * n + prim, d_cc);
+        unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? d_op : op * (1.0f - op) * d_op);
+        unsafeAtomicAdd(a.acc + 6 * n + prim, d_c0);
+        unsafeAtomicAdd(a.acc + 7 * n + prim, d_c1);
+        unsafeAtomicAdd(a.acc + 8 * n + prim, d_c2);
     }
 }
 
@@ -278,16 +279,16 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
         for (int k = 0; k < 9; ++k) t[k] = s_acc[0][tid][k] + s_acc[1][tid][k] + s_acc[2][tid][k];
         const uint32_t prim = s_prim[tid];
         const float op = s_b[tid].y;
-        float* const accp = a.acc + (size_t)prim * a.acc_ps; const size_t es = a.acc_es;
-        unsafeAtomicAdd(accp + 0 * es, t[0]);
-        unsafeAtomicAdd(accp + 1 * es, t[1]);
-        unsafeAtomicAdd(accp + 2 * es, t[2]);
-        unsafeAtomicAdd(accp + 3 * es, t[3]);
-        unsafeAtomicAdd(accp + 4 * es, t[4]);
-        unsafeAtomicAdd(accp + 5 * es, a.proper_aa ? t[5] : op * (1.0f - op) * t[5]);
-        unsafeAtomicAdd(accp + 6 * es, t[6]);
-        unsafeAtomicAdd(accp + 7 * es, t[7]);
-        unsafeAtomicAdd(accp + 8 * es, t[8]);
+        const size_t n = a.n;
+        unsafeAtomicAdd(a.acc + prim, t[0]);
+        unsafeAtomicAdd(a.acc + n + prim, t[1]);
+        unsafeAtomicAdd(a.acc + 2 * n + prim, t[2]);
+        unsafeAtomicAdd(a.acc + 3 * n + prim, t[3]);
+        unsafeAtomicAdd(a.acc + 4 * n + prim, t[4]);
+        unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? t[5] : op * (1.0f - op) * t[5]);
+        unsafeAtomicAdd(a.acc + 6 * n + prim, t[6]);
+        unsafeAtomicAdd(a.acc + 7 * n + prim, t[7]);
+        unsafeAtomicAdd(a.acc + 8 * n + prim, t[8]);
     }
 }
 

@@ -66,11 +66,9 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const float* final_T; const uint32_t* n_processed; const uint32_t* max_n_processed;
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
-    float* acc;                           // 9 sums per primitive: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
-    uint32_t acc_es, acc_ps;              // element k of primitive i lives at acc[k * acc_es + i * acc_ps]: planar (N, 1) or records (1, 9)
+    float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
-    int atomic_policy;                    // 0: one atomic per lane and sum; 1: lanes whose sums are all zero stay silent
 };
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s);      // per-pixel staging pass
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);    // K11 proper
@@ -80,8 +78,8 @@ struct AdamHyper { float step_size, beta1, beta2, eps, bc2_sqrt_rcp; };
 struct BackwardView {                   // what K12 needs per camera view (one on the single-GPU path, up to kMaxBatchViews on the sharded path)
     CameraArgs cam;
     const uint32_t* n_touched;            // [N] tile count of the view, 0 = invisible
-    const uint32_t* slot;                 // sharded path: accumulator record of visible primitive i is slot[i]; nullptr: i itself
-    const float* acc; uint32_t acc_es, acc_ps;   // element k of accumulator record r lives at acc[k * acc_es + r * acc_ps]
+    const float* acc;                     // single view: planar [9][N] (K11's accumulators). Sharded path (several views per launch):
+    const uint32_t* slot;                 //   the returned 9-float accumulator RECORDS, that of visible primitive i being record slot[i]
     float* view_dir;                      // [N][3] scratch: unit view direction of visible primitives, consumed by the SH-rest pass
 };
 struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for the 14 non-SH-rest floats
@@ -96,9 +94,9 @@ struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for th
 };
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s);
 
-struct ShRestView { const float* view_dir; const uint32_t* n_touched; const uint32_t* slot; const float* acc; uint32_t acc_es, acc_ps; };
+struct ShRestView { const float* view_dir; const uint32_t* n_touched; const float* acc; const uint32_t* slot; };   // acc / slot as in BackwardView
 struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload, streamed flat and fully coalesced
-    int n_views; ShRestView view[kMaxBatchViews];
+    int n_views; ShRestView view[kMaxBatchViews];    // n_views > 1 or a slot table = the sharded path (records), else planar accumulators
     float* grad_sh_rest;                  // unfused: [N][K-1][3] written for every primitive
     float* p; float* m; float* v; AdamHyper h;   // fused (one view)
     uint32_t n; uint32_t total_sh_rest; uint32_t active_sh_bases;
@@ -127,9 +125,9 @@ struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const ui
                          const uint32_t* counters; uint32_t* out; uint32_t* counts_out; };
 struct PackRecordsBatch { int n_views; uint32_t capacity; PackRecordsView v[kMaxBatchViews]; };
 hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
-hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, uint32_t spread, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
+hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
                                        uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s);
-hipError_t launch_pack_acc(const float* acc, uint32_t acc_es, uint32_t acc_ps, uint32_t n, uint32_t spread, float* out, hipStream_t s);
+hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s);
 
 // aux_ops.hip: the reference's remaining exported operators
 hipError_t launch_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int n,

@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
     bool visible = false;
     float m[3] = {0.0f, 0.0f, 0.0f}, s[3] = {0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int n_views = MULTI ? a.n_views : 1;
+    const Camera cam0 = load_camera(a.view[0].cam);     // single view: requested before the visibility test, as are the moments above
     for (int vw = 0; vw < n_views; ++vw) {
         const BackwardView& V = a.view[MULTI ? vw : 0];
         if (V.n_touched[i] == 0) continue;                                             // kb:45
@@ -73,8 +74,10 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
             for (int k = 0; k < 4; ++k) q[k] = FUSED ? st_p[10 + k] : a.rotations[4 * (size_t)i + k];
         }
         visible = true;
-        const Camera cam = load_camera(V.cam);
-        const float* const accp = V.acc + (size_t)(V.slot != nullptr ? V.slot[i] : i) * V.acc_ps; const size_t es = V.acc_es;
+        const Camera cam = (MULTI && vw > 0) ? load_camera(V.cam) : cam0;
+        // single view: K11's planar accumulators [9][N]; sharded path: the returned record of this primitive, 9 contiguous floats
+        const float* const accp = MULTI ? V.acc + (size_t)V.slot[i] * kAccRecordWords : V.acc + i;
+        const size_t es = MULTI ? 1 : n;
         const float gcol[3] = {accp[6 * es], accp[7 * es], accp[8 * es]};
 
         // ---- SH backward w.r.t. sh0 and the view direction (sh_utils.cuh:84-153) ----
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
             const size_t e = (size_t)i * kGroupWidth[grp] + k;
             const int o = kGroupOffset[grp] + k;
             if (!FUSED) {
-                if (!a.accumulate) outs[grp][e] = grad[o];
+                if (!MULTI || !a.accumulate) outs[grp][e] = grad[o];       // view batches after the first add (sharded path only)
                 else if (visible) outs[grp][e] += grad[o];
             } else {
                 adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
@@ -226,7 +229,7 @@ hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardA
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBackwardBlock - 1) / kPreprocessBackwardBlock), block(kPreprocessBackwardBlock);
     if (fused_adam) hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, 0, s, a);
-    else if (a.n_views == 1) hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, 0, s, a);
+    else if (a.view[0].slot == nullptr) hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -236,22 +239,22 @@ hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardA
 // the lane rebuilds basis_k(view_dir) * dL/dcolour (sh_utils.cuh:90-111) from 28 bytes that 15 neighbouring lanes share.
 struct PairGrad { float b; float c[3]; };
 
-template <int RT>
+template <int RT, bool RECORDS>
 __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShRestView& V, const uint32_t pair_in, const uint32_t n_pairs) {
     // All seven loads are issued unconditionally (one memory round trip instead of a dependent chain); the result is
     // SELECTED to zero for invisible Gaussians / inactive degrees because their view_dir slot is uninitialised scratch.
     const uint32_t pair = pair_in < n_pairs ? pair_in : n_pairs - 1u;
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t gi = pair / R, k = pair - gi * R;
+    const size_t n = a.n;
     const uint32_t touched = V.n_touched[gi];
     const float x = V.view_dir[3 * (size_t)gi], y = V.view_dir[3 * (size_t)gi + 1], z = V.view_dir[3 * (size_t)gi + 2];
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    if (V.slot == nullptr) {             // dense accumulators: always in bounds, requested together with everything else
-        const float* const accp = V.acc + (size_t)gi * V.acc_ps;
-        c0 = accp[6 * (size_t)V.acc_es]; c1 = accp[7 * (size_t)V.acc_es]; c2 = accp[8 * (size_t)V.acc_es];
+    if (!RECORDS) {                      // K11's planar accumulators: always in bounds, requested together with everything else
+        c0 = V.acc[6 * n + gi]; c1 = V.acc[7 * n + gi]; c2 = V.acc[8 * n + gi];
     } else if (touched != 0) {           // sharded path: a record exists only for visible primitives (slot[] of the others is scratch)
-        const float* const accp = V.acc + (size_t)V.slot[gi] * V.acc_ps;
-        c0 = accp[6 * (size_t)V.acc_es]; c1 = accp[7 * (size_t)V.acc_es]; c2 = accp[8 * (size_t)V.acc_es];
+        const float* const accp = V.acc + (size_t)V.slot[gi] * kAccRecordWords;
+        c0 = accp[6]; c1 = accp[7]; c2 = accp[8];
     }
     // coefficient k belongs to degree 1 (k<3), 2 (k<8), 3 (k<15); it receives a gradient only if that degree is active
     const bool degree_on = (k < 3 && a.active_sh_bases > 1) || (k >= 3 && k < 8 && a.active_sh_bases > 4) ||
@@ -270,17 +273,6 @@ __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShR
     return r;
 }
 
-// gradient of one (Gaussian, basis) pair summed over the views of the launch: out[c] = sum_v basis_k(dir_v) * dL/dcolour_v[c]
-template <int RT>
-__device__ __forceinline__ void pair_gradient_sum(const ShRestArgs& a, const uint32_t pair, const uint32_t n_pairs, float (&out)[3]) {
-    const PairGrad q = pair_gradient<RT>(a, a.view[0], pair, n_pairs);
-    out[0] = q.b * q.c[0]; out[1] = q.b * q.c[1]; out[2] = q.b * q.c[2];
-    for (int vw = 1; vw < a.n_views; ++vw) {
-        const PairGrad w = pair_gradient<RT>(a, a.view[vw], pair, n_pairs);
-        out[0] += w.b * w.c[0]; out[1] += w.b * w.c[1]; out[2] += w.b * w.c[2];
-    }
-}
-
 // Unfused form: one lane per (Gaussian, basis) pair writes its 12 bytes (one basis evaluation per 12 B; the float4 form
 // below needs two per 16 B and measured slower for a pure 540 MB write), two pairs per lane for memory-level parallelism.
 template <int RT>
@@ -288,16 +280,27 @@ __global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs 
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t n_pairs = a.n * R;
     const uint32_t p0 = blockIdx.x * 512u + threadIdx.x, p1 = p0 + 256u;
-    float g0[3], g1[3];
-    pair_gradient_sum<RT>(a, p0, n_pairs, g0);
-    pair_gradient_sum<RT>(a, p1, n_pairs, g1);
-    if (a.accumulate) {                  // view batches after the first: an all-zero gradient adds nothing, skip the read-modify-write
-        if (p0 < n_pairs && ((g0[0] != 0.0f) | (g0[1] != 0.0f) | (g0[2] != 0.0f))) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] += g0[0]; o[1] += g0[1]; o[2] += g0[2]; }
-        if (p1 < n_pairs && ((g1[0] != 0.0f) | (g1[1] != 0.0f) | (g1[2] != 0.0f))) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] += g1[0]; o[1] += g1[1]; o[2] += g1[2]; }
-        return;
+    const PairGrad q0 = pair_gradient<RT, false>(a, a.view[0], p0, n_pairs), q1 = pair_gradient<RT, false>(a, a.view[0], p1, n_pairs);
+    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = q0.b * q0.c[0]; o[1] = q0.b * q0.c[1]; o[2] = q0.b * q0.c[2]; }
+    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = q1.b * q1.c[0]; o[1] = q1.b * q1.c[1]; o[2] = q1.b * q1.c[2]; }
+}
+
+// Sharded path: the gradient of a pair is summed over the views of the launch, out[c] = sum_v basis_k(dir_v) * dL/dcolour_v[c],
+// with the colour gradients read from the returned accumulator records.
+template <int RT>
+__global__ void __launch_bounds__(256) sh_rest_gradient_views_kernel(const ShRestArgs a) {
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t n_pairs = a.n * R;
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    for (int vw = 0; vw < a.n_views; ++vw) {
+        const PairGrad w = pair_gradient<RT, true>(a, a.view[vw], pair, n_pairs);
+        g[0] += w.b * w.c[0]; g[1] += w.b * w.c[1]; g[2] += w.b * w.c[2];
     }
-    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = g0[0]; o[1] = g0[1]; o[2] = g0[2]; }
-    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = g1[0]; o[1] = g1[1]; o[2] = g1[2]; }
+    if (pair >= n_pairs) return;
+    float* o = a.grad_sh_rest + 3 * (size_t)pair;
+    if (!a.accumulate) { o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; }
+    else if ((g[0] != 0.0f) | (g[1] != 0.0f) | (g[2] != 0.0f)) { o[0] += g[0]; o[1] += g[1]; o[2] += g[2]; }   // view batches after the first
 }
 
 template <bool FUSED, int RT>
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(256) sh_rest_backward_kernel(const ShRestArgs 
             m4 = load_float4_nt(a.m + e0);
             v4 = load_float4_nt(a.v + e0);
         }
-        const PairGrad q0 = pair_gradient<RT>(a, a.view[0], p0, n_pairs), q1 = pair_gradient<RT>(a, a.view[0], p0 + 1u, n_pairs);
+        const PairGrad q0 = pair_gradient<RT, false>(a, a.view[0], p0, n_pairs), q1 = pair_gradient<RT, false>(a, a.view[0], p0 + 1u, n_pairs);
         float g[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -357,7 +360,12 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
     const uint64_t n_vec = (n_elems + 3) / 4;
     const unsigned blocks = static_cast<unsigned>(n_vec / 256 + 1 < 8192 ? n_vec / 256 + 1 : 8192);   // grid-stride: 32 workgroups per CU
     const dim3 grid(blocks), block(256);
-    if (!fused_adam) {
+    if (!fused_adam && a.view[0].slot != nullptr) {          // sharded path: records + sum over views
+        const uint64_t n_pairs = n_elems / 3;
+        const dim3 pgrid(static_cast<unsigned>((n_pairs + 255) / 256));
+        if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_gradient_views_kernel<15>, pgrid, block, 0, s, a);
+        else hipLaunchKernelGGL(sh_rest_gradient_views_kernel<0>, pgrid, block, 0, s, a);
+    } else if (!fused_adam) {
         const uint64_t n_pairs = n_elems / 3;
         const dim3 pgrid(static_cast<unsigned>((n_pairs + 511) / 512));
         if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_gradient_kernel<15>, pgrid, block, 0, s, a);

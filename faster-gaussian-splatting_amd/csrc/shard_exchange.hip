@@ -32,10 +32,9 @@ __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecor
     o[6] = make_uint2(w.depth_keys[j], w.n_touched[i]);
 }
 
-// Renderer side: the concatenated records of all shards become the primitives of a pipeline that starts at K2 (record j
-// is primitive j * spread mod n).
+// Renderer side: the concatenated records of all shards become primitives 0..n-1 of a pipeline that starts at K2.
 // Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
-__global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, uint32_t spread, PrimRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, PrimRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
                                                                    uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -43,23 +42,20 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
     if (j >= n) return;
     const uint2* m = reinterpret_cast<const uint2*>(records + (size_t)kSplatRecordWords * j);
     const uint2 w0 = m[0], w1 = m[1], w2 = m[2], w3 = m[3], w4 = m[4], w5 = m[5], w6 = m[6];
-    const uint32_t d = static_cast<uint32_t>((uint64_t)j * spread % n);          // see spread_multiplier() in api.hip
-    uint4* r = reinterpret_cast<uint4*>(rec + d);
+    uint4* r = reinterpret_cast<uint4*>(rec + j);
     r[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
     r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
     r[2] = make_uint4(w4.x, w4.y, w5.x, w5.y);
-    depth_keys[j] = w6.x; prim_idx[j] = d; n_touched[d] = w6.y;
+    depth_keys[j] = w6.x; prim_idx[j] = j; n_touched[j] = w6.y;
 }
 
 // planar accumulators [9][n] (what K11 adds into) -> one 36-byte record per record j, ready to be cut into per-shard segments
-__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t es, uint32_t ps, uint32_t n, uint32_t spread,
-                                                       float* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, float* __restrict__ out) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n) return;
-    const uint32_t d = static_cast<uint32_t>((uint64_t)j * spread % n);
     float v[kAccRecordWords];
 #pragma unroll
-    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * es + (size_t)d * ps];
+    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n + j];
 #pragma unroll
     for (int k = 0; k < kAccRecordWords; ++k) out[(size_t)kAccRecordWords * j + k] = v[k];
 }
@@ -71,16 +67,16 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, uint32_t spread, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
+hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
                                        uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s) {
     const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, spread, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_acc(const float* acc, uint32_t es, uint32_t ps, uint32_t n, uint32_t spread, float* out, hipStream_t s) {
+hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, es, ps, n, spread, out);
+    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, n, out);
     return hipGetLastError();
 }
 
