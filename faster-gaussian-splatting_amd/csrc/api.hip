@@ -513,9 +513,10 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
             PreprocessArgs& pa = pb.v[k];
             pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
             pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets;
-            pa.slot = b.keys[1];                   // the second depth-key buffer is free on this path (no sort on the owner)
+            pa.count_appended = 1;
             pa.n = n; pa.cam = camera_of(settings[v], geo); pa.ranges = nullptr; pa.n_tiles = 0;   // the tile ranges belong to the renderer of the view
-            rb.v[k] = PackRecordsView{b.rec, b.n_touched, b.keys[0], b.prims[0], b.counters,
+            // slot table for fgs_shard_backward: the second depth-key buffer is free on this path (no sort on the owner)
+            rb.v[k] = PackRecordsView{b.rec, b.n_touched, b.keys[0], b.prims[0], b.counters, b.keys[1],
                                       static_cast<uint32_t*>(records_out) + (size_t)v * n * kSplatRecordWords, counts_out + 2 * v};
         }
         if (n == 0) { FGS_HIP(hipMemsetAsync(counts_out + 2 * v0, 0, 2 * sizeof(uint32_t) * pb.n_views, stream)); continue; }

@@ -19,7 +19,7 @@ struct PreprocessArgs {                 // K1
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
     uint32_t n;
-    uint32_t* slot;                                // sharded path: slot[i] = position of visible primitive i in the compacted list (else nullptr)
+    int count_appended;                            // sharded path: counters[2] counts the huge-footprint entries appended to the list
     CameraArgs cam;
 };
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s);
@@ -122,7 +122,7 @@ hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s);
 
 // shard_exchange.hip: record (un)packing either side of the two exchanges of the Gaussian-sharded multi-GPU path
 struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const uint32_t* depth_keys; const uint32_t* prim_idx;
-                         const uint32_t* counters; uint32_t* out; uint32_t* counts_out; };
+                         const uint32_t* counters; uint32_t* slot; uint32_t* out; uint32_t* counts_out; };
 struct PackRecordsBatch { int n_views; uint32_t capacity; PackRecordsView v[kMaxBatchViews]; };
 hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,

@@ -161,7 +161,6 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         for (unsigned w = 0; w < wave; ++w) off += s_vis[w];
         a.depth_keys[off] = __float_as_uint(depth);
         a.prim_idx[off] = idx;
-        if (a.slot != nullptr) a.slot[idx] = off;
     }
 }
 
@@ -200,7 +199,7 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
                 const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
                 a.depth_keys[off] = __float_as_uint(depth);
                 a.prim_idx[off] = idx;
-                if (a.slot != nullptr) a.slot[idx] = off;
+                if (a.count_appended) atomicAdd(&a.counters[2], 1u);     // sharded path: how many entries this kernel appended
             }
         }
         __syncthreads();

@@ -15,17 +15,29 @@ namespace fgs {
 
 static_assert(kSplatRecordWords == 14 && sizeof(PrimRec) == 48, "a splat record is the 48-byte PrimRec + depth key + tile count");
 
-// One lane per visible Gaussian j of a (shard, view), in the order K1 compacted them; grid.y = view; `counts_out` = (V, I).
+// One lane per visible Gaussian j of a (shard, view); grid.y = view; `counts_out` = (V, I). Record order = the order K1
+// compacted the visible list in, with one exception: K1 appends the huge-footprint Gaussians (thousands of tiles each -- the
+// heavy hitters of K11's atomics) as ONE run at the end, and 32 neighbours in record order share a 128-byte line of every
+// accumulator plane on the renderer (measured: K11 0.71 -> 0.97 ms on views with ~200 of them). They trade places with
+// evenly spaced regular records instead. slot[i] = record index of visible primitive i, for fgs_shard_backward.
 __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecordsBatch b) {
     const PackRecordsView& w = b.v[blockIdx.y];
     const uint32_t n_visible = w.counters[0];
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j == 0) { w.counts_out[0] = n_visible; w.counts_out[1] = w.counters[1]; }
     if (j >= n_visible) return;
+    const uint32_t n_heavy = w.counters[2], n_regular = n_visible - n_heavy;
+    const uint32_t stride = n_heavy != 0 ? n_regular / n_heavy : 0u;
+    uint32_t dst = j;
+    if (stride >= 64u) {
+        if (j >= n_regular) dst = (j - n_regular) * stride + stride / 2u;                                  // heavy #a -> a spread slot
+        else if (j % stride == stride / 2u && j / stride < n_heavy) dst = n_regular + j / stride;           // its former tenant -> the end
+    }
     const uint32_t i = w.prim_idx[j];
+    w.slot[i] = dst;
     const uint4* r = reinterpret_cast<const uint4*>(w.rec + i);
     const uint4 a = r[0], c = r[1], d = r[2];
-    uint2* o = reinterpret_cast<uint2*>(w.out + (size_t)kSplatRecordWords * j);      // 56-byte records: 8-byte aligned
+    uint2* o = reinterpret_cast<uint2*>(w.out + (size_t)kSplatRecordWords * dst);    // 56-byte records: 8-byte aligned
     o[0] = make_uint2(a.x, a.y); o[1] = make_uint2(a.z, a.w);
     o[2] = make_uint2(c.x, c.y); o[3] = make_uint2(c.z, c.w);
     o[4] = make_uint2(d.x, d.y); o[5] = make_uint2(d.z, d.w);

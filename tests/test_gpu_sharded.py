@@ -56,6 +56,20 @@ def test_cut_pipeline_equals_whole_pipeline_s0(hip_backend, n_shards):
     _cut_vs_whole(helpers.poisoned(hip_backend), params, RS, n_shards, 1e-2)
 
 
+def test_cut_pipeline_with_huge_footprints(hip_backend):
+    """Screen-filling Gaussians take K1's workgroup path and, on the sharded path, are spread through the record order by the
+    pack kernel (they trade places with regular records): V, I, image and gradients must not notice."""
+    from harness.scenes import View
+    p, v = make_s0(seed=13, n=6000)
+    v = View(v.w2c, v.position, 1280, 960, 1000.0, 1000.0, 640.0, 480.0, 0.2, 1e4, torch.zeros(3))
+    p['scales'][:40] = p['scales'][:40] + 3.2            # > 1024 candidate tiles each
+    p['opacities'][:40] -= 3.0                           # faint, so that everything behind them still receives gradients
+    _, RS = helpers.settings_pair(v, device=DEV)
+    for n_shards in (1, 3):
+        table = _cut_vs_whole(helpers.poisoned(hip_backend), p, RS, n_shards, 1e-3, strict=False)
+        assert int(table[:, 0].sum()) > 3000
+
+
 def test_cut_pipeline_full_size(hip_backend):
     """BASELINE.json full size: 1 M garden-like Gaussians at 1920x1080, 8 shards; also: strided ownership balances the
     per-shard record counts (the all-to-all message sizes) to a few percent."""
