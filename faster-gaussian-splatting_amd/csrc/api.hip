@@ -165,6 +165,8 @@ struct BackwardScratch {
     }
 };
 
+int g_seq_tiles = kSeqTiles;           // fgs_debug_set_option key 5
+
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
 }
@@ -256,7 +258,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     PreprocessArgs pa{};
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
-    pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles;
+    pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles; pa.seq_tiles = g_seq_tiles;
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
@@ -513,7 +515,7 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
             PreprocessArgs& pa = pb.v[k];
             pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
             pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets;
-            pa.count_appended = 1;
+            pa.count_appended = 1; pa.seq_tiles = g_seq_tiles;
             pa.n = n; pa.cam = camera_of(settings[v], geo); pa.ranges = nullptr; pa.n_tiles = 0;   // the tile ranges belong to the renderer of the view
             // slot table for fgs_shard_backward: the second depth-key buffer is free on this path (no sort on the owner)
             rb.v[k] = PackRecordsView{b.rec, b.n_touched, b.keys[0], b.prims[0], b.counters, b.keys[1],
@@ -760,6 +762,8 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
+        case 5: if (value < 1 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 1..32");
+                g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }

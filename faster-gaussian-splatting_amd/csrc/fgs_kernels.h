@@ -19,6 +19,7 @@ struct PreprocessArgs {                 // K1
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
     uint32_t n;
+    int seq_tiles;                                 // candidate tiles each lane tests itself before the wave cooperates (1..32)
     int count_appended;                            // sharded path: counters[2] counts the huge-footprint entries appended to the list
     CameraArgs cam;
 };

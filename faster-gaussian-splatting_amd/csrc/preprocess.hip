@@ -79,6 +79,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         if (wave_ballot(active) != 0) {                                                // kf:181
             // ---- exact tile count (kernel_utils.cuh:117-180), wave64 version ----
             const float sx = m2x - 0.5f, sy = m2y - 0.5f;
+            const unsigned seq_tiles = static_cast<unsigned>(a.seq_tiles);
             uint32_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 32
             // Footprints above kHugeFootprint candidate tiles are counted by preprocess_huge_kernel (a workgroup each):
             // Morton order keeps the Gaussians nearest to the camera in the same wave, and counting their tens of
@@ -86,11 +87,11 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
             const bool huge = active && n_max > kHugeFootprint;
             if (huge) active = false;
             if (active) {
-                const unsigned n_seq = n_max < (unsigned)kSeqTiles ? n_max : (unsigned)kSeqTiles;
+                const unsigned n_seq = n_max < seq_tiles ? n_max : seq_tiles;
                 for (unsigned t = 0; t < n_seq; ++t)
                     if (tile_contributes(sx, sy, ca, cb, cc, tx0 + t % tbw, ty0 + t / tbw, power_threshold)) { ++cnt; hit_mask |= 1u << t; }
             }
-            uint64_t pending = wave_ballot(active && n_max > (unsigned)kSeqTiles);
+            uint64_t pending = wave_ballot(active && n_max > seq_tiles);
             while (pending != 0) {                              // wave-uniform loop over lanes with large footprints
                 const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
                 pending &= pending - 1;
@@ -100,12 +101,12 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 const float o_ca = wave_read(ca, src), o_cb = wave_read(cb, src), o_cc = wave_read(cc, src);
                 const float o_pt = wave_read(power_threshold, src);
                 unsigned found = 0;
-                for (unsigned base = kSeqTiles; base < o_cnt; base += kWave) {
+                for (unsigned base = seq_tiles; base < o_cnt; base += kWave) {
                     const unsigned t = base + lane;
                     const bool hit = t < o_cnt && tile_contributes(o_sx, o_sy, o_ca, o_cb, o_cc, o_tx0 + t % o_tbw, o_ty0 + t / o_tbw, o_pt);
                     const uint64_t hits = wave_ballot(hit);
                     found += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
-                    if (base == (unsigned)kSeqTiles && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << kSeqTiles);
+                    if (base == seq_tiles && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << seq_tiles);
                 }
                 if (lane == static_cast<unsigned>(src)) cnt += found;
             }
