@@ -57,6 +57,22 @@ def build_scene(args):
     return params, orbit_views(8), f'{args.scene}: {n} garden-like Gaussians (SH degree 3), 1920x1080, 8 orbit views'
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/r01_s2_pmc_*.txt, separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command on S2; counters are in KiB, and FETCH_SIZE reports half of the wide
+    reads on gfx950 -- calibrated on the Adam kernel). Counters cannot be collected from inside the timed run."""
+    try:
+        vals = {}
+        for key in ('fetch', 'write'):
+            for line in (REPO / 'profiles' / f'r01_s2_pmc_{key}_size.txt').read_text().splitlines():
+                if kernel.split('<')[0] in line and f'{key.upper()}_SIZE' in line:
+                    vals[key] = float(line.split()[-1]) * 1024.0
+                    break
+        return 2.0 * vals['fetch'] + vals['write'], 'profiles/r01_s2_pmc_{fetch,write}_size.txt: 2 x FETCH_SIZE + WRITE_SIZE per launch (bytes)'
+    except Exception as exc:
+        return None, f'PMC summary not readable: {exc}'
+
+
 def cpu_baseline(params, view, stats: dict) -> dict:
     """Times ONE training iteration (forward + backward + Adam on all 59 floats per Gaussian) of the same workload on the
     host cores with the CPU oracle (a port of the reference arithmetic, oracle/fgs_oracle.c; OpenMP over Gaussians / tiles /
@@ -223,6 +239,7 @@ def main():
     dom_s = per_launch[dom] * 1e-3
     achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
     bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
+    traffic, traffic_note = pmc_traffic(kernel_of.get(dom, dom)) if args.scene == 'S2' and not args.n_gaussians else (None, 'no PMC summary for this scene')
     out = {
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -231,7 +248,7 @@ def main():
                                'densification_info updated', 'parallelism': f'view-parallel dp{world} ({args.dp_mode})' if vp is not None else 'single GPU',
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_},
         'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_kernel_ms': dom_s * 1e3,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_note, 'avg_kernel_ms': dom_s * 1e3,
                      'algorithmic_bytes_per_launch': stage_bytes[dom],
                      'note': 'dominant = longest kernel of the timed region (HIP events on the launch stream); traffic: see profiles/ PMC summaries',
                      'iteration_algorithmic_GB': bytes_iter / 1e9,
