@@ -122,3 +122,48 @@ def make_garden_like(n: int, seed: int = 1234, sh_bases: int = 16, morton: bool 
 
 
 SCENE_SIZES = {'S1': 1_000_000, 'S2': 3_000_000, 'S3': 6_000_000}
+
+
+# ---- initialisation from a point cloud (reference Model.py:202-231) -------------------------------------------------------
+SH_C0 = 0.28209479177387814
+
+
+def rgb_to_sh0(rgb):
+    """Inverse of the degree-0 colour model colour = 0.5 + C0 * sh0 (sh_utils.cuh:32-35; the reference's utils.rgb_to_sh0)."""
+    return (rgb - 0.5) / SH_C0
+
+
+def root_mean_squared_knn_distances(points: torch.Tensor, k: int = 3, chunk: int = 4096) -> torch.Tensor:
+    """sqrt of the mean squared distance to the k nearest other points -- the scale heuristic of 3DGS (NeRFICG's
+    `compute_root_mean_squared_knn_distances`, an un-vendored dependency; restated from its use at Model.py:216).
+    Brute force in chunks: O(N^2) distance evaluations on the tensor's device, fine up to a few 100 k points."""
+    n = points.shape[0]
+    out = torch.empty(n, dtype=points.dtype, device=points.device)
+    for s in range(0, n, chunk):
+        d2 = torch.cdist(points[s:s + chunk], points).square_()
+        d2[torch.arange(min(chunk, n - s), device=points.device), torch.arange(s, min(s + chunk, n), device=points.device)] = float('inf')
+        out[s:s + chunk] = d2.topk(min(k, n - 1), dim=1, largest=False).values.mean(dim=1).clamp_min(1e-7).sqrt()
+    return out
+
+
+def initialize_from_point_cloud(positions: torch.Tensor, colors: torch.Tensor | None = None, max_sh_degree: int = 3,
+                                use_mcmc: bool = False) -> dict:
+    """The six parameter tensors the reference builds from an SfM point cloud (Model.py:202-231): isotropic log-scale =
+    RMS distance to the 3 nearest neighbours (x 0.1 for MCMC), identity rotation, opacity logit(0.1) (0.5 for MCMC),
+    sh0 from the point colour (grey without colours), higher SH bands zero."""
+    n = positions.shape[0]
+    dev = positions.device
+    sh0 = torch.full((n, 1, 3), rgb_to_sh0(0.5), dtype=torch.float32, device=dev) if colors is None else rgb_to_sh0(colors.float()[:, None, :])
+    dist = root_mean_squared_knn_distances(positions.float())
+    dist = dist * 0.1 if use_mcmc else dist
+    rotations = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    rotations[:, 0] = 1.0
+    p0 = 0.5 if use_mcmc else 0.1
+    return {
+        'means': positions.float().contiguous(),
+        'scales': dist.log()[:, None].repeat(1, 3).contiguous(),
+        'rotations': rotations,
+        'opacities': torch.full((n, 1), math.log(p0 / (1.0 - p0)), dtype=torch.float32, device=dev),
+        'sh_coefficients_0': sh0.contiguous(),
+        'sh_coefficients_rest': torch.zeros((n, (max_sh_degree + 1) ** 2 - 1, 3), dtype=torch.float32, device=dev),
+    }

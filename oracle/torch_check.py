@@ -39,8 +39,8 @@ def _sh_color(sh0, sh_rest, means, cam, active):
     return res
 
 
-def autograd_reference(params: dict, settings, fwd: dict, grad_image: np.ndarray) -> dict:
-    """Returns {'image': ndarray, grads...} in fp64. `params` holds numpy/torch arrays named as in oracle.forward,
+def autograd_reference(params: dict, settings, fwd: dict, grad_image: np.ndarray, loss_only: bool = False):
+    """Returns {'image': ndarray, grads...} in fp64 (or, with loss_only, just the scalar sum(grad_image * image)). `params` holds numpy/torch arrays named as in oracle.forward,
     `settings` is an oracle.Settings, `fwd` the dict returned by oracle.forward (training mode)."""
     t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
     P = {k: t(v).requires_grad_(True) for k, v in params.items()}
@@ -122,6 +122,8 @@ def autograd_reference(params: dict, settings, fwd: dict, grad_image: np.ndarray
     w = T_before * alpha
     img = w @ color + T_after[:, -1:] * bg[None, :]
     image = img.T.reshape(3, H, W)
+    if loss_only:                      # the scalar <grad_image, image> in fp64: what finite differences perturb (no autograd involved)
+        return float((image.detach() * t(grad_image).reshape(3, H, W)).sum())
     image.backward(t(grad_image).reshape(3, H, W))
     out = {'image': image.detach().numpy()}
     for k, v in P.items():

@@ -106,3 +106,26 @@ def test_ply_round_trip(tmp_path):
         if k == 'rotations':
             ref = ref / ref.norm(dim=1, keepdim=True)
         assert back[k].shape == ref.shape and torch.allclose(back[k], ref, atol=1e-7), k
+
+
+def test_initialize_from_point_cloud():
+    """Model.py:202-231: log RMS-3NN scales, identity quaternions, logit(0.1) opacities, sh0 = (rgb - 0.5) / C0."""
+    from harness.scenes import initialize_from_point_cloud, root_mean_squared_knn_distances
+    gen = torch.Generator().manual_seed(0)
+    pts = torch.rand(500, 3, generator=gen)
+    col = torch.rand(500, 3, generator=gen)
+    p = initialize_from_point_cloud(pts, col)
+    d = torch.cdist(pts, pts)
+    d.fill_diagonal_(float('inf'))
+    ref = d.square().topk(3, dim=1, largest=False).values.mean(dim=1).sqrt()
+    assert torch.allclose(root_mean_squared_knn_distances(pts, chunk=128), ref, rtol=1e-4, atol=1e-7)   # cdist expands |a-b|^2: ~1e-5
+    assert torch.allclose(p['scales'], ref.log()[:, None].expand(-1, 3), atol=1e-4)
+    assert torch.equal(p['rotations'], torch.tensor([1.0, 0, 0, 0]).expand(500, 4))
+    assert torch.allclose(torch.sigmoid(p['opacities']), torch.full((500, 1), 0.1))
+    assert torch.allclose(0.5 + 0.28209479177387814 * p['sh_coefficients_0'][:, 0], col, atol=1e-6)
+    assert p['sh_coefficients_rest'].shape == (500, 15, 3) and not p['sh_coefficients_rest'].any()
+    m = initialize_from_point_cloud(pts, None, use_mcmc=True)
+    assert torch.allclose(m['scales'], (0.1 * ref).log()[:, None].expand(-1, 3), atol=1e-4)
+    assert torch.allclose(torch.sigmoid(m['opacities']), torch.full((500, 1), 0.5)) and torch.allclose(m['sh_coefficients_0'], torch.zeros(500, 1, 3))
+    g = Gaussians(p, 'cpu')          # feeds the trainer unchanged
+    assert g.means.shape == (500, 3)

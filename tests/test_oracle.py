@@ -118,3 +118,36 @@ def test_gradients_match_fp64_autograd(oracle, aa, K):
     assert np.abs(ref['image'] - f['image']).max() < 5e-6
     for k in helpers.GRAD_KEYS:
         assert helpers.rel_inf(g[k], ref[k].reshape(g[k].shape)) < 2e-5, k
+
+
+def test_gradients_match_finite_differences(oracle):
+    """central differences of the fp64 image-formation model on a 16-Gaussian scene against the oracle's
+    hand-written fp32 backward -- independent of autograd. The discrete structure (order, tile lists) is held fixed."""
+    from oracle.torch_check import autograd_reference
+    p, v = make_s0(seed=21, n=16)
+    p['means'][:, :2] *= 0.4
+    v = View(v.w2c, v.position, 48, 36, 40.0, 40.0, 24.0, 18.0, 0.2, 1e4, torch.tensor([0.1, 0.3, 0.6]))
+    S, _ = helpers.settings_pair(v, 16, False)
+    a = helpers.np_params(p)
+    names = ('means', 'scales', 'rotations', 'opacities', 'sh0', 'sh_rest')
+    f = oracle.forward(*a, S)
+    assert f['V'] >= 8
+    gi = np.random.default_rng(5).standard_normal(f['image'].shape).astype(np.float32)
+    g = oracle.backward(f, S, gi)
+    base = {k: np.asarray(x, np.float64).copy() for k, x in zip(names, a)}
+    rng = np.random.default_rng(6)
+    visible = np.flatnonzero(f['n_touched'] > 0)
+    for k, gk in zip(names, helpers.GRAD_KEYS):
+        grad = np.asarray(g[gk], np.float64).reshape(base[k].shape)
+        scale = np.abs(grad).max()
+        for _ in range(6):                                   # six random entries of visible Gaussians per tensor
+            i = int(rng.choice(visible))
+            idx = (i,) + tuple(int(rng.integers(0, d)) for d in base[k].shape[1:])
+            eps = 1e-5 * max(1.0, abs(base[k][idx]))
+            vals = []
+            for sgn in (+1.0, -1.0):
+                q = {n: x.copy() for n, x in base.items()}
+                q[k][idx] += sgn * eps
+                vals.append(autograd_reference(q, S, f, gi, loss_only=True))
+            fd = (vals[0] - vals[1]) / (2.0 * eps)
+            assert abs(fd - grad[idx]) <= 2e-3 * scale + 1e-6, (k, idx, fd, grad[idx])
