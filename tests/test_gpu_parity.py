@@ -169,6 +169,20 @@ def test_huge_footprints_workgroup_path(hip_backend, oracle):
     _forward_check(hip_backend, oracle, p, v)
 
 
+def test_more_than_65536_tiles_uses_32_bit_keys(hip_backend, oracle):
+    """fwd:152-153: above 65 536 tiles the instance keys are 32-bit (275 x 250 = 68 750 tiles here). Forward intermediates and the
+    backward pass against the oracle."""
+    p, v = make_s0(seed=17, n=4000)
+    v = View(v.w2c, v.position, 4400, 3000, 3500.0, 3500.0, 2200.0, 1500.0, 0.2, 1e4, torch.zeros(3))
+    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+    assert int(f['inst_keys'].max()) > 65535
+    gi = np.random.default_rng(4).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g = oracle.backward(f, S, gi)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                 dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    _grads_close(grads, g, tol=2e-4)
+
+
 def test_public_operators_autograd_and_fused_adam(hip_backend, oracle):
     """diff_rasterize -> loss.backward() -> FusedAdam.step(): the call sequence of Trainer.py:170-199."""
     from FasterGSCudaBackend import FusedAdam, diff_rasterize
