@@ -198,6 +198,7 @@ int check_settings(const fgs_settings* s) {
     if (!s->w2c || !s->cam_position || !s->bg_color) return fail(FGS_ERR_INVALID_ARGUMENT, "w2c / cam_position / bg_color must be device pointers");
     if (s->width <= 0 || s->height <= 0) return fail(FGS_ERR_INVALID_ARGUMENT, "image size %dx%d", s->width, s->height);
     if (s->active_sh_bases < 1 || s->active_sh_bases > 16) return fail(FGS_ERR_INVALID_ARGUMENT, "active_sh_bases %d", s->active_sh_bases);
+    if (s->total_sh_bases_rest > 15) return fail(FGS_ERR_INVALID_ARGUMENT, "sh_coefficients_rest has %d bases (SH degree 3 = 15 is the maximum)", s->total_sh_bases_rest);
     if (s->total_sh_bases_rest < 0 || (s->active_sh_bases > 1 && s->total_sh_bases_rest < s->active_sh_bases - 1))
         return fail(FGS_ERR_INVALID_ARGUMENT, "sh_coefficients_rest has %d bases, active_sh_bases %d", s->total_sh_bases_rest, s->active_sh_bases);
     return FGS_OK;

@@ -273,34 +273,60 @@ __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShR
     return r;
 }
 
-// Unfused form: one lane per (Gaussian, basis) pair writes its 12 bytes (one basis evaluation per 12 B; the float4 form
-// below needs two per 16 B and measured slower for a pure 540 MB write), two pairs per lane for memory-level parallelism.
-template <int RT>
+// Unfused form (the gradient tensor is materialised). One lane per GAUSSIAN evaluates the 15 basis values once and forms its
+// 45 gradient floats; the wave's 64 x 45 block is contiguous in the [N, R, 3] tensor, so it is transposed through the wave's
+// private LDS slice and leaves as fully coalesced 16-byte stores. (v1: one lane per (Gaussian, basis) pair evaluated all 15
+// basis functions to keep one -- 33 VALU instructions per output float, half VALU-bound at 0.184 ms for a 540 MB write.)
+// MULTI (sharded path): the gradient is summed over the views of the launch, colour gradients come from the accumulator records.
+template <int RT, bool MULTI>
 __global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs a) {
+    constexpr int kMaxRest = 15;
+    __shared__ __attribute__((aligned(16))) float s_out[256 / kWave][kWave * kMaxRest * 3];
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
-    const uint32_t n_pairs = a.n * R;
-    const uint32_t p0 = blockIdx.x * 512u + threadIdx.x, p1 = p0 + 256u;
-    const PairGrad q0 = pair_gradient<RT, false>(a, a.view[0], p0, n_pairs), q1 = pair_gradient<RT, false>(a, a.view[0], p1, n_pairs);
-    if (p0 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p0; o[0] = q0.b * q0.c[0]; o[1] = q0.b * q0.c[1]; o[2] = q0.b * q0.c[2]; }
-    if (p1 < n_pairs) { float* o = a.grad_sh_rest + 3 * (size_t)p1; o[0] = q1.b * q1.c[0]; o[1] = q1.b * q1.c[1]; o[2] = q1.b * q1.c[2]; }
-}
-
-// Sharded path: the gradient of a pair is summed over the views of the launch, out[c] = sum_v basis_k(dir_v) * dL/dcolour_v[c],
-// with the colour gradients read from the returned accumulator records.
-template <int RT>
-__global__ void __launch_bounds__(256) sh_rest_gradient_views_kernel(const ShRestArgs a) {
-    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
-    const uint32_t n_pairs = a.n * R;
-    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
-    float g[3] = {0.0f, 0.0f, 0.0f};
-    for (int vw = 0; vw < a.n_views; ++vw) {
-        const PairGrad w = pair_gradient<RT, true>(a, a.view[vw], pair, n_pairs);
-        g[0] += w.b * w.c[0]; g[1] += w.b * w.c[1]; g[2] += w.b * w.c[2];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t first = (blockIdx.x * 256u + wv * kWave);         // first Gaussian of this wave
+    if (first >= a.n) return;                                         // wave-uniform
+    const uint32_t gi = first + lane;
+    const bool in_range = gi < a.n;
+    const size_t n = a.n;
+    float g[kMaxRest][3];
+#pragma unroll
+    for (int k = 0; k < kMaxRest; ++k) { g[k][0] = 0.0f; g[k][1] = 0.0f; g[k][2] = 0.0f; }
+    const int n_views = MULTI ? a.n_views : 1;
+    for (int vw = 0; vw < n_views; ++vw) {
+        const ShRestView& V = a.view[MULTI ? vw : 0];
+        if (!in_range || V.n_touched[gi] == 0) continue;
+        const float x = V.view_dir[3 * (size_t)gi], y = V.view_dir[3 * (size_t)gi + 1], z = V.view_dir[3 * (size_t)gi + 2];
+        float c[3];
+        if (!MULTI) { c[0] = V.acc[6 * n + gi]; c[1] = V.acc[7 * n + gi]; c[2] = V.acc[8 * n + gi]; }       // planar accumulators
+        else { const float* r = V.acc + (size_t)V.slot[gi] * kAccRecordWords; c[0] = r[6]; c[1] = r[7]; c[2] = r[8]; }
+        float B[kMaxRest];
+#pragma unroll
+        for (int k = 0; k < kMaxRest; ++k) B[k] = 0.0f;                 // degrees above the active one keep a zero gradient
+        if (a.active_sh_bases > 1) sh_basis(x, y, z, a.active_sh_bases, B);
+#pragma unroll
+        for (int k = 0; k < kMaxRest; ++k) {
+            if (!MULTI) { g[k][0] = B[k] * c[0]; g[k][1] = B[k] * c[1]; g[k][2] = B[k] * c[2]; }
+            else { g[k][0] += B[k] * c[0]; g[k][1] += B[k] * c[1]; g[k][2] += B[k] * c[2]; }
+        }
     }
-    if (pair >= n_pairs) return;
-    float* o = a.grad_sh_rest + 3 * (size_t)pair;
-    if (!a.accumulate) { o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; }
-    else if ((g[0] != 0.0f) | (g[1] != 0.0f) | (g[2] != 0.0f)) { o[0] += g[0]; o[1] += g[1]; o[2] += g[2]; }   // view batches after the first
+    float* mine = &s_out[wv][lane * R * 3u];
+#pragma unroll
+    for (int k = 0; k < kMaxRest; ++k)
+        if (static_cast<uint32_t>(k) < R) { mine[3 * k] = g[k][0]; mine[3 * k + 1] = g[k][1]; mine[3 * k + 2] = g[k][2]; }
+    wave_lds_fence();
+    const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;      // floats this wave owns
+    float* out = a.grad_sh_rest + (size_t)first * R * 3u;                             // 64 * R * 12 bytes per wave: 16-byte aligned
+    const bool add = MULTI && a.accumulate;                                            // view batches after the first
+    for (uint32_t e = 4u * lane; e < count; e += 4u * kWave) {
+        if (e + 4u <= count) {
+            float4 v = *reinterpret_cast<const float4*>(&s_out[wv][e]);
+            if (add) { const float4 o = *reinterpret_cast<const float4*>(out + e); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(out + e) = v;
+        } else {
+            for (uint32_t j = e; j < count; ++j) out[j] = add ? out[j] + s_out[wv][j] : s_out[wv][j];
+        }
+    }
 }
 
 template <bool FUSED, int RT>
@@ -360,16 +386,17 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
     const uint64_t n_vec = (n_elems + 3) / 4;
     const unsigned blocks = static_cast<unsigned>(n_vec / 256 + 1 < 8192 ? n_vec / 256 + 1 : 8192);   // grid-stride: 32 workgroups per CU
     const dim3 grid(blocks), block(256);
-    if (!fused_adam && a.view[0].slot != nullptr) {          // sharded path: records + sum over views
-        const uint64_t n_pairs = n_elems / 3;
-        const dim3 pgrid(static_cast<unsigned>((n_pairs + 255) / 256));
-        if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_gradient_views_kernel<15>, pgrid, block, 0, s, a);
-        else hipLaunchKernelGGL(sh_rest_gradient_views_kernel<0>, pgrid, block, 0, s, a);
-    } else if (!fused_adam) {
-        const uint64_t n_pairs = n_elems / 3;
-        const dim3 pgrid(static_cast<unsigned>((n_pairs + 511) / 512));
-        if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_gradient_kernel<15>, pgrid, block, 0, s, a);
-        else hipLaunchKernelGGL(sh_rest_gradient_kernel<0>, pgrid, block, 0, s, a);
+    if (!fused_adam) {
+        if (a.total_sh_rest > 15) return hipErrorInvalidValue;
+        const dim3 ggrid((a.n + 255u) / 256u);
+        const bool views = a.view[0].slot != nullptr;           // sharded path: records + sum over views
+        if (a.total_sh_rest == 15) {
+            if (views) hipLaunchKernelGGL((sh_rest_gradient_kernel<15, true>), ggrid, block, 0, s, a);
+            else hipLaunchKernelGGL((sh_rest_gradient_kernel<15, false>), ggrid, block, 0, s, a);
+        } else {
+            if (views) hipLaunchKernelGGL((sh_rest_gradient_kernel<0, true>), ggrid, block, 0, s, a);
+            else hipLaunchKernelGGL((sh_rest_gradient_kernel<0, false>), ggrid, block, 0, s, a);
+        }
     } else if (a.total_sh_rest == 15) {
         hipLaunchKernelGGL((sh_rest_backward_kernel<true, 15>), grid, block, 0, s, a);
     } else {
