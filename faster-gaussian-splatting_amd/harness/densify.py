@@ -139,3 +139,91 @@ def run_callbacks(g: Gaussians, iteration: int, schedule: dict = GARDEN_SCHEDULE
     if s['opacity_reset_interval'] <= iteration <= s['densification_end'] and iteration % s['opacity_reset_interval'] == 0:
         reset_opacities(g)
     return out
+
+
+# ---- the MCMC policy and Speedy-Splat pruning (reference Model.py:367-457,465-484); their kernels are the backend's
+# relocation_adjustment / add_noise / update_pruning_scores. `ops` injects the operators (default: the HIP backend's wrappers;
+# the CPU tests pass the simulation backend's).
+def _default_ops():
+    from FasterGSCudaBackend import add_noise, relocation_adjustment
+    return relocation_adjustment, add_noise
+
+
+def reset_state(g: Gaussians, indices: torch.Tensor) -> None:
+    """Optim.adam_utils.reset_state: zero the Adam moments of the given Gaussians in every group."""
+    if g.optimizer is None:
+        return
+    for group in g.optimizer.param_groups:
+        st = g.optimizer.state.get(group['params'][0])
+        if st:
+            st['exp_avg'][indices] = 0.0
+            st['exp_avg_sq'][indices] = 0.0
+
+
+@torch.no_grad()
+def _relocated(g: Gaussians, sampled: torch.Tensor, min_opacity: float, relocation_adjustment):
+    """Model.py:382-391 / 424-433: opacity and scale shared between a sampled Gaussian and its copies (3DGS-MCMC Eq. 9)."""
+    opacities = torch.sigmoid(g.opacities.detach()).flatten()
+    _, inverse, counts_per_unique = sampled.unique(sorted=False, return_inverse=True, return_counts=True)
+    counts = counts_per_unique[inverse] + 1                                   # +1 for the original Gaussian
+    new_op, new_sc = relocation_adjustment(opacities[sampled][:, None].contiguous(), g.scales.detach()[sampled].exp().contiguous(), counts)
+    new_op = new_op.clamp(min_opacity, 1.0 - torch.finfo(torch.float32).eps).logit()
+    return new_op.reshape(-1, 1), new_sc.log()
+
+
+@torch.no_grad()
+def mcmc_densification(g: Gaussians, min_opacity: float, cap_max: int, generator: torch.Generator | None = None, ops=None) -> dict:
+    """Model.py:367-457: dead Gaussians are relocated onto live ones sampled by opacity, then the set grows by 5 % up to cap_max."""
+    relocation_adjustment, _ = ops or _default_ops()
+    stats = {'relocated': 0, 'added': 0}
+    dead = g.opacities.detach().flatten() <= math.log(min_opacity / (1.0 - min_opacity))
+    dead |= g.rotations.detach().square().sum(dim=1) < 1e-8
+    n_dead = int(dead.sum())
+    if n_dead > 0:
+        dead_idx, alive_idx = torch.where(dead)[0], torch.where(~dead)[0]
+        prob = torch.sigmoid(g.opacities.detach()).flatten()[alive_idx]
+        sampled = alive_idx[torch.multinomial(prob.cpu(), n_dead, replacement=True, generator=generator).to(alive_idx.device)]
+        new_op, new_sc = _relocated(g, sampled, min_opacity, relocation_adjustment)
+        g.opacities.data[sampled] = new_op
+        g.scales.data[sampled] = new_sc
+        for k in ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'rotations'):
+            getattr(g, k).data[dead_idx] = getattr(g, k).data[sampled]
+        g.opacities.data[dead_idx] = new_op
+        g.scales.data[dead_idx] = new_sc
+        reset_state(g, sampled)
+        g.densification_info = None
+        stats['relocated'] = n_dead
+    n = g.means.shape[0]
+    n_add = max(0, min(cap_max, int(1.05 * n)) - n)
+    if n_add > 0:
+        prob = torch.sigmoid(g.opacities.detach()).flatten()
+        sampled = torch.multinomial(prob.cpu(), n_add, replacement=True, generator=generator).to(g.means.device)
+        new_op, new_sc = _relocated(g, sampled, min_opacity, relocation_adjustment)
+        g.opacities.data[sampled] = new_op
+        g.scales.data[sampled] = new_sc
+        extend(g, {'means': g.means.detach()[sampled], 'sh_coefficients_0': g.sh_coefficients_0.detach()[sampled],
+                   'sh_coefficients_rest': g.sh_coefficients_rest.detach()[sampled], 'opacities': new_op, 'scales': new_sc,
+                   'rotations': g.rotations.detach()[sampled]})
+        reset_state(g, sampled)
+        g.densification_info = None
+        stats['added'] = n_add
+    stats['total'] = g.means.shape[0]
+    return stats
+
+
+@torch.no_grad()
+def importance_pruning(g: Gaussians, scores: torch.Tensor, pruning_ratio: float) -> int:
+    """Model.py:465-470 (Speedy-Splat): drop the given fraction of Gaussians with the lowest accumulated importance score."""
+    k = int(pruning_ratio * (scores.numel() - 1)) + 1                          # kthvalue is 1-based
+    threshold = torch.kthvalue(scores.cpu(), k).values.to(scores.device)
+    mask = scores <= threshold
+    prune(g, mask)
+    return int(mask.sum())
+
+
+@torch.no_grad()
+def post_optimizer_step(g: Gaussians, inject_noise: bool, lr_means: float, ops=None) -> None:
+    """Model.py:472-477 (3D filter off): the SGLD noise of 3DGS-MCMC after every optimizer step."""
+    if inject_noise:
+        _, add_noise = ops or _default_ops()
+        add_noise(g.scales.detach(), g.rotations.detach(), g.opacities.detach(), g.means.data, 5e5 * lr_means)

@@ -129,3 +129,58 @@ def test_initialize_from_point_cloud():
     assert torch.allclose(torch.sigmoid(m['opacities']), torch.full((500, 1), 0.5)) and torch.allclose(m['sh_coefficients_0'], torch.zeros(500, 1, 3))
     g = Gaussians(p, 'cpu')          # feeds the trainer unchanged
     assert g.means.shape == (500, 3)
+
+
+def _sim_ops():
+    be = helpers.sim_backend()
+
+    def add_noise(raw_scales, raw_rotations, raw_opacities, means, current_lr):
+        be.add_noise(raw_scales.contiguous(), raw_rotations.contiguous(), raw_opacities.contiguous(), torch.randn_like(means), means, current_lr)
+    return be.relocation_adjustment, add_noise
+
+
+def test_mcmc_densification_relocates_and_grows():
+    """Model.py:367-457 on the simulation backend's relocation kernel: dead Gaussians become copies of sampled live ones with
+    the shared opacity / scale of 3DGS-MCMC Eq. 9, the sampled ones lose their Adam moments, the set grows by 5 % up to the cap."""
+    g = _gaussians(200)
+    with torch.no_grad():
+        g.opacities[:20] = -12.0                 # dead (sigmoid << min_opacity)
+        g.rotations[20:25] = 0.0                 # degenerate quaternion: dead as well
+        g.opacities[25:] = g.opacities[25:].clamp_min(-1.0)
+    before = {k: getattr(g, k).detach().clone() for k in PARAM_ORDER}
+    stats = D.mcmc_densification(g, 0.005, 200, generator=torch.Generator().manual_seed(0), ops=_sim_ops())    # cap reached: relocation only
+    assert stats['relocated'] == 25 and stats['added'] == 0 and g.means.shape[0] == 200
+    op = torch.sigmoid(g.opacities.detach()).flatten()
+    assert float(op.min()) >= 0.005 - 1e-6                                                    # nothing dead is left
+    # every relocated Gaussian sits exactly on a previously live one and shares its new opacity and scale
+    for i in range(25):
+        src = torch.where((before['means'][25:] == g.means.detach()[i]).all(dim=1))[0]
+        assert src.numel() >= 1
+        j = 25 + int(src[0])
+        assert torch.equal(g.opacities.detach()[i], g.opacities.detach()[j]) and torch.equal(g.scales.detach()[i], g.scales.detach()[j])
+        assert float(torch.sigmoid(g.opacities.detach()[j])) < float(torch.sigmoid(before['opacities'][j])) + 1e-7   # shared => not larger
+        st = g.optimizer.state[g.means]
+        assert torch.all(st['exp_avg'][j] == 0.0)
+    assert g.densification_info is None
+    # growth: 5 % more Gaussians, capped; the copies start with zero moments
+    stats = D.mcmc_densification(g, 0.005, 208, generator=torch.Generator().manual_seed(1), ops=_sim_ops())
+    assert stats['relocated'] == 0 and stats['added'] == 8 and g.means.shape[0] == 208        # min(cap, int(1.05 * 200)) = 208
+    st = g.optimizer.state[g.means]
+    assert st['exp_avg'].shape[0] == 208 and torch.all(st['exp_avg'][200:] == 0.0)
+    assert D.mcmc_densification(g, 0.005, 208, generator=torch.Generator().manual_seed(2), ops=_sim_ops())['added'] == 0
+
+
+def test_importance_pruning_and_noise_hook():
+    g = _gaussians(100)
+    scores = torch.arange(100, dtype=torch.float32)
+    tag = g.means.detach().clone()
+    removed = D.importance_pruning(g, scores, 0.3)                      # Model.py:465-470: k = int(0.3 * 99) + 1 = 30 lowest
+    assert removed == 30 and g.means.shape[0] == 70 and torch.equal(g.means.detach(), tag[30:])
+    assert g.optimizer.state[g.means]['exp_avg'].shape[0] == 70
+    before = g.means.detach().clone()
+    torch.manual_seed(0)
+    D.post_optimizer_step(g, False, 1.6e-4, ops=_sim_ops())
+    assert torch.equal(g.means.detach(), before)
+    D.post_optimizer_step(g, True, 1.6e-4, ops=_sim_ops())             # Model.py:472-475: SGLD noise scaled by (1 - opacity) sigmoid gate
+    moved = (g.means.detach() - before).abs().max()
+    assert 0.0 < float(moved) < 5.0
