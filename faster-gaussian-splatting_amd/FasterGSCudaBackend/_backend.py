@@ -301,6 +301,29 @@ class Backend:
                                                 S, _stream_of(device)), 'fgs_shard_backward')
         return out
 
+    def shard_backward_adam_fused(self, acc_records: torch.Tensor, n_visible: Sequence[int], primitive_buffer: torch.Tensor, densification_info,
+                                  params: Sequence[torch.Tensor], exp_avgs, exp_avg_sqs, views: Sequence[RasterizerSettings], step: int,
+                                  lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15) -> None:
+        """`shard_backward` + Adam on the shard without materialising the gradients (<= 8 views). params / moments / lrs in
+        optimizer-group order: means, sh0, sh_rest, opacities, scales, rotations."""
+        device = self._check_params(tuple(params) + tuple(exp_avgs) + tuple(exp_avg_sqs), ['param/moment'] * 18)
+        n, k = params[0].shape[0], len(views)
+        total_rest = params[2].shape[1] if params[2].dim() == 3 else 0
+        total = int(sum(n_visible))
+        if len(n_visible) != k or (total > 0 and (acc_records.dtype != torch.float32 or acc_records.numel() < 9 * total
+                                                  or not acc_records.is_contiguous() or acc_records.device != device)):
+            raise RuntimeError('acc_records must be contiguous float32 [sum(n_visible), 9] and n_visible one entry per view')
+        keep: list = []
+        S = self._settings_array(views, total_rest, device, keep)
+        dens = densification_info if densification_info is not None and densification_info.numel() > 0 else None
+        scratch = torch.empty(max(int(self.lib.fgs_shard_backward_scratch_bytes(n, k)), 1), dtype=torch.uint8, device=device)
+        counts = (C.c_int32 * k)(*[int(x) for x in n_visible])
+        arr = lambda ts: (C.c_void_p * 6)(*[_ptr(t) for t in ts])
+        self._check(self.lib.fgs_shard_backward_adam_fused(_ptr(acc_records) if total > 0 else None, counts, _ptr(primitive_buffer), arr(params),
+                                                           arr(exp_avgs), arr(exp_avg_sqs), _ptr(dens), scratch.data_ptr(), n, k, S, int(step),
+                                                           (C.c_double * 6)(*[float(x) for x in lrs]), float(betas[0]), float(betas[1]),
+                                                           float(eps), _stream_of(device)), 'fgs_shard_backward_adam_fused')
+
     # -- the remaining exported operators (reference torch_bindings/filter3d.py, densification.py) ---------------------------
     def update_3d_filter(self, positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
                          near_plane, clipping_tolerance, distance2filter) -> None:

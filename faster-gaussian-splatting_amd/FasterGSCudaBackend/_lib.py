@@ -65,6 +65,8 @@ _SIGNATURES = {
     'fgs_backward_to_records': (C.c_int32, [_P] * 2 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
     'fgs_shard_backward_scratch_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_shard_backward': (C.c_int32, [_P, C.POINTER(_I32), _P] + [_P] * 5 + [_P] * 6 + [_P, _P, _I32, _I32, C.POINTER(Settings), _P]),
+    'fgs_shard_backward_adam_fused': (C.c_int32, [_P, C.POINTER(_I32), _P] + [C.POINTER(_P)] * 3 + [_P, _P, _I32, _I32, C.POINTER(Settings), _I32,
+                                                  C.POINTER(_F64), _F64, _F64, _F64, _P]),
     'fgs_blob_layout': (C.c_int32, [_I32] * 6 + [C.POINTER(BlobEntry), _I32]),
     'fgs_update_3d_filter': (C.c_int32, [_P] * 4 + [_I32, _I32, _I32] + [C.c_float] * 7 + [_P]),
     'fgs_relocation_table': (C.c_int32, [C.POINTER(C.c_float)]),

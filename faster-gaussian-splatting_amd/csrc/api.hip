@@ -575,13 +575,15 @@ size_t fgs_shard_backward_scratch_bytes(int32_t n_primitives, int32_t n_views) {
     return ((size_t)n_primitives * 3 * sizeof(float) + 255) / 256 * 256 * (size_t)n_views + 256;     // one view-direction array per view
 }
 
-int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
-                           const float* means, const float* scales, const float* rotations, const float* opacities,
-                           const float* sh_coefficients_rest,
-                           float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
-                           float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
-                           float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
-                           const fgs_settings* settings, void* stream_) {
+struct ShardAdam { float* const* params; float* const* exp_avgs; float* const* exp_avg_sqs; int step; const double* lrs; double beta1, beta2, eps; };
+
+static int run_shard_backward(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                              const float* means, const float* scales, const float* rotations, const float* opacities,
+                              const float* sh_coefficients_rest,
+                              float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                              float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                              float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                              const fgs_settings* settings, const ShardAdam* adam, void* stream_) {
     if (n_views < 1 || !settings || !n_visible) return fail(FGS_ERR_INVALID_ARGUMENT, "n_views %d / settings / n_visible", n_views);
     int64_t total_visible = 0;
     for (int v = 0; v < n_views; ++v) {
@@ -592,9 +594,11 @@ int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, c
     if (n_primitives < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "n_primitives %d", n_primitives);
     if (n_primitives == 0) return FGS_OK;
     if (!primitive_buffers || !scratch || (total_visible > 0 && !acc_records)) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL buffer");
-    if (!means || !scales || !rotations || !opacities || !grad_means || !grad_scales || !grad_rotations || !grad_opacities || !grad_sh_coefficients_0)
-        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter / gradient tensor");
-    if (settings->total_sh_bases_rest > 0 && !grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
+    if (!means || !scales || !rotations || !opacities) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL parameter tensor");
+    if (!adam && (!grad_means || !grad_scales || !grad_rotations || !grad_opacities || !grad_sh_coefficients_0 ||
+                  (settings->total_sh_bases_rest > 0 && !grad_sh_coefficients_rest)))
+        return fail(FGS_ERR_INVALID_ARGUMENT, "NULL gradient tensor");
+    if (adam && n_views > kMaxBatchViews) return fail(FGS_ERR_INVALID_ARGUMENT, "the fused form sums at most %d views in registers (got %d)", kMaxBatchViews, n_views);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t n = static_cast<uint32_t>(n_primitives);
     const Geometry geo = geometry_of(settings->width, settings->height);
@@ -622,14 +626,52 @@ int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, c
             sh.view[k] = sh_rest_view(a.view[k]);
             first_record += static_cast<size_t>(n_visible[v]);
         }
-        { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }
+        if (adam) {       // API group order (Model.py:238-245): 0 means, 1 sh0, 2 sh_rest, 3 opacities, 4 scales, 5 rotations
+            const int map[5] = {0, 1, 3, 4, 5};     // kernel group order: means, sh0, opacities, scales, rotations
+            for (int k = 0; k < 5; ++k) {
+                a.p[k] = adam->params[map[k]]; a.m[k] = adam->exp_avgs[map[k]]; a.v[k] = adam->exp_avg_sqs[map[k]];
+                a.h[k] = adam_hyper(adam->step, adam->lrs[map[k]], adam->beta1, adam->beta2, adam->eps);
+            }
+            sh.p = adam->params[2]; sh.m = adam->exp_avgs[2]; sh.v = adam->exp_avg_sqs[2];
+            sh.h = adam_hyper(adam->step, adam->lrs[2], adam->beta1, adam->beta2, adam->eps);
+        }
+        // fused: the geometry kernel reads sh_rest (pre-update) and leaves the view directions, then the SH-rest pass updates it
+        { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(adam != nullptr, a, stream)); }
         if (settings->total_sh_bases_rest > 0) {
             sh.grad_sh_rest = grad_sh_coefficients_rest;
             sh.n = n; sh.total_sh_rest = settings->total_sh_bases_rest; sh.active_sh_bases = settings->active_sh_bases; sh.accumulate = a.accumulate;
-            { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, sh, stream)); }
+            { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(adam != nullptr, sh, stream)); }
         }
     }
     return FGS_OK;
+}
+
+int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                           const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh_coefficients_rest,
+                           float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                           float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                           float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                           const fgs_settings* settings, void* stream) {
+    return run_shard_backward(acc_records, n_visible, primitive_buffers, means, scales, rotations, opacities, sh_coefficients_rest, grad_means,
+                              grad_scales, grad_rotations, grad_opacities, grad_sh_coefficients_0, grad_sh_coefficients_rest, densification_info,
+                              scratch, n_primitives, n_views, settings, nullptr, stream);
+}
+
+int32_t fgs_shard_backward_adam_fused(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                                      float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                      float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                                      const fgs_settings* settings, int32_t step, const double* lrs, double beta1, double beta2, double eps,
+                                      void* stream) {
+    if (!params || !exp_avgs || !exp_avg_sqs || !lrs || step < 1 || !settings) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int k = 0; k < 6; ++k)
+        if (n_primitives > 0 && (!params[k] || !exp_avgs[k] || !exp_avg_sqs[k])) {
+            if (k == 2 && settings->total_sh_bases_rest == 0) continue;
+            return fail(FGS_ERR_INVALID_ARGUMENT, "NULL tensor in group %d", k);
+        }
+    const ShardAdam adam{params, exp_avgs, exp_avg_sqs, step, lrs, beta1, beta2, eps};
+    return run_shard_backward(acc_records, n_visible, primitive_buffers, params[0], params[4], params[5], params[3], params[2], nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, densification_info, scratch, n_primitives, n_views, settings, &adam, stream);
 }
 
 int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,

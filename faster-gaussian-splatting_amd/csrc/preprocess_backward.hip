@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBackwardBlock - 1) / kPreprocessBackwardBlock), block(kPreprocessBackwardBlock);
-    if (fused_adam) hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, 0, s, a);
+    if (fused_adam && a.view[0].slot != nullptr) hipLaunchKernelGGL((preprocess_backward_kernel<true, true>), grid, block, 0, s, a);
+    else if (fused_adam) hipLaunchKernelGGL((preprocess_backward_kernel<true, false>), grid, block, 0, s, a);
     else if (a.view[0].slot == nullptr) hipLaunchKernelGGL((preprocess_backward_kernel<false, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), grid, block, 0, s, a);
     return hipGetLastError();
@@ -278,14 +279,13 @@ __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShR
 // private LDS slice and leaves as fully coalesced 16-byte stores. (v1: one lane per (Gaussian, basis) pair evaluated all 15
 // basis functions to keep one -- 33 VALU instructions per output float, half VALU-bound at 0.184 ms for a 540 MB write.)
 // MULTI (sharded path): the gradient is summed over the views of the launch, colour gradients come from the accumulator records.
+// lane `lane` of a wave whose first Gaussian is `first`: the 3 * R gradient floats of Gaussian first + lane, summed over the
+// views of the launch, written to the wave's LDS slice at [lane * R * 3 ...] (the slice then holds the wave's contiguous
+// block of the [N, R, 3] tensor).
 template <int RT, bool MULTI>
-__global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs a) {
+__device__ __forceinline__ void sh_rest_block_to_lds(const ShRestArgs& a, const uint32_t first, const uint32_t lane, float* slice) {
     constexpr int kMaxRest = 15;
-    __shared__ __attribute__((aligned(16))) float s_out[256 / kWave][kWave * kMaxRest * 3];
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t first = (blockIdx.x * 256u + wv * kWave);         // first Gaussian of this wave
-    if (first >= a.n) return;                                         // wave-uniform
     const uint32_t gi = first + lane;
     const bool in_range = gi < a.n;
     const size_t n = a.n;
@@ -310,11 +310,21 @@ __global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs 
             else { g[k][0] += B[k] * c[0]; g[k][1] += B[k] * c[1]; g[k][2] += B[k] * c[2]; }
         }
     }
-    float* mine = &s_out[wv][lane * R * 3u];
+    float* mine = slice + lane * R * 3u;
 #pragma unroll
     for (int k = 0; k < kMaxRest; ++k)
         if (static_cast<uint32_t>(k) < R) { mine[3 * k] = g[k][0]; mine[3 * k + 1] = g[k][1]; mine[3 * k + 2] = g[k][2]; }
     wave_lds_fence();
+}
+
+template <int RT, bool MULTI>
+__global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_out[256 / kWave][kWave * 15 * 3];
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t first = (blockIdx.x * 256u + wv * kWave);         // first Gaussian of this wave
+    if (first >= a.n) return;                                         // wave-uniform
+    sh_rest_block_to_lds<RT, MULTI>(a, first, lane, s_out[wv]);
     const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;      // floats this wave owns
     float* out = a.grad_sh_rest + (size_t)first * R * 3u;                             // 64 * R * 12 bytes per wave: 16-byte aligned
     const bool add = MULTI && a.accumulate;                                            // view batches after the first
@@ -325,6 +335,35 @@ __global__ void __launch_bounds__(256) sh_rest_gradient_kernel(const ShRestArgs 
             *reinterpret_cast<float4*>(out + e) = v;
         } else {
             for (uint32_t j = e; j < count; ++j) out[j] = add ? out[j] + s_out[wv][j] : s_out[wv][j];
+        }
+    }
+}
+
+// Sharded path, fused with Adam: the wave's gradient block (summed over the views) stays in LDS and feeds the update of the
+// wave's contiguous 64 x R x 3 slice of parameter / exp_avg / exp_avg_sq, streamed as non-temporal 16-byte accesses.
+template <int RT>
+__global__ void __launch_bounds__(256) sh_rest_adam_views_kernel(const ShRestArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_out[256 / kWave][kWave * 15 * 3];
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t first = (blockIdx.x * 256u + wv * kWave);
+    if (first >= a.n) return;
+    sh_rest_block_to_lds<RT, true>(a, first, lane, s_out[wv]);
+    const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;
+    const size_t base = (size_t)first * R * 3u;
+    for (uint32_t e = 4u * lane; e < count; e += 4u * kWave) {
+        if (e + 4u <= count) {
+            float4 p4 = load_float4_nt(a.p + base + e), m4 = load_float4_nt(a.m + base + e), v4 = load_float4_nt(a.v + base + e);
+            const float4 g = *reinterpret_cast<const float4*>(&s_out[wv][e]);
+            adam_update(p4.x, m4.x, v4.x, g.x, a.h); adam_update(p4.y, m4.y, v4.y, g.y, a.h);
+            adam_update(p4.z, m4.z, v4.z, g.z, a.h); adam_update(p4.w, m4.w, v4.w, g.w, a.h);
+            store_float4_nt(a.p + base + e, p4); store_float4_nt(a.m + base + e, m4); store_float4_nt(a.v + base + e, v4);
+        } else {
+            for (uint32_t j = e; j < count; ++j) {
+                float pp = a.p[base + j], mm = a.m[base + j], vv = a.v[base + j];
+                adam_update(pp, mm, vv, s_out[wv][j], a.h);
+                a.p[base + j] = pp; a.m[base + j] = mm; a.v[base + j] = vv;
+            }
         }
     }
 }
@@ -397,6 +436,11 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
             if (views) hipLaunchKernelGGL((sh_rest_gradient_kernel<0, true>), ggrid, block, 0, s, a);
             else hipLaunchKernelGGL((sh_rest_gradient_kernel<0, false>), ggrid, block, 0, s, a);
         }
+    } else if (a.view[0].slot != nullptr) {                      // sharded path fused with Adam
+        if (a.total_sh_rest > 15) return hipErrorInvalidValue;
+        const dim3 ggrid((a.n + 255u) / 256u);
+        if (a.total_sh_rest == 15) hipLaunchKernelGGL(sh_rest_adam_views_kernel<15>, ggrid, block, 0, s, a);
+        else hipLaunchKernelGGL(sh_rest_adam_views_kernel<0>, ggrid, block, 0, s, a);
     } else if (a.total_sh_rest == 15) {
         hipLaunchKernelGGL((sh_rest_backward_kernel<true, 15>), grid, block, 0, s, a);
     } else {

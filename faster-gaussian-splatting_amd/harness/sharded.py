@@ -42,9 +42,10 @@ def shard_of(params: dict, rank: int, world: int) -> dict:
 
 class ShardedTrainer:
     def __init__(self, backend: Backend, shard_params: dict, lrs: dict, *, group=None, betas=(0.9, 0.999), eps: float = 1e-15,
-                 loss: str = 'l1_dssim') -> None:
+                 loss: str = 'l1_dssim', fused: bool = True) -> None:
         assert loss in ('l1', 'l1_dssim')
         self.be, self.group, self.betas, self.eps, self.loss = backend, group, betas, eps, loss
+        self.fused = fused            # phase C as ONE fused K12 + Adam pass (gradients never materialised) when the batch has <= 8 views
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         device = shard_params['means'].device
@@ -116,11 +117,17 @@ class ShardedTrainer:
                update_densification: bool) -> None:
         """Phase C (owner): K12 on the shard, gradients summed over the views in registers (one launch), then one Adam launch."""
         p = self.params
-        grads = tuple(self.grads[k] for k in _BACKWARD_ORDER)
         dens = self.densification_info if update_densification else None
+        self.step_count += 1
+        if self.fused and len(views) <= 8:
+            view_of = lambda arena, k: arena[self.layout[k][0]:self.layout[k][0] + self.layout[k][1]].view(self.layout[k][2])
+            self.be.shard_backward_adam_fused(acc_back, sent, prim, dens, [p[k] for k in SEGMENTS], [view_of(self.exp_avg, k) for k in SEGMENTS],
+                                              [view_of(self.exp_avg_sq, k) for k in SEGMENTS], views, self.step_count,
+                                              [self.lrs[k] for k in SEGMENTS], self.betas, self.eps)
+            return
+        grads = tuple(self.grads[k] for k in _BACKWARD_ORDER)
         self.be.shard_backward(acc_back, sent, prim, dens, p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_rest'],
                                views, grads)
-        self.step_count += 1
         segs = [(k, self.layout[k][0], self.layout[k][0] + self.layout[k][1]) for k in SEGMENTS if self.layout[k][1] > 0]
         self.be.adam_step_multi([self.grad_arena[a:b] for _, a, b in segs], [self.param_arena[a:b] for _, a, b in segs],
                                 [self.exp_avg[a:b] for _, a, b in segs], [self.exp_avg_sq[a:b] for _, a, b in segs],

@@ -176,6 +176,15 @@ int32_t fgs_shard_backward(const float* acc_records, const int32_t* n_visible, c
                            float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
                            const fgs_settings* settings, void* stream);
 
+/* fgs_shard_backward fused with Adam on the shard (as fgs_backward_adam_fused is for the single-GPU path): the gradients,
+ * summed over the n_views <= 8 views in registers / LDS, are never materialised. params / exp_avgs / exp_avg_sqs / lrs:
+ * [host] arrays of 6 in optimizer-group order (means, sh_coefficients_0, sh_coefficients_rest, opacities, scales, rotations). */
+int32_t fgs_shard_backward_adam_fused(const float* acc_records, const int32_t* n_visible, const void* primitive_buffers,
+                                      float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                      float* densification_info, void* scratch, int32_t n_primitives, int32_t n_views,
+                                      const fgs_settings* settings, int32_t step, const double* lrs, double beta1, double beta2, double eps,
+                                      void* stream);
+
 /* Test/bench introspection: byte offsets of the named sub-arrays inside a scratch buffer, so tests can compare every
  * intermediate with the oracle. Returns the number of entries written (<= max_entries); names are static strings. */
 typedef struct fgs_blob_entry { const char* name; size_t offset; size_t bytes; } fgs_blob_entry;

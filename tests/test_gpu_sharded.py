@@ -101,7 +101,8 @@ def test_shard_backward_sums_views_on_device(hip_backend):
             assert helpers.rel_inf(g.cpu().numpy(), t[s::2].cpu().numpy()) < 1e-4, (k, s)
 
 
-def test_local_shard_group_equals_replicated_trainer(hip_backend):
+@pytest.mark.parametrize('fused', [True, False])
+def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
     """4 owners x 4 views, 3 steps, against ViewParallelTrainer summing the four per-view gradients itself."""
     from harness.distributed import SEGMENTS, ViewParallelTrainer
     from harness.sharded import LocalShardGroup
@@ -110,7 +111,7 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend):
     views = orbit_views(8, width=640, height=360, focal=473.0)[:4]
     RS = [helpers.settings_pair(v, device=DEV)[1] for v in views]
     targets = [torch.rand(3, 360, 640, generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(4)]
-    grp = LocalShardGroup(hip_backend, params, LRS, 4)
+    grp = LocalShardGroup(hip_backend, params, LRS, 4, fused=fused)
     tr = ViewParallelTrainer(hip_backend, params, LRS)
     start = {k: params[k].clone() for k in SEGMENTS}
     for _ in range(3):

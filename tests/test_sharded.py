@@ -181,3 +181,18 @@ def test_local_shard_group_matches_summed_gradient_reference(world):
         tr._adam(0, tr.param_arena.numel(), 0)
     for k in SEGMENTS:
         assert torch.allclose(got[k], tr.params[k], rtol=0, atol=1e-6), (k, (got[k] - tr.params[k]).abs().max())
+
+
+def test_fused_and_unfused_phase_c_agree():
+    """fgs_shard_backward_adam_fused == fgs_shard_backward + Adam (3 owners x 3 views, 2 steps; moments compared as well)."""
+    from harness.sharded import LocalShardGroup
+    params, settings, targets = _scene()
+    views, tg = [settings[i % 2] for i in range(3)], [targets[i % 2] for i in range(3)]
+    groups = [LocalShardGroup(helpers.sim_backend(), params, LRS, 3, fused=f) for f in (True, False)]
+    for grp in groups:
+        for _ in range(2):
+            grp.step(views, tg)
+    for a, b in zip(groups[0].ranks, groups[1].ranks):
+        assert torch.allclose(a.param_arena, b.param_arena, rtol=0, atol=1e-6)
+        assert torch.allclose(a.exp_avg, b.exp_avg, rtol=1e-5, atol=1e-9) and torch.allclose(a.exp_avg_sq, b.exp_avg_sq, rtol=1e-5, atol=1e-12)
+        assert torch.equal(a.densification_info, b.densification_info)

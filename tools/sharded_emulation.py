@@ -25,6 +25,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scene', default='S2')
 ap.add_argument('--worlds', type=int, nargs='+', default=[2, 4, 8])
 ap.add_argument('--steps', type=int, default=6)
+ap.add_argument('--unfused', action='store_true', help='phase C as K12 + separate Adam launch')
 a = ap.parse_args()
 
 sys.argv = ['bench.py', '--scene', a.scene]
@@ -55,7 +56,7 @@ out['single_gpu_ms_per_iteration'] = single_ms
 
 LINK_GBS = 76.8          # one xGMI link, one direction (153.6 GB/s bidirectional); every pair of GPUs has its own link
 for G in a.worlds:
-    grp = LocalShardGroup(be, full, lrs, G)
+    grp = LocalShardGroup(be, full, lrs, G, fused=not a.unfused)
     batch = lambda i: [(i * G + r) % len(views) for r in range(G)]
     for i in range(2):
         idx = batch(i)
