@@ -169,6 +169,33 @@ def test_huge_footprints_workgroup_path(hip_backend, oracle):
     _forward_check(hip_backend, oracle, p, v)
 
 
+def test_known_answer_single_gaussian_on_device(hip_backend):
+    """The hand-derived known answer of tests/test_oracle.py::test_known_answer_single_gaussian, against the HIP path directly
+    (no oracle involved): one isotropic Gaussian on the optical axis, image and two analytic gradients."""
+    W, H, f, z, sigma, logit = 32, 24, 30.0, 5.0, 0.1, 2.0
+    bg, sh0, C0 = np.array([0.1, 0.2, 0.3]), np.array([0.7, -0.2, 1.1]), 0.28209479177387814
+    v = View(torch.eye(4), torch.zeros(3), W, H, f, f, W / 2, H / 2, 0.2, 1e4, torch.tensor(bg, dtype=torch.float32))
+    _, RS = helpers.settings_pair(v, 1, False, device=DEV)
+    t = lambda x: torch.tensor(x, dtype=torch.float32, device=DEV)
+    P = dict(means=t([[0, 0, z]]), scales=t(np.full((1, 3), np.log(sigma))), rotations=t([[1, 0, 0, 0]]), opacities=t([[logit]]),
+             sh_coefficients_0=t(sh0.reshape(1, 1, 3)), sh_coefficients_rest=torch.zeros(1, 15, 3, device=DEV))
+    res = hip_backend.forward(*[P[k] for k in helpers.NAMES], RS)
+    cov, op = (f * sigma / z) ** 2 + 0.3, 1.0 / (1.0 + np.exp(-logit))
+    ys, xs = np.mgrid[0:H, 0:W]
+    G = np.exp(-0.5 * ((xs + 0.5 - W / 2) ** 2 + (ys + 0.5 - H / 2) ** 2) / cov)
+    alpha = np.where(op * G >= 1.0 / 255.0, op * G, 0.0)
+    colour = 0.5 + C0 * sh0
+    expected = alpha[None] * colour[:, None, None] + (1.0 - alpha[None]) * bg[:, None, None]
+    assert res.state[0] == 1 and np.abs(res.image.cpu().numpy() - expected).max() < 5e-6
+    gi = np.random.default_rng(0).standard_normal((3, H, W)).astype(np.float32)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, P['means'], P['scales'], P['rotations'],
+                                 P['opacities'], P['sh_coefficients_rest'], res.buffers, RS, res.state)
+    d_sh0 = C0 * (alpha[None] * gi).sum(axis=(1, 2))
+    d_logit = op * (1.0 - op) * (np.where(alpha > 0, G, 0.0)[None] * (colour - bg)[:, None, None] * gi).sum()
+    assert np.abs(grads[4].cpu().numpy().reshape(3) - d_sh0).max() < 1e-4 * max(1.0, np.abs(d_sh0).max())
+    assert abs(float(grads[3].cpu().reshape(-1)[0]) - d_logit) < 1e-4 * max(1.0, abs(d_logit))
+
+
 def test_more_than_65536_tiles_uses_32_bit_keys(hip_backend, oracle):
     """fwd:152-153: above 65 536 tiles the instance keys are 32-bit (275 x 250 = 68 750 tiles here). Forward intermediates and the
     backward pass against the oracle."""

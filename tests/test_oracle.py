@@ -151,3 +151,36 @@ def test_gradients_match_finite_differences(oracle):
                 vals.append(autograd_reference(q, S, f, gi, loss_only=True))
             fd = (vals[0] - vals[1]) / (2.0 * eps)
             assert abs(fd - grad[idx]) <= 2e-3 * scale + 1e-6, (k, idx, fd, grad[idx])
+
+
+def test_known_answer_single_gaussian(oracle):
+    """Hand-derived known answer, independent of the oracle's code: ONE isotropic Gaussian on the optical axis.
+    mean2d = (cx, cy); cov2d = ((f*sigma/z)^2 + 0.3) I (kf:115-145); alpha(p) = sigmoid(o) * exp(-|p + 0.5 - mean2d|^2 / (2 cov))
+    where alpha >= 1/255 (kf:452-470), colour = 0.5 + C0 * sh0 (sh:32-35), pixel = alpha * colour + (1 - alpha) * bg (kf:481-486).
+    Also two analytic gradients: dL/dsh0 = C0 * sum_p alpha_p * g_p and dL/dopacity_logit = o(1-o) * sum_p G_p (c - bg) . g_p."""
+    W, H, f, z, sigma, logit = 32, 24, 30.0, 5.0, 0.1, 2.0
+    bg = np.array([0.1, 0.2, 0.3])
+    sh0 = np.array([0.7, -0.2, 1.1])
+    C0 = 0.28209479177387814
+    v = View(torch.eye(4), torch.zeros(3), W, H, f, f, W / 2, H / 2, 0.2, 1e4, torch.tensor(bg, dtype=torch.float32))
+    S, _ = helpers.settings_pair(v, 1, False)
+    f32 = np.float32
+    a = (np.array([[0, 0, z]], f32), np.full((1, 3), np.log(sigma), f32), np.array([[1, 0, 0, 0]], f32), np.array([[logit]], f32),
+         sh0.reshape(1, 1, 3).astype(f32), np.zeros((1, 15, 3), f32))
+    fwd = oracle.forward(*a, S)
+    cov = (f * sigma / z) ** 2 + 0.3
+    op = 1.0 / (1.0 + np.exp(-logit))
+    ys, xs = np.mgrid[0:H, 0:W]
+    d2 = (xs + 0.5 - W / 2) ** 2 + (ys + 0.5 - H / 2) ** 2
+    G = np.exp(-0.5 * d2 / cov)
+    alpha = np.where(op * G >= 1.0 / 255.0, op * G, 0.0)
+    colour = 0.5 + C0 * sh0
+    expected = alpha[None] * colour[:, None, None] + (1.0 - alpha[None]) * bg[:, None, None]
+    assert fwd['V'] == 1 and np.abs(fwd['image'] - expected).max() < 2e-6
+    assert int((alpha > 0).sum()) > 20                                    # the footprint spans several pixels
+    gi = np.random.default_rng(0).standard_normal((3, H, W)).astype(f32)
+    g = oracle.backward(fwd, S, gi)
+    d_sh0 = C0 * (alpha[None] * gi).sum(axis=(1, 2))
+    d_logit = op * (1.0 - op) * (np.where(alpha > 0, G, 0.0)[None] * (colour - bg)[:, None, None] * gi).sum()
+    assert np.abs(g['sh0'].reshape(3) - d_sh0).max() < 1e-5 * max(1.0, np.abs(d_sh0).max())
+    assert abs(float(g['opacities'].reshape(-1)[0]) - d_logit) < 1e-5 * max(1.0, abs(d_logit))
