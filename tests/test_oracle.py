@@ -184,3 +184,69 @@ def test_known_answer_single_gaussian(oracle):
     d_logit = op * (1.0 - op) * (np.where(alpha > 0, G, 0.0)[None] * (colour - bg)[:, None, None] * gi).sum()
     assert np.abs(g['sh0'].reshape(3) - d_sh0).max() < 1e-5 * max(1.0, np.abs(d_sh0).max())
     assert abs(float(g['opacities'].reshape(-1)[0]) - d_logit) < 1e-5 * max(1.0, abs(d_logit))
+
+
+def test_known_answer_two_rotated_gaussians(oracle):
+    """Second hand-derived case: two anisotropic, arbitrarily rotated Gaussians on the optical axis at different depths.
+    On the axis the projection Jacobian is (f/z) [I2 | 0], so cov2d = (f/z)^2 (R diag(s^2) R^T)[:2,:2] + 0.3 I with R the standard
+    rotation matrix of the normalised (w, x, y, z) quaternion; compositing is front to back:
+    pixel = a1 c1 + (1 - a1) a2 c2 + (1 - a1)(1 - a2) bg. Checks the quaternion convention, the conic's off-diagonal sign and the order."""
+    W, H, f = 48, 36, 40.0
+    bg = np.array([0.05, 0.1, 0.15])
+    C0 = 0.28209479177387814
+    zs = [4.0, 6.0]
+    quats = np.array([[0.9, 0.1, -0.3, 0.25], [0.3, -0.6, 0.2, 0.7]])
+    scales = np.array([[0.25, 0.08, 0.15], [0.3, 0.35, 0.1]])
+    logits = np.array([1.0, 3.0])
+    sh0 = np.array([[1.2, 0.1, -0.6], [-0.3, 0.9, 0.4]])
+    v = View(torch.eye(4), torch.zeros(3), W, H, f, f, W / 2, H / 2, 0.2, 1e4, torch.tensor(bg, dtype=torch.float32))
+    S, _ = helpers.settings_pair(v, 1, False)
+    f32 = np.float32
+    a = (np.array([[0, 0, zs[0]], [0, 0, zs[1]]], f32), np.log(scales).astype(f32), quats.astype(f32), logits.reshape(2, 1).astype(f32),
+         sh0.reshape(2, 1, 3).astype(f32), np.zeros((2, 15, 3), f32))
+    fwd = oracle.forward(*a, S)
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = W / 2 - (xs + 0.5), H / 2 - (ys + 0.5)
+    T = np.ones((H, W))
+    img = np.zeros((3, H, W))
+    for i in range(2):                                                    # depth order: z = 4 first
+        w, x, y, z = quats[i] / np.linalg.norm(quats[i])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        cov = (f / zs[i]) ** 2 * (R @ np.diag(scales[i] ** 2) @ R.T)[:2, :2] + 0.3 * np.eye(2)
+        inv = np.linalg.inv(cov)
+        G = np.exp(-0.5 * (inv[0, 0] * dx * dx + 2 * inv[0, 1] * dx * dy + inv[1, 1] * dy * dy))
+        alpha = 1.0 / (1.0 + np.exp(-logits[i])) * G
+        alpha = np.where(alpha >= 1.0 / 255.0, alpha, 0.0)
+        colour = np.maximum(0.5 + C0 * sh0[i], 0.0)                       # clamped at blend time (kf:430)
+        img += (T * alpha)[None] * colour[:, None, None]
+        T = T * (1.0 - alpha)
+    img += T[None] * bg[:, None, None]
+    assert fwd['V'] == 2 and list(fwd['prim_idx']) == [0, 1]
+    assert np.abs(fwd['image'] - img).max() < 3e-6
+
+
+def test_sh_basis_is_orthonormal(oracle):
+    """Pins the 16 spherical-harmonic constants restated from sh_utils.cuh:32-69 without trusting them: evaluated through the
+    oracle's forward pass (colour of a Gaussian whose rest coefficients are one-hot) on 1 500 quasi-uniform directions, the basis
+    must satisfy the defining property of real orthonormal SH, integral(Y_i Y_j) = delta_ij. (Signs follow the 3DGS convention.)"""
+    M = 1500
+    k = np.arange(M) + 0.5
+    phi, ct = np.pi * (1 + 5 ** 0.5) * k, 1 - 2 * k / M                   # Fibonacci sphere
+    dirs = np.stack([np.cos(phi) * np.sqrt(1 - ct * ct), np.sin(phi) * np.sqrt(1 - ct * ct), ct], 1)
+    v = View(torch.eye(4), torch.zeros(3), 32, 24, 30.0, 30.0, 16.0, 12.0, 0.2, 1e4, torch.zeros(3))
+    f32 = np.float32
+    means = np.tile(np.array([[0, 0, 5.0]], f32), (15, 1))
+    sh_rest = np.zeros((15, 15, 3), f32)
+    sh_rest[np.arange(15), np.arange(15), 0] = 1.0                        # Gaussian j: coefficient j of the red channel = 1
+    a = [means, np.full((15, 3), np.log(0.05), f32), np.tile(np.array([[1, 0, 0, 0]], f32), (15, 1)), np.full((15, 1), 2.0, f32),
+         np.zeros((15, 1, 3), f32), sh_rest]
+    Y = np.zeros((M, 16))
+    Y[:, 0] = 0.28209479177387814
+    for m in range(M):
+        view = View(v.w2c, torch.tensor(means[0] - dirs[m].astype(f32)), 32, 24, 30.0, 30.0, 16.0, 12.0, 0.2, 1e4, torch.zeros(3))
+        S, _ = helpers.settings_pair(view, 16, False)
+        Y[m, 1:] = oracle.forward(*a, S, inference=False)['color'][:, 0] - 0.5   # colour = 0.5 + basis_j(direction)
+    gram = 4 * np.pi / M * Y.T @ Y
+    assert np.abs(gram - np.eye(16)).max() < 2e-3, np.abs(gram - np.eye(16)).max()
