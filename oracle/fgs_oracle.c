@@ -4,8 +4,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
  *  and its CUDA implementation cannot be compiled or run in this environment
  * (no nvcc, no NVIDIA device). This file restates the reference arithmetic from its sources; it is
- * pinned only by (a) an independent fp64 torch.autograd compositor (oracle/torch_check.py) and
- * (b) structural invariants (tests/test_oracle.py). See DESIGN.md "Oracle".
+ * pinned only by (a) an independent fp64 torch.autograd compositor (oracle/torch_check.py) and finite
+ * differences of it, (b) hand-derived closed-form cases (one / two Gaussians on the optical axis: image
+ * and analytic gradients) and the orthonormality of the SH basis, (c) structural invariants
+ * (all in tests/test_oracle.py). None of these is an output of the reference itself. See DESIGN.md "Oracle".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product path (faster-gaussian-splatting_amd/) never links, imports or calls it.
