@@ -196,3 +196,36 @@ def test_fused_and_unfused_phase_c_agree():
         assert torch.allclose(a.param_arena, b.param_arena, rtol=0, atol=1e-6)
         assert torch.allclose(a.exp_avg, b.exp_avg, rtol=1e-5, atol=1e-9) and torch.allclose(a.exp_avg_sq, b.exp_avg_sq, rtol=1e-5, atol=1e-12)
         assert torch.equal(a.densification_info, b.densification_info)
+
+
+def _worker_n(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _setup_paths()
+        import helpers as h
+        from harness.sharded import ShardedTrainer, shard_of
+        params, settings, targets = _scene()
+        tr = ShardedTrainer(h.sim_backend(), shard_of(params, rank, world), LRS)
+        for _ in range(2):
+            tr.step([settings[i % 2] for i in range(world)], targets[rank % 2])
+        full = tr.gather_parameters()
+        if rank == 0:
+            torch.save(full, Path(out_dir) / 'full.pt')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_world4_gloo_equals_local_group(tmp_path):
+    """Four processes exchanging through all_to_all_single (uneven splits, 4 x 4 count table) == the four owners stepped in one
+    process with local copies: the collectives move exactly the slices the local twin takes."""
+    from harness.sharded import LocalShardGroup
+    mp.spawn(_worker_n, args=(4, 33500 + (os.getpid() % 2000), str(tmp_path)), nprocs=4, join=True)
+    got = torch.load(tmp_path / 'full.pt')
+    params, settings, targets = _scene()
+    grp = LocalShardGroup(helpers.sim_backend(), params, LRS, 4)
+    for _ in range(2):
+        grp.step([settings[i % 2] for i in range(4)], [targets[i % 2] for i in range(4)])
+    ref = grp.gather_parameters()
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
