@@ -805,10 +805,32 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
+        case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 5: if (value < 1 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
+}
+
+size_t fgs_debug_radix_sort_temp_bytes(int32_t n, int32_t end_bit) {
+    return n < 0 ? 0 : own_sort_temp_bytes(static_cast<uint32_t>(n), end_bit);
+}
+
+int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, int32_t key_bytes, int32_t end_bit,
+                             void* temp, size_t temp_bytes, void* stream) {
+    if (n < 0 || (key_bytes != 2 && key_bytes != 4) || end_bit < 1 || end_bit > 8 * key_bytes)
+        return fail(FGS_ERR_INVALID_ARGUMENT, "bad sort arguments");
+    if (n > 0 && (!keys0 || !keys1 || !vals0 || !vals1 || !temp)) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL buffer");
+    int selector = 0;
+    uint32_t* vals[2] = {vals0, vals1};
+    if (key_bytes == 2) {
+        uint16_t* k[2] = {static_cast<uint16_t*>(keys0), static_cast<uint16_t*>(keys1)};
+        FGS_HIP(own_sort_pairs_u16(temp, temp_bytes, k, vals, selector, static_cast<uint32_t>(n), end_bit, static_cast<hipStream_t>(stream)));
+    } else {
+        uint32_t* k[2] = {static_cast<uint32_t*>(keys0), static_cast<uint32_t*>(keys1)};
+        FGS_HIP(own_sort_pairs_u32(temp, temp_bytes, k, vals, selector, static_cast<uint32_t>(n), end_bit, static_cast<hipStream_t>(stream)));
+    }
+    return selector;                     // 0 / 1: which buffer pair holds the sorted result
 }
 
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {

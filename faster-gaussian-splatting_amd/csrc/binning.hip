@@ -26,6 +26,8 @@ size_t depth_sort_temp_bytes(uint32_t n) {
     size_t sort_bytes = 0, scan_bytes = 0;
     rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
     (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, v, n, 0u, 32u);
+    const size_t own = own_sort_temp_bytes(n, 32);                         // radix_sort.hip; either implementation fits
+    sort_bytes = own > sort_bytes ? own : sort_bytes;
     auto in = rocprim::make_transform_iterator(static_cast<const uint32_t*>(nullptr), TouchedFromRec{nullptr});
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, in, static_cast<uint32_t*>(nullptr), 0u, n, rocprim::plus<uint32_t>());
     return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
@@ -35,6 +37,7 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
                           uint32_t n_visible, hipStream_t s) {
     selector = 0;
     if (n_visible == 0) return hipSuccess;
+    if (g_sort_implementation & 2) return own_sort_pairs_u32(temp, temp_bytes, keys, vals, selector, n_visible, 32, s);
     rocprim::double_buffer<uint32_t> k(keys[0], keys[1]), v(vals[0], vals[1]);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n_visible, 0u, 32u, s);
     if (e != hipSuccess) return e;
@@ -250,7 +253,8 @@ static size_t tile_sort_temp_bytes_t(uint32_t n, int end_bit) {
     rocprim::double_buffer<KeyT> k(nullptr, nullptr);
     rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
     (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, n, 0u, static_cast<unsigned>(end_bit));
-    return bytes;
+    const size_t own = own_sort_temp_bytes(n, end_bit);
+    return own > bytes ? own : bytes;
 }
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit) {
     return key_bytes == 2 ? tile_sort_temp_bytes_t<uint16_t>(n_instances, end_bit) : tile_sort_temp_bytes_t<uint32_t>(n_instances, end_bit);
@@ -270,6 +274,14 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* key
                          uint32_t n_instances, int end_bit, hipStream_t s) {
     selector = 0;
     if (n_instances == 0) return hipSuccess;
+    if (g_sort_implementation & 1) {
+        if (key_bytes == 2) {
+            uint16_t* k16[2] = {static_cast<uint16_t*>(keys[0]), static_cast<uint16_t*>(keys[1])};
+            return own_sort_pairs_u16(temp, temp_bytes, k16, vals, selector, n_instances, end_bit, s);
+        }
+        uint32_t* k32[2] = {static_cast<uint32_t*>(keys[0]), static_cast<uint32_t*>(keys[1])};
+        return own_sort_pairs_u32(temp, temp_bytes, k32, vals, selector, n_instances, end_bit, s);
+    }
     return key_bytes == 2 ? run_tile_sort_t<uint16_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s)
                           : run_tile_sort_t<uint32_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s);
 }

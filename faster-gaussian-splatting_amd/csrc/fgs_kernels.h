@@ -45,6 +45,12 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* key
                          uint32_t n_instances, int end_bit, hipStream_t s);
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, hipStream_t s);
 
+// radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
+extern int g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
+size_t own_sort_temp_bytes(uint32_t n, int end_bit);
+hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
+hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
+
 // K8+K9: inclusive scan of ceil(len/kBucket) per tile
 size_t bucket_scan_temp_bytes(uint32_t n_tiles);
 hipError_t run_bucket_scan(void* temp, size_t temp_bytes, const uint2* ranges, uint32_t* bucket_offsets, uint32_t n_tiles, hipStream_t s);

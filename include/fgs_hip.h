@@ -225,6 +225,12 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries);
  * tests/test_gpu_parity.py checks against the expected pattern. which == FGS_BUF_COUNT in fgs_blob_layout describes the
  * backward scratch buffer. */
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
+
+/* Test hook for the binning stage's radix sort (csrc/radix_sort.hip): stable sort of n (key, uint32 value) pairs on key bits
+ * [0, end_bit); key_bytes 2 or 4. Returns 0 / 1 = the buffer pair that holds the result, or a negative fgs_status. */
+size_t fgs_debug_radix_sort_temp_bytes(int32_t n, int32_t end_bit);
+int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, int32_t key_bytes, int32_t end_bit,
+                             void* temp, size_t temp_bytes, void* stream);
 /* Selects the blend-backward formulation: 0 = systolic (lane = Gaussian), 1 = strip (lane = pixel, default). A/B switch for
  * tests and bench; both must give the same gradients. */
 int32_t fgs_debug_set_backward_variant(int32_t variant);

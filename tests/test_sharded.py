@@ -76,7 +76,7 @@ def test_cut_pipeline_equals_whole_pipeline(n_shards):
         assert torch.allclose(dens[sh], info_ref[:, sh::n_shards], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize('n_views', [2, 3, 9])
+@pytest.mark.parametrize('n_views', [2, 9])
 def test_shard_backward_sums_over_views(n_views):
     """K12's in-register sum over the views of a launch (and the accumulate path across launches of 8 views, n_views = 9)."""
     params, settings, _ = _scene()
@@ -157,7 +157,7 @@ def test_sharded_world2_gloo(tmp_path):
     assert torch.equal(r[0]['counts'], r[1]['counts']) and int(r[0]['counts'][..., 0].sum()) > 0
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [3])
 def test_local_shard_group_matches_summed_gradient_reference(world):
     """G owners in one process (the twin that GPU tests and tools/sharded_emulation.py use): same update as the reference."""
     from harness.sharded import LocalShardGroup
@@ -184,11 +184,11 @@ def test_local_shard_group_matches_summed_gradient_reference(world):
 
 
 def test_fused_and_unfused_phase_c_agree():
-    """fgs_shard_backward_adam_fused == fgs_shard_backward + Adam (3 owners x 3 views, 2 steps; moments compared as well)."""
+    """fgs_shard_backward_adam_fused == fgs_shard_backward + Adam (2 owners x 2 views, 2 steps; moments compared as well)."""
     from harness.sharded import LocalShardGroup
     params, settings, targets = _scene()
-    views, tg = [settings[i % 2] for i in range(3)], [targets[i % 2] for i in range(3)]
-    groups = [LocalShardGroup(helpers.sim_backend(), params, LRS, 3, fused=f) for f in (True, False)]
+    views, tg = [settings[i % 2] for i in range(2)], [targets[i % 2] for i in range(2)]
+    groups = [LocalShardGroup(helpers.sim_backend(), params, LRS, 2, fused=f) for f in (True, False)]
     for grp in groups:
         for _ in range(2):
             grp.step(views, tg)
