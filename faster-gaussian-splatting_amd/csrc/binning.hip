@@ -2,7 +2,8 @@
 //   depth sort (32-bit keys) -> exclusive scan of tile counts in depth order -> instance creation (exact overlap)
 //   -> stable tile sort on end_bit bits -> per-tile [start,end) ranges -> inclusive scan of per-tile bucket counts.
 // Semantics: reference rasterization/src/forward.cu:104-231 + kernels_forward.cuh:211-360 (two-stage "Splatshop" sort,
-// no 64-bit tile|depth key). Sorts and scans use rocPRIM (the native AMD device primitives); the gather of K3
+// no 64-bit tile|depth key). The two sorts are radix_sort.hip (rocPRIM's onesweep stays selectable for A/B runs), the scans
+// use rocPRIM (the native AMD device primitives); the gather of K3
 // (apply_depth_ordering_cu) and the bucket-count kernel K8 are folded into the scans as transform iterators, so two
 // kernel launches and two V/T-sized round trips through HBM disappear.
 // Built with -ffp-contract=off (the exact-overlap test must agree bit-for-bit with the one in preprocess.hip).
