@@ -210,6 +210,12 @@ uint32_t* pinned_counters() {          // 16 bytes of pinned host memory per hos
     return p;
 }
 
+hipEvent_t counters_copied_event() {   // per host thread: marks the end of the counter copy so that later launches are not waited for
+    thread_local hipEvent_t e = nullptr;
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
 AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps) {   // adam.cu:52-54
     const double bc1_rcp = 1.0 / (1.0 - std::pow(beta1, step));
     const double bc2_sqrt_rcp = 1.0 / std::sqrt(1.0 - std::pow(beta2, step));
@@ -224,8 +230,8 @@ AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps
 enum ForwardMode { MODE_TRAINING, MODE_INFERENCE, MODE_SCORES };
 
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
-                 uint32_t n_instances, const fgs_settings* settings, float* image, int to_chw, int clamp_output, fgs_resize_fn resize,
-                 void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores);
+                 uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores);
 
 int run_forward(ForwardMode mode, const float* means, const float* scales, const float* rotations, const float* opacities,
                 const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
@@ -263,25 +269,33 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
-    // the one host read of the pass: V and I (fwd:99-102)
+    // the one host read of the pass: V and I (fwd:99-102). The depth sort does not need them on the host (radix_sort.hip reads
+    // the count on the device), so it is enqueued BEHIND the copy and runs while the host waits for the two words.
     uint32_t* host = pinned_counters();
-    if (!host) return fail(FGS_ERR_HIP, "hipHostMalloc for the counter read-back failed");
+    hipEvent_t ready = counters_copied_event();
+    if (!host || !ready) return fail(FGS_ERR_HIP, "pinned memory / event for the counter read-back unavailable");
     FGS_HIP(hipMemcpyAsync(host, pb.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    FGS_HIP(hipStreamSynchronize(stream));
+    FGS_HIP(hipEventRecord(ready, stream));
+    int depth_sel = -1;
+    if (n > 0 && depth_sort_takes_device_count()) {
+        StageScope t(ST_DEPTH_SORT, stream);
+        FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, stream));
+    }
+    FGS_HIP(hipEventSynchronize(ready));
     const uint32_t n_visible = host[0], n_instances = host[1];
 
-    return forward_tail(mode, pb, tb, geo, n_visible, n_instances, settings, image, to_chw, clamp_output, resize, user, state_out, stream, scores);
+    return forward_tail(mode, pb, tb, geo, n_visible, n_instances, depth_sel, settings, image, to_chw, clamp_output, resize, user, state_out, stream, scores);
 }
 
-// K2..K10 over a filled primitive buffer (rec, n_touched, unsorted depth keys + indices of the n_visible visible entries)
+// K2..K10 over a filled primitive buffer (rec, n_touched, depth keys + indices of the n_visible visible entries; depth_sel >= 0:
+// already depth-sorted, the sorted half is depth_sel)
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
-                 uint32_t n_instances, const fgs_settings* settings, float* image, int to_chw, int clamp_output, fgs_resize_fn resize,
-                 void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores) {
+                 uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores) {
     const bool training = mode == MODE_TRAINING;
     PrimitiveBuffers pb = pb_in;
     // K2-K4 (fwd:104-127)
-    int depth_sel = 0;
-    { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
+    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
     { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, stream)); }
 
@@ -552,7 +566,7 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
     FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
       FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, stream)); }
-    return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
+    return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
 int32_t fgs_backward_to_records(const float* grad_image, const float* image,

@@ -46,6 +46,12 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
     return hipSuccess;
 }
 
+bool depth_sort_takes_device_count() { return (g_sort_implementation & 2) != 0; }
+hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
+                                       uint32_t capacity, const uint32_t* n_visible_ptr, hipStream_t s) {
+    return own_sort_pairs_u32_device_count(temp, temp_bytes, keys, vals, selector, capacity, n_visible_ptr, 32, s);
+}
+
 hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
                             uint32_t n_visible, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;

@@ -33,6 +33,10 @@ hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s);
 size_t depth_sort_temp_bytes(uint32_t n);
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
                           uint32_t n_visible, hipStream_t s);
+// the same with the count still on the device (n_visible_ptr), `capacity` >= *n_visible_ptr; false if this build path needs the host count
+bool depth_sort_takes_device_count();
+hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
+                                       uint32_t capacity, const uint32_t* n_visible_ptr, hipStream_t s);
 hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
                             uint32_t n_visible, hipStream_t s);
 
@@ -50,6 +54,9 @@ extern int g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort u
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
+// the item count lives on the device (*n_ptr <= capacity): lets the depth sort start before the host has read the counters back
+hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
+                                           const uint32_t* n_ptr, int end_bit, hipStream_t s);
 
 // K8+K9: inclusive scan of ceil(len/kBucket) per tile
 size_t bucket_scan_temp_bytes(uint32_t n_tiles);

@@ -46,10 +46,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 }
 
 // per-workgroup digit histogram, written digit-major: hist[digit * n_blocks + block]
+// The item count comes by value or -- when the host does not know it yet -- through `n_ptr` (grid sized by a capacity, workgroups
+// beyond the count contribute zero rows and scatter nothing).
 template <typename KeyT>
-__global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const KeyT* __restrict__ keys, const uint32_t n, const int shift,
-                                                                       const int bits, uint32_t* __restrict__ hist, const uint32_t n_blocks) {
+__global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const KeyT* __restrict__ keys, const uint32_t n_value, const uint32_t* __restrict__ n_ptr,
+                                                                       const int shift, const int bits, uint32_t* __restrict__ hist, const uint32_t n_blocks) {
     __shared__ uint32_t s_hist[kMaxBins];
+    const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
     if (threadIdx.x < bins) s_hist[threadIdx.x] = 0u;
     __syncthreads();
@@ -102,9 +105,11 @@ __global__ void __launch_bounds__(kSortThreads) radix_row_scan_kernel(uint32_t* 
 template <typename KeyT>
 __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                     const uint32_t n, const int shift, const int bits,
-                                                                     const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals,
-                                                                     const uint32_t n_blocks) {
+                                                                     const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const int shift,
+                                                                     const int bits, const uint32_t* __restrict__ table,
+                                                                     const uint32_t* __restrict__ totals, const uint32_t n_blocks) {
+    const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
+    if (blockIdx.x * kSortBlockItems >= n) return;                  // workgroup-uniform (capacity-sized grid)
     __shared__ uint32_t s_cnt[kSortWaves][kMaxBins];              // per wave and digit: running count, later start inside the digit's run
     __shared__ uint32_t s_first[kMaxBins];                        // first workgroup-local position of each digit
     __shared__ uint32_t s_dst[kMaxBins];                          // global position of this workgroup's first item of each digit
@@ -195,8 +200,10 @@ SortPlan plan_sort(uint32_t n, int end_bit) {
     return p;
 }
 
+// `n` = item count, or with n_ptr != nullptr an upper bound of the count stored at n_ptr on the device
 template <typename KeyT>
-hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
+hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
+                      int end_bit, hipStream_t s) {
     selector = 0;
     if (n == 0) return hipSuccess;
     const SortPlan p = plan_sort(n, end_bit);
@@ -207,10 +214,10 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
     int shift = 0;
     for (int i = 0; i < p.n_passes; ++i) {
         const int bits = p.bits[i];
-        hipLaunchKernelGGL(radix_histogram_kernel<KeyT>, grid, block, 0, s, keys[selector], n, shift, bits, table, p.n_blocks);
+        hipLaunchKernelGGL(radix_histogram_kernel<KeyT>, grid, block, 0, s, keys[selector], n, n_ptr, shift, bits, table, p.n_blocks);
         hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), block, 0, s, table, totals, p.n_blocks);
         hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, grid, block, 0, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1],
-                           n, shift, bits, table, totals, p.n_blocks);
+                           n, n_ptr, shift, bits, table, totals, p.n_blocks);
         selector ^= 1;
         shift += bits;
     }
@@ -228,10 +235,14 @@ size_t own_sort_temp_bytes(uint32_t n, int end_bit) {
 }
 
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, n, end_bit, s);
+    return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, n, nullptr, end_bit, s);
 }
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint16_t>(temp, temp_bytes, keys, vals, selector, n, end_bit, s);
+    return sort_pairs<uint16_t>(temp, temp_bytes, keys, vals, selector, n, nullptr, end_bit, s);
+}
+hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
+                                           const uint32_t* n_ptr, int end_bit, hipStream_t s) {
+    return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, end_bit, s);
 }
 
 }  // namespace fgs
