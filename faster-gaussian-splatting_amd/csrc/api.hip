@@ -384,7 +384,7 @@ extern "C" {
 
 int32_t fgs_abi_version(void) { return FGS_ABI_VERSION; }
 const char* fgs_last_error(void) { return g_error; }
-const char* fgs_build_info(void) { return "libfgs_hip gfx950 wave64 tile16x12 bucket64 rocprim-sort"; }
+const char* fgs_build_info(void) { return "libfgs_hip gfx950 wave64 tile16x12 bucket64 radix-sort-v1"; }
 
 int32_t fgs_forward(const float* means, const float* scales, const float* rotations, const float* opacities,
                     const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
