@@ -1,4 +1,5 @@
-"""K11 on the records path vs the whole pipeline, per view, in one process (stage times from HIP events)."""
+"""K11 on the records path (sharded multi-GPU renderer) vs the whole pipeline, per view, in one process (HIP-event stage times).
+This comparison exposed the heavy-hitter line contention described in DESIGN.md section 6."""
 import sys, torch
 sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd', '/root/repo/tests']
 import bench
@@ -29,8 +30,7 @@ for vi, v in enumerate(views):
         be.backward_to_records(gl, res.image, res.buffers, S, res.state, 15)
         return res.state
     out = {}
-    for name, fn, lay in (('whole_p0', whole, 0), ('whole_p1', whole, 1), ('cut_p0', cut, 0), ('cut_p1', cut, 1)):
-        be.lib.fgs_debug_set_option(4, lay)
+    for name, fn in (('whole', whole), ('cut', cut)):
         for _ in range(2): st = fn()
         torch.cuda.synchronize(); be.profile_enable(True); be.profile_read()
         for _ in range(4): fn()
