@@ -6,7 +6,8 @@
 // decoupled look-back chain, 14 launches, 0.167 ms for 32 MB of traffic; the tile sort moves 16 M items at 1.7 TB/s (0.266 ms).
 // Here a pass is three launches over 4096-item workgroups -- per-workgroup digit histogram -> one workgroup per digit scans its
 // row of the [digit][workgroup] table -> stable scatter -- with ceil(end_bit / 8) passes of evenly split digit widths
-// (depth keys 4 x 8 bits, tile keys at 1080p 2 x 7 bits). Measured on MI355X (tools/ab_sort.py, S2): depth sort 0.135 ms,
+// (depth keys 4 x 8 bits, tile keys at 1080p 2 x 7 bits); 8 / 16 / 24 items per thread measured 0.193 / 0.181 / 0.188 ms for the tile
+// sort. Measured on MI355X (tools/ab_sort.py, S2): depth sort 0.135 ms,
 // tile sort 0.173 ms with rocPRIM's scan between the kernels; wider (11-bit) digits were slower: without the LDS reorder below,
 // 2 M x 2 scattered 4-byte stores per pass cost 55-72 us.
 //
