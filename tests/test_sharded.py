@@ -229,3 +229,24 @@ def test_sharded_world4_gloo_equals_local_group(tmp_path):
     ref = grp.gather_parameters()
     for k in ref:
         assert torch.equal(got[k], ref[k]), k
+
+
+@pytest.mark.parametrize('sh_bases', [1, 4])
+def test_sharded_step_with_fewer_sh_bands(sh_bases):
+    """SH degree 0 / 1 models through the sharded path (generic-R kernels, empty sh_rest): fused and unfused phase C agree."""
+    from harness.scenes import View, make_s0
+    from harness.sharded import LocalShardGroup
+    params, v0 = make_s0(seed=9, n=150, sh_bases=sh_bases)
+    views = []
+    for shift in (0.0, 0.4):
+        w2c = v0.w2c.clone()
+        w2c[0, 3] = shift
+        views.append(helpers.settings_pair(View(w2c, torch.tensor([-shift, 0.0, -4.0]), 48, 36, 48.0, 48.0, 24.0, 18.0, 0.2, 1e4, torch.zeros(3)),
+                                           active_sh_bases=sh_bases)[1])
+    targets = [torch.full((3, 36, 48), 0.4), torch.full((3, 36, 48), 0.6)]
+    groups = [LocalShardGroup(helpers.sim_backend(), params, LRS, 2, fused=f) for f in (True, False)]
+    for grp in groups:
+        grp.step(views, targets)
+    for a, b in zip(groups[0].ranks, groups[1].ranks):
+        assert torch.allclose(a.param_arena, b.param_arena, rtol=0, atol=1e-6)
+        assert torch.isfinite(a.param_arena).all()

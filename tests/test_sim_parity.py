@@ -196,3 +196,33 @@ def test_error_reporting(sim_backend):
         sim_backend.forward(*[params[k] for k in helpers.NAMES], bad)
     with pytest.raises(RuntimeError, match='contiguous float32'):
         sim_backend.forward(params['means'].double(), *[params[k] for k in helpers.NAMES[1:]], RS)
+
+
+@pytest.mark.parametrize('w,h,n', [(1, 1, 40), (7, 5, 3), (16, 12, 1), (31, 23, 65)])
+def test_degenerate_image_and_set_sizes(sim_backend, oracle, w, h, n):
+    """Images smaller than a tile, a single pixel, one Gaussian, one more than a wavefront."""
+    p, v = make_s0(seed=11, n=n)
+    p['means'][:, :2] *= 0.05                       # keep them in front of the tiny image
+    v = View(v.w2c, v.position, w, h, 20.0, 20.0, w / 2.0, h / 2.0, 0.2, 1e4, torch.tensor([0.3, 0.1, 0.6]))
+    _run(sim_backend, oracle, p, v)
+
+
+@pytest.mark.parametrize('sh_bases', [1, 4])
+def test_models_with_fewer_sh_bands(sim_backend, oracle, sh_bases):
+    """sh_coefficients_rest with 0 or 3 bases (SH degree 0 / 1 models): empty tensors, generic-R kernels, fused path."""
+    p, v = make_s0(seed=5, n=120, sh_bases=sh_bases)
+    v = View(v.w2c, v.position, 40, 30, 32.0, 32.0, 20.0, 15.0, 0.2, 1e4, torch.zeros(3))
+    res, f = _run(sim_backend, oracle, p, v, K=sh_bases)
+    _, RS = helpers.settings_pair(v, sh_bases)
+    order = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
+    P = [p[k].clone() for k in order]
+    M, V = [torch.zeros_like(t) for t in P], [torch.zeros_like(t) for t in P]
+    gi = torch.randn(3, 30, 40, generator=torch.Generator().manual_seed(1))
+    res2 = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    sim_backend.backward_adam_fused(None, gi, res2.image, P, M, V, res2.buffers, RS, res2.state, 1, [1e-3] * 6)
+    grads = sim_backend.backward(None, gi, res2.image, p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_rest'],
+                                 res2.buffers, RS, res2.state)
+    gmap = dict(zip(helpers.NAMES, grads))
+    for k, t, m in zip(order, P, M):                # first Adam step: m = (1 - beta1) * g
+        assert t.shape == p[k].shape
+        assert torch.allclose(m, 0.1 * gmap[k], rtol=1e-4, atol=1e-9), k
