@@ -17,7 +17,7 @@ def build(force: bool = False) -> Path:
     if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return OUT
     OUT.parent.mkdir(exist_ok=True)
-    cmd = ['g++', '-std=c++17', '-O1', '-g', '-fPIC', '-shared', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+    cmd = ['g++', '-std=c++17', '-O2', '-fPIC', '-shared', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
            '-Wno-unknown-pragmas', '-Wno-sign-compare', '-Wno-unused-variable', '-Wno-unused-but-set-variable',
            f'-I{SIM / "include"}', f'-I{CSRC}', f'-I{REPO / "include"}', '-o', str(OUT)]
     for s in srcs:

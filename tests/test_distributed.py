@@ -24,14 +24,14 @@ def _scene():
     _setup_paths()
     import helpers
     from harness.scenes import View, make_s0
-    params, v0 = make_s0(seed=5, n=300)
+    params, v0 = make_s0(seed=5, n=200)
     views = []
     for shift in (0.0, 0.6):
         w2c = v0.w2c.clone()
         w2c[0, 3] = shift
-        views.append(View(w2c, torch.tensor([-shift, 0.0, -4.0]), 64, 48, 64.0, 64.0, 32.0, 24.0, 0.2, 1e4, torch.zeros(3)))
+        views.append(View(w2c, torch.tensor([-shift, 0.0, -4.0]), 48, 36, 48.0, 48.0, 24.0, 18.0, 0.2, 1e4, torch.zeros(3)))
     settings = [helpers.settings_pair(v)[1] for v in views]
-    targets = [torch.full((3, 48, 64), 0.3 + 0.2 * i) for i in range(2)]
+    targets = [torch.full((3, 36, 48), 0.3 + 0.2 * i) for i in range(2)]
     return params, settings, targets
 
 
@@ -44,7 +44,7 @@ def _worker(rank, world, mode, port, out_dir):
         from harness.distributed import ViewParallelTrainer
         params, settings, targets = _scene()
         tr = ViewParallelTrainer(helpers.sim_backend(), params, LRS, mode=mode)
-        for _ in range(3):
+        for _ in range(2):
             tr.step(settings[rank], targets[rank])
         info = tr.gather_densification_info()
         torch.save({'params': {k: v.clone() for k, v in tr.params.items()}, 'info': info.clone()}, Path(out_dir) / f'{mode}_{rank}.pt')
@@ -59,8 +59,8 @@ def _single_process_reference():
     params, settings, targets = _scene()
     be = helpers.sim_backend()
     tr = ViewParallelTrainer(be, params, LRS)          # world 1: used for its arena / Adam plumbing only
-    info = torch.zeros(2, 300)
-    for _ in range(3):
+    info = torch.zeros(2, 200)
+    for _ in range(2):
         tr.step_count += 1
         total = torch.zeros_like(tr.grad_arena)
         for s, t in zip(settings, targets):

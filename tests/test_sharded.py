@@ -131,7 +131,7 @@ def _worker(rank, world, port, out_dir):
         from harness.sharded import ShardedTrainer, shard_of
         params, settings, targets = _scene()
         tr = ShardedTrainer(h.sim_backend(), shard_of(params, rank, world), LRS)
-        for _ in range(3):
+        for _ in range(2):
             tr.step(settings, targets[rank])
         full = tr.gather_parameters()
         torch.save({'shard': {k: v.clone() for k, v in tr.params.items()}, 'full': full, 'info': tr.densification_info.clone(),
