@@ -103,12 +103,15 @@ __global__ void __launch_bounds__(kSortThreads) radix_row_scan_kernel(uint32_t* 
 
 // table[d * n_blocks + blk] (after the row scan) + exclusive scan of totals[] over d = where this workgroup's first item with
 // digit d goes.
-template <typename KeyT>
+// BITS (the digit width) is a template parameter so that the match loop is straight-line code: as a run-time loop it cost
+// 8 VALU + 4 SALU + a branch per bit and round.
+template <typename KeyT, int BITS>
 __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                      const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const int shift,
-                                                                     const int bits, const uint32_t* __restrict__ table,
+                                                                     const uint32_t* __restrict__ table,
                                                                      const uint32_t* __restrict__ totals, const uint32_t n_blocks) {
+    constexpr int bits = BITS;
     const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     if (blockIdx.x * kSortBlockItems >= n) return;                  // workgroup-uniform (capacity-sized grid)
     __shared__ uint32_t s_cnt[kSortWaves][kMaxBins];              // per wave and digit: running count, later start inside the digit's run
@@ -143,9 +146,11 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         const bool valid = seg + r * kWave + lane < n;
         const uint32_t d = digit_of(key[r], shift, mask);
         uint64_t peers = wave_ballot(valid);                                           // lanes of this round holding the same digit
-        for (int b = 0; b < bits; ++b) {
-            const uint64_t set = wave_ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? set : ~set;
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool mine = (d & (1u << b)) != 0u;
+            const uint64_t set = wave_ballot(mine), clear = ~set;
+            peers &= mine ? set : clear;
         }
         const uint32_t before = s_cnt[wv][d];                                          // every lane reads before the leaders write
         rank[r] = before + lanes_below(peers);
@@ -201,6 +206,14 @@ SortPlan plan_sort(uint32_t n, int end_bit) {
     return p;
 }
 
+template <typename KeyT>
+void launch_scatter(int bits, dim3 grid, dim3 block, hipStream_t s, const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out,
+                    uint32_t n, const uint32_t* n_ptr, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks) {
+#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, shift, table, totals, n_blocks); break;
+    switch (bits) { FGS_SCATTER(1) FGS_SCATTER(2) FGS_SCATTER(3) FGS_SCATTER(4) FGS_SCATTER(5) FGS_SCATTER(6) FGS_SCATTER(7) default: FGS_SCATTER(8) }
+#undef FGS_SCATTER
+}
+
 // `n` = item count, or with n_ptr != nullptr an upper bound of the count stored at n_ptr on the device
 template <typename KeyT>
 hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
@@ -217,8 +230,8 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
         const int bits = p.bits[i];
         hipLaunchKernelGGL(radix_histogram_kernel<KeyT>, grid, block, 0, s, keys[selector], n, n_ptr, shift, bits, table, p.n_blocks);
         hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), block, 0, s, table, totals, p.n_blocks);
-        hipLaunchKernelGGL(radix_scatter_kernel<KeyT>, grid, block, 0, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1],
-                           n, n_ptr, shift, bits, table, totals, p.n_blocks);
+        launch_scatter<KeyT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, shift, table,
+                             totals, p.n_blocks);
         selector ^= 1;
         shift += bits;
     }
