@@ -56,6 +56,14 @@ def test_cut_pipeline_equals_whole_pipeline_s0(hip_backend, n_shards):
     _cut_vs_whole(helpers.poisoned(hip_backend), params, RS, n_shards, 1e-2)
 
 
+@pytest.mark.parametrize('K,aa', [(4, True), (9, False), (1, True)])
+def test_cut_pipeline_sh_degrees_and_antialiasing(hip_backend, K, aa):
+    """Proper antialiasing (opacity scaling in K1, its chain rule in K12) and lower active SH degrees through the records path."""
+    params, view = make_s0(seed=4, n=2500)
+    _, RS = helpers.settings_pair(view, K, aa, device=DEV)
+    _cut_vs_whole(helpers.poisoned(hip_backend), params, RS, 3, 1e-2)
+
+
 def test_cut_pipeline_with_huge_footprints(hip_backend):
     """Screen-filling Gaussians take K1's workgroup path and, on the sharded path, are spread through the record order by the
     pack kernel (they trade places with regular records): V, I, image and gradients must not notice."""
