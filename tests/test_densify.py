@@ -184,3 +184,37 @@ def test_importance_pruning_and_noise_hook():
     D.post_optimizer_step(g, True, 1.6e-4, ops=_sim_ops())             # Model.py:472-475: SGLD noise scaled by (1 - opacity) sigmoid gate
     moved = (g.means.detach() - before).abs().max()
     assert 0.0 < float(moved) < 5.0
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """Adam moments, step counts, learning rates and the SH degree survive save -> load: two more optimizer steps after a resume
+    equal two more steps of the uninterrupted run (FusedAdam replaced by the same update in torch for this CPU test)."""
+    from harness.checkpoint import load_checkpoint, save_checkpoint
+
+    def adam_steps(g, start, count):            # the FusedAdam update rule (adam.cu:22-33) on CPU tensors, deterministic "gradients"
+        for it in range(start, start + count):
+            g.update_learning_rate(it + 1)
+            for group in g.optimizer.param_groups:
+                p = group['params'][0]
+                grad = torch.sin(p.detach() * (it + 1))
+                st = g.optimizer.state.setdefault(p, {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)})
+                st['step'] += 1
+                st['exp_avg'].mul_(0.9).add_(grad, alpha=0.1)
+                st['exp_avg_sq'].mul_(0.999).addcmul_(grad, grad, value=0.001)
+                bc1, bc2 = 1 - 0.9 ** st['step'], 1 - 0.999 ** st['step']
+                p.data.addcdiv_(st['exp_avg'], (st['exp_avg_sq'] / bc2).sqrt() + 1e-15, value=-group['lr'] / bc1)
+
+    a = _gaussians(50)
+    a.optimizer.state.clear()
+    a.active_sh_degree = 2
+    adam_steps(a, 0, 3)
+    save_checkpoint(a, tmp_path / 'ckpt.pt', iteration=3)
+    b, it = load_checkpoint(tmp_path / 'ckpt.pt', 'cpu')
+    assert it == 3 and b.active_sh_degree == 2 and b.means.shape == a.means.shape
+    adam_steps(a, 3, 2)
+    adam_steps(b, 3, 2)
+    for k in PARAM_ORDER:
+        assert torch.equal(getattr(a, k).detach(), getattr(b, k).detach()), k
+    for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
+        sa, sb = a.optimizer.state[ga['params'][0]], b.optimizer.state[gb['params'][0]]
+        assert sa['step'] == sb['step'] == 5 and torch.equal(sa['exp_avg'], sb['exp_avg']) and ga['lr'] == gb['lr']
