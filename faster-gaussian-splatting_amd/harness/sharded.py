@@ -178,6 +178,48 @@ class ShardedTrainer:
     def set_learning_rates(self, lrs: dict) -> None:
         self.lrs.update(lrs)
 
+    # ---- maintenance of the shard (densification / pruning / re-ordering run on the owner, every ~100 steps) ---------------
+    def as_gaussians(self):
+        """The shard as a `harness.trainer.Gaussians` whose optimizer carries this trainer's Adam moments, so that
+        `harness.densify` (clone / split / prune / MCMC relocation / opacity reset / Morton sort) can be applied to it unchanged.
+        Every decision is per Gaussian and `densification_info` already holds the statistics of ALL views of the steps (the owner
+        accumulates them), so owners densify independently -- no collective; only MCMC's global cap needs the total count."""
+        from .trainer import Gaussians
+        g = Gaussians({k: self.params[k].clone() for k in SEGMENTS}, self.device)
+        g.training_setup(training_cameras_extent=1.0)
+        for group in g.optimizer.param_groups:
+            k = group['name']
+            o, n, shape = self.layout[k]
+            group['lr'] = self.lrs[k]
+            g.optimizer.state[group['params'][0]] = {'step': self.step_count, 'exp_avg': self.exp_avg[o:o + n].view(shape).clone(),
+                                                     'exp_avg_sq': self.exp_avg_sq[o:o + n].view(shape).clone()}
+        g.densification_info = self.densification_info.clone()
+        return g
+
+    def rebuild_from(self, g) -> None:
+        """Adopt a (densified / pruned / re-ordered) `Gaussians`: new arenas, moments taken from its optimizer state."""
+        new = {k: getattr(g, k).detach() for k in SEGMENTS}
+        state = {group['name']: g.optimizer.state.get(group['params'][0], {}) for group in g.optimizer.param_groups}
+        self.n = new['means'].shape[0]
+        self.layout, off = {}, 0
+        for k in SEGMENTS:
+            self.layout[k] = (off, new[k].numel(), tuple(new[k].shape))
+            off += (new[k].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        mk = lambda: torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq = mk(), mk(), mk(), mk()
+        self.params, self.grads = {}, {}
+        for k in SEGMENTS:
+            o, n, shape = self.layout[k]
+            self.params[k] = self.param_arena[o:o + n].view(shape)
+            self.params[k].copy_(new[k])
+            self.grads[k] = self.grad_arena[o:o + n].view(shape)
+            if 'exp_avg' in state[k]:
+                self.exp_avg[o:o + n].view(shape).copy_(state[k]['exp_avg'])
+                self.exp_avg_sq[o:o + n].view(shape).copy_(state[k]['exp_avg_sq'])
+        self.densification_info = g.densification_info.clone() if g.densification_info is not None and g.densification_info.shape[1] == self.n \
+            else torch.zeros((2, self.n), dtype=torch.float32, device=self.device)
+        self.records = torch.empty((self.records.shape[0], max(self.n, 1), _lib.SPLAT_RECORD_BYTES), dtype=torch.uint8, device=self.device)
+
 
 class LocalShardGroup:
     """All G shard owners of a step inside ONE process, exchanging through local copies instead of RCCL: the functional twin of

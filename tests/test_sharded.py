@@ -250,3 +250,30 @@ def test_sharded_step_with_fewer_sh_bands(sh_bases):
     for a, b in zip(groups[0].ranks, groups[1].ranks):
         assert torch.allclose(a.param_arena, b.param_arena, rtol=0, atol=1e-6)
         assert torch.isfinite(a.param_arena).all()
+
+
+def test_owner_side_densification_between_steps():
+    """Owners densify their shards independently (harness.densify on `as_gaussians()`), adopt the result (`rebuild_from`) and keep
+    training: sizes change per shard, Adam moments of the survivors are carried over, new Gaussians start from zero moments."""
+    from harness import densify as D
+    from harness.sharded import LocalShardGroup
+    params, settings, targets = _scene()
+    grp = LocalShardGroup(helpers.sim_backend(), params, LRS, 2)
+    grp.step(settings, targets)
+    sizes = []
+    for t in grp.ranks:
+        g = t.as_gaussians()
+        assert float(g.densification_info[0].max()) >= 1.0                     # the owner saw the statistics of both views
+        n0 = g.means.shape[0]
+        kept_moment = g.optimizer.state[g.means]['exp_avg'].clone()
+        stats = D.adaptive_density_control(g, 1e-7, 0.005, False, generator=torch.Generator().manual_seed(3))
+        assert stats['cloned'] + stats['split'] > 0
+        D.reset_densification_info(g)
+        t.rebuild_from(g)
+        sizes.append((n0, t.n))
+        assert t.params['means'].shape[0] == t.n == g.means.shape[0] and t.densification_info.shape == (2, t.n)
+        o, n, shape = t.layout['means']
+        assert torch.equal(t.exp_avg[o:o + n].view(shape), g.optimizer.state[g.means]['exp_avg']) and kept_moment.abs().max() > 0
+    assert any(a != b for a, b in sizes)
+    images = grp.step(settings, targets)                                        # the next step runs on the new shards
+    assert all(torch.isfinite(im).all() for im in images) and all(torch.isfinite(t.param_arena).all() for t in grp.ranks)
