@@ -1,37 +1,68 @@
-"""FusedAdam: torch.optim.Adam subclass whose step() runs the HIP Adam kernel (reference torch_bindings/adam.py:6-36).
+"""FusedAdam for the HIP backend.
 
-Same contract as the reference: exactly one tensor per param group, lazily created state (step / exp_avg / exp_avg_sq),
-groups whose grad is None are skipped. All groups that do step are updated by ONE kernel launch (fgs_adam_step_multi).
+Public contract = the reference's optimizer (torch_bindings/adam.py:6-36): a `torch.optim.Adam` subclass constructed as
+`FusedAdam(param_groups, lr, eps)`, ONE tensor per parameter group, moments created on first use, groups without a gradient
+left untouched, `state[param]` holding `step` (int) / `exp_avg` / `exp_avg_sq` so that NeRFICG-style optimizer surgery
+(extend / prune / sort of the moments) keeps working.
+
+What differs is the execution: the reference issues one `adam_step` launch per group (6 per iteration); here every group that
+has a gradient is collected first and the whole optimizer step is ONE `fgs_adam_step_multi` launch (up to 8 groups per launch).
 """
 from __future__ import annotations
+
+from typing import Iterator, NamedTuple
 
 import torch
 
 from ._backend import default_backend
+
+_GROUPS_PER_LAUNCH = 8          # AdamArgs::g[8] in csrc/fgs_kernels.h
+
+
+class _Update(NamedTuple):
+    grad: torch.Tensor
+    param: torch.Tensor
+    exp_avg: torch.Tensor
+    exp_avg_sq: torch.Tensor
+    step: int
+    lr: float
 
 
 class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr, eps) -> None:
         super().__init__(params=params, lr=lr, eps=eps)
 
+    def _moments(self, tensor: torch.Tensor) -> dict:
+        """Optimizer state of `tensor`, zero-initialised the first time it is stepped (adam.py:17-21 of the reference)."""
+        entry = self.state[tensor]
+        if not entry:
+            entry.update(step=0, exp_avg=torch.zeros_like(tensor), exp_avg_sq=torch.zeros_like(tensor))
+        return entry
+
+    def _pending(self) -> Iterator[tuple[tuple, _Update]]:
+        """(launch key, update) for every group that has something to do this step."""
+        for group in self.param_groups:
+            tensors = group['params']
+            if len(tensors) != 1:
+                raise ValueError(f'FusedAdam expects one tensor per parameter group, group {group.get("name", "?")} has {len(tensors)}')
+            tensor = tensors[0]
+            gradient = tensor.grad
+            if gradient is None or tensor.numel() == 0:
+                continue
+            moments = self._moments(tensor)
+            moments['step'] += 1
+            beta1, beta2 = group['betas']
+            yield (float(beta1), float(beta2), float(group['eps']), tensor.device), _Update(
+                gradient.contiguous(), tensor, moments['exp_avg'], moments['exp_avg_sq'], moments['step'], float(group['lr']))
+
     @torch.no_grad()
     def step(self) -> None:
-        batches: dict = {}
-        for group in self.param_groups:
-            assert len(group['params']) == 1, 'more than one tensor in group'
-            param = group['params'][0]
-            if param.grad is None or param.numel() == 0:
-                continue
-            state = self.state[param]
-            if len(state) == 0:
-                state['step'] = 0
-                state['exp_avg'] = torch.zeros_like(param)
-                state['exp_avg_sq'] = torch.zeros_like(param)
-            state['step'] += 1
-            key = (tuple(group['betas']), group['eps'], param.device)
-            batches.setdefault(key, []).append((param.grad if param.grad.is_contiguous() else param.grad.contiguous(), param,
-                                                state['exp_avg'], state['exp_avg_sq'], state['step'], group['lr']))
-        for (betas, eps, _device), items in batches.items():
-            for i in range(0, len(items), 8):
-                g, p, m, v, s, lr = zip(*items[i:i + 8])
-                default_backend().adam_step_multi(g, p, m, v, s, lr, betas[0], betas[1], eps)
+        launches: dict[tuple, list[_Update]] = {}
+        for key, update in self._pending():
+            launches.setdefault(key, []).append(update)
+        backend = default_backend()
+        for (beta1, beta2, eps, _device), updates in launches.items():
+            for first in range(0, len(updates), _GROUPS_PER_LAUNCH):
+                chunk = updates[first:first + _GROUPS_PER_LAUNCH]
+                backend.adam_step_multi([u.grad for u in chunk], [u.param for u in chunk], [u.exp_avg for u in chunk],
+                                        [u.exp_avg_sq for u in chunk], [u.step for u in chunk], [u.lr for u in chunk], beta1, beta2, eps)
