@@ -37,10 +37,10 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-stage timing with HIP events recorded on the caller's stream (fgs_profile_enable / fgs_profile_read) ----
 enum Stage { ST_PREPROCESS, ST_DEPTH_SORT, ST_OFFSETS_SCAN, ST_CREATE_INSTANCES, ST_TILE_SORT, ST_RANGES, ST_BUCKET_SCAN,
-             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_RECORDS, ST_COUNT };
+             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_RECORDS, ST_FUSED_BACKWARD_ADAM, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_scan", "create_instances", "tile_sort", "extract_ranges",
                                            "bucket_scan", "blend_forward", "stage_pixels", "blend_backward", "preprocess_backward",
-                                           "sh_rest_backward", "adam", "l1_dssim_loss", "shard_records"};
+                                           "sh_rest_backward", "adam", "l1_dssim_loss", "shard_records", "fused_backward_adam"};
 struct StageRecord { int stage; hipEvent_t start, stop; };
 struct Profiler {
     bool enabled = false;
@@ -119,6 +119,7 @@ struct PrimitiveBuffers {             // cf. bu:45-94
 };
 struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed are tile-major here
     uint2* ranges; uint32_t* bucket_offsets; uint32_t* max_n_processed; float* final_T; uint32_t* n_processed;
+    uint32_t* live_count;             // backward: number of live buckets (K11 planning pass)
     char* temp; size_t temp_bytes;
     static TileBuffers carve(Carver& c, uint32_t t, bool training) {
         TileBuffers b{};
@@ -130,6 +131,7 @@ struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed a
             b.n_processed = c.take<uint32_t>("n_processed", (size_t)t * kTilePixels);
             b.temp_bytes = bucket_scan_temp_bytes(t);
             b.temp = c.take<char>("scan_temp", b.temp_bytes);
+            b.live_count = c.take<uint32_t>("live_count", 4);
         }
         return b;
     }
@@ -146,11 +148,12 @@ struct InstanceBuffers {              // cf. bu:96-124
     }
 };
 struct BucketBuffers {                // cf. bu:154-163
-    uint32_t* tile_index; float4* ckpt;
+    uint32_t* tile_index; float4* ckpt; uint2* work_list;
     static BucketBuffers carve(Carver& c, uint32_t n) {
         BucketBuffers b;
         b.tile_index = c.take<uint32_t>("tile_index", n);
         b.ckpt = c.take<float4>("ckpt", (size_t)n * kTilePixels);
+        b.work_list = c.take<uint2>("work_list", n);        // backward: the live (tile, bucket) pairs
         return b;
     }
 };
@@ -166,6 +169,7 @@ struct BackwardScratch {
 };
 
 int g_seq_tiles = kSeqTiles;           // fgs_debug_set_option key 5
+int g_fused_single_kernel = 1;         // fgs_debug_set_option key 3: fgs_backward_adam_fused as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
@@ -369,6 +373,7 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
     a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
+    a.work_list = P.bb.work_list; a.live_count = P.tb.live_count;
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
@@ -481,16 +486,20 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
         a.p[k] = params[map[k]]; a.m[k] = exp_avgs[map[k]]; a.v[k] = exp_avg_sqs[map[k]];
         a.h[k] = adam_hyper(step, lrs[map[k]], beta1, beta2, eps);
     }
-    // The geometry kernel reads sh_rest (pre-update) and leaves the view direction for the SH-rest pass, which then
-    // updates sh_rest in place; means are updated by the geometry kernel after it has taken the direction.
-    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(true, a, stream)); }
-    if (settings->total_sh_bases_rest > 0) {
-        ShRestArgs s{};
-        s.n_views = 1; s.view[0] = sh_rest_view(a.view[0]);
-        s.p = params[2]; s.m = exp_avgs[2]; s.v = exp_avg_sqs[2]; s.h = adam_hyper(step, lrs[2], beta1, beta2, eps);
-        s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
-        { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(true, s, stream)); }
+    ShRestArgs sh{};
+    sh.n_views = 1; sh.view[0] = sh_rest_view(a.view[0]);
+    sh.p = params[2]; sh.m = exp_avgs[2]; sh.v = exp_avg_sqs[2]; sh.h = adam_hyper(step, lrs[2], beta1, beta2, eps);
+    sh.n = a.n; sh.total_sh_rest = settings->total_sh_bases_rest; sh.active_sh_bases = settings->active_sh_bases;
+    if (g_fused_single_kernel) {
+        // one kernel for all 59 floats: a wave gathers its Gaussians' sh_rest once, keeps the view direction in registers
+        StageScope t(ST_FUSED_BACKWARD_ADAM, stream);
+        FGS_HIP(launch_fused_backward_adam(a, sh, stream));
+        return FGS_OK;
     }
+    // Two-kernel form (round 1, kept for A/B): the geometry kernel reads sh_rest (pre-update) and leaves the view direction for
+    // the SH-rest pass, which then updates sh_rest in place; means are updated by the geometry kernel after it has taken the direction.
+    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(true, a, stream)); }
+    if (settings->total_sh_bases_rest > 0) { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(true, sh, stream)); }
     return FGS_OK;
 }
 
@@ -808,7 +817,7 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
 }
 
 int32_t fgs_debug_set_backward_variant(int32_t variant) {
-    if (variant < 0 || variant > 2) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip) or 2 (systolic, global dL/dC)");
+    if (variant < 0 || variant > 3) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC) or 3 (live list + compacted pixels)");
     fgs::g_backward_variant = variant;
     return FGS_OK;
 }
@@ -819,6 +828,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 1: if (value != 1 && value != 2 && value != 4) return fail(FGS_ERR_INVALID_ARGUMENT, "adam unroll must be 1, 2 or 4");
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
+        case 3: g_fused_single_kernel = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 5: if (value < 1 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 1..32");
                 g_seq_tiles = value; return FGS_OK;

@@ -292,8 +292,179 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
     }
 }
 
-int g_backward_variant = 2;   // 2 (default): systolic (lane = Gaussian), dL/dC prefetched from global memory (0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel: 0.85 ms, the 81
-                              // reduction instructions per (Gaussian, strip) pair outweigh the culled pairs); fgs_debug_set_backward_variant()
+// ---- variant 3 (default): work list of live buckets + compacted live pixels + two-value pipeline state -----------------
+// Three observations about the systolic form above (rocprofv3 PMC, round 1: VALU-issue bound, ~70 instructions per step):
+//  (1) 91 % of the launched buckets lie behind their tile's max_n_processed (kb:295) and exit after four dependent loads.
+//      A one-workgroup planning pass turns (ranges, max_n_processed) into a dense list of LIVE (tile, bucket) pairs and its
+//      length; the blend kernel walks that list (grid-stride), so no wave is ever launched for a dead bucket.
+//  (2) inside a live bucket only pixels whose last contributor lies at or behind the bucket's first Gaussian can receive
+//      anything (kb:412). The order in which pixels travel through the lanes is irrelevant, so staging COMPACTS the live
+//      pixels (ballot + prefix count) and the pipeline runs n_live_pixels + 63 steps instead of 255. Per pixel the LDS holds
+//      24 bytes: dL/dC (3 floats) + one packed word (x, y inside the tile and min(last - first Gaussian, 64) as three bytes,
+//      each converted by a single v_cvt_f32_ubyteN) read by lane l at slot step - l, and the injected state (8 bytes).
+//  (3) dL/dalpha only needs the remaining colour behind a Gaussian projected on the pixel's dL/dC (kb:434-436):
+//          dL/dalpha = T (c . g) - (S - g_w) / (1 - alpha),   S = (C_final - T_final bg - C_front) . g
+//      so the pixel state that shifts through the lanes is TWO scalars (T, S - g_w) instead of four, S is updated with one
+//      FMA, and the per-Gaussian sums that are linear in per-lane constants are factored out of the loop: the colour-clamp
+//      gate multiplies sum(w g) once at the end (kb:426-427), dL/dopacity = -2 sum(hh) / opacity because G = alpha / opacity
+//      (kb:438), and dL/dmean2d = 2 [a b; b c] (sum(hh dx), sum(hh dy)) (kb:449-453) with hh = -alpha/2 dL/dalpha.
+//      About 50 VALU instructions per step remain.
+__global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBackwardArgs a) {
+    __shared__ uint32_t s_wave_total[1024 / kWave];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const unsigned per = (a.n_tiles + 1023u) / 1024u;
+    const unsigned t0 = tid * per, t1 = min(t0 + per, a.n_tiles);
+    uint32_t mine = 0;
+    for (unsigned t = t0; t < t1; ++t) mine += (a.max_n_processed[t] + kBucket - 1) / kBucket;      // live buckets of tile t (kb:295)
+    const uint32_t before_in_wave = wave_exclusive_sum(mine);
+    if (lane == 63u) s_wave_total[wv] = before_in_wave + mine;
+    __syncthreads();
+    uint32_t base = before_in_wave;
+    for (unsigned w = 0; w < wv; ++w) base += s_wave_total[w];
+    for (unsigned t = t0; t < t1; ++t) {
+        const uint32_t nl = (a.max_n_processed[t] + kBucket - 1) / kBucket;
+        for (uint32_t k = 0; k < nl; ++k) a.work_list[base + k] = make_uint2(t, k);
+        base += nl;
+    }
+    if (tid == 1023u) *a.live_count = base;
+}
+
+__global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const BlendBackwardArgs a) {
+    const unsigned lane = threadIdx.x;
+    __shared__ float4 s_pix[kTilePixels + 1];          // dL/dC rgb + packed (x | y << 8 | rel_last << 16); slot n_px = dead sentinel
+    __shared__ float2 s_inj[kTilePixels + 1];          // T_ckpt, S - g_w: enters the pipeline at lane 0
+    const unsigned n_live = *a.live_count;
+    const float lane_f = static_cast<float>(lane);
+    for (unsigned item = blockIdx.x; item < n_live; item += gridDim.x) {            // wave-uniform
+        const uint2 work = a.work_list[item];
+        const unsigned tile = work.x, tb = work.y;
+        const uint2 range = a.ranges[tile];
+        const unsigned tile_n = range.y - range.x;
+        const unsigned bucket = (tile == 0 ? 0u : a.bucket_offsets[tile - 1]) + tb;
+        const unsigned first_gaussian = tb * kBucket;
+
+        // ---- stage the live pixels, compacted (kb:349-380) ----
+        unsigned n_px = 0;
+        {
+            const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
+            const float4* __restrict__ ck = a.ckpt + (size_t)bucket * kTilePixels;
+            float4 g[kTilePixels / kWave], cst[kTilePixels / kWave], k[kTilePixels / kWave];
+#pragma unroll
+            for (int c = 0; c < kTilePixels / kWave; ++c) {                        // all nine loads in flight together
+                const unsigned p = static_cast<unsigned>(c) * kWave + lane;
+                g[c] = pix[2 * p]; cst[c] = pix[2 * p + 1]; k[c] = ck[p];
+            }
+#pragma unroll
+            for (int c = 0; c < kTilePixels / kWave; ++c) {
+                const unsigned p = static_cast<unsigned>(c) * kWave + lane;
+                const unsigned last = __float_as_uint(cst[c].w);
+                // a pixel that finished before this bucket never wrote its checkpoint (kf:436) and receives nothing here
+                const bool live = last > first_gaussian;
+                const uint64_t m = wave_ballot(live);
+                if (live) {
+                    const unsigned slot = n_px + lanes_below(m);
+                    const unsigned rel = min(last - first_gaussian, static_cast<unsigned>(kBucket));
+                    const unsigned packed = (p & (kTileW - 1)) | ((p / kTileW) << 8) | (rel << 16);
+                    s_pix[slot] = make_float4(g[c].x, g[c].y, g[c].z, __uint_as_float(packed));
+                    const float S = (cst[c].x - k[c].x) * g[c].x + (cst[c].y - k[c].y) * g[c].y + (cst[c].z - k[c].z) * g[c].z;   // kb:371-374
+                    s_inj[slot] = make_float2(k[c].w, S - g[c].w);
+                }
+                n_px += static_cast<unsigned>(__popcll(m));
+            }
+            if (lane == 0) {
+                s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));   // rel_last 0: never contributes
+                s_inj[n_px] = make_float2(0.0f, 0.0f);
+            }
+        }
+
+        const unsigned tp = first_gaussian + lane;
+        const bool valid_prim = tp < tile_n;
+        uint32_t prim = 0;
+        float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, op = 0.0f;
+        float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+        if (valid_prim) {
+            prim = a.inst_prims[range.x + tp];
+            const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+            const float4 r0 = r[0], r1 = r[1];
+            const float raw2 = reinterpret_cast<const float*>(r + 2)[0];
+            mx = r0.x; my = r0.y; ca = r0.z; cb = r0.w; cc = r1.x; op = r1.y;
+            col0 = fmaxf(r1.z, 0.0f); col1 = fmaxf(r1.w, 0.0f); col2 = fmaxf(raw2, 0.0f);
+            f0 = r1.z >= 0.0f ? 1.0f : 0.0f; f1 = r1.w >= 0.0f ? 1.0f : 0.0f; f2 = raw2 >= 0.0f ? 1.0f : 0.0f;   // kb:313-318
+        }
+        const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f;
+        const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
+        wave_lds_fence();
+
+        float a_c0 = 0.0f, a_c1 = 0.0f, a_c2 = 0.0f;                 // sum w g_c               (kb:426-427 without the clamp gate)
+        float a_h = 0.0f, a_x = 0.0f, a_y = 0.0f;                     // sum hh, sum hh dx, sum hh dy
+        float a_xx = 0.0f, a_xy = 0.0f, a_yy = 0.0f;                  // sum hh dx^2, hh dx dy, hh dy^2   (kb:443-448)
+        float sT = 0.0f, sS = 0.0f;                                   // the pixel state travelling through the lanes
+        const bool lane0 = lane == 0;
+        uint64_t ever = 0;
+
+        // software-pipelined LDS reads, one step ahead; lane l reads slot clamp(step - l, 0, n_px) (n_px = the dead sentinel)
+        const int n_px_i = static_cast<int>(n_px);
+        float2 inj_next = s_inj[0];
+        int idx_next = -static_cast<int>(lane);                       // pixel slot of this lane in the NEXT step to execute
+        float4 pix_next = s_pix[idx_next < 0 ? n_px_i : idx_next];
+        const int n_steps = n_px_i + kWave - 1;
+#pragma unroll 2
+        for (int i = 0; i < n_steps; ++i) {
+            sT = wave_shift_up1(sT); sS = wave_shift_up1(sS);                                   // kb:383-393
+            const float2 inj = inj_next;
+            const float4 px = pix_next;
+            inj_next = s_inj[min(i + 1, n_px_i)];                                               // wave-uniform address: LDS broadcast
+            ++idx_next;
+            pix_next = s_pix[static_cast<unsigned>(idx_next) < n_px ? idx_next : n_px_i];      // negative / beyond the list -> sentinel
+            sT = lane0 ? inj.x : sT; sS = lane0 ? inj.y : sS;                                   // kb:401-410
+            const unsigned packed = __float_as_uint(px.w);
+            const float pxf = x0 + static_cast<float>(packed & 0xffu);
+            const float pyf = y0 + static_cast<float>((packed >> 8) & 0xffu);
+            const float rel = static_cast<float>((packed >> 16) & 0xffu);
+            const float dx = mx - pxf, dy = my - pyf;
+            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            const float alpha_raw = op * __expf(fminf(power, 0.0f));
+            const bool contrib = lane_f < rel && alpha_raw >= kMinAlphaThreshold;               // kb:412,419-421
+            const uint64_t contrib_mask = wave_ballot(contrib);
+            if (contrib_mask == 0) continue;                                                    // wave-uniform
+            ever |= contrib_mask;
+            const float alpha = contrib ? alpha_raw : 0.0f;
+            const float T = sT;
+            const float w = T * alpha;
+            a_c0 += w * px.x; a_c1 += w * px.y; a_c2 += w * px.z;
+            const float cg = col0 * px.x + col1 * px.y + col2 * px.z;
+            sS -= w * cg;                                                                        // kb:429 projected on dL/dC
+            const float oma = 1.0f - alpha;
+            const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+            const float dl_dalpha = T * cg - sS * oma_rcp;                                       // kb:434-436
+            const float hh = (-0.5f * alpha) * dl_dalpha;
+            const float t = hh * dx, u = hh * dy;
+            a_h += hh; a_x += t; a_y += u;
+            a_xx += t * dx; a_xy += t * dy; a_yy += u * dy;
+            sT = T * oma;
+        }
+
+        const bool silent = ((ever >> lane) & 1ull) == 0;
+        if (valid_prim && !silent) {                                                             // kb:459-470
+            const size_t n = a.n;
+            unsafeAtomicAdd(a.acc + prim, 2.0f * (ca * a_x + cb * a_y));
+            unsafeAtomicAdd(a.acc + n + prim, 2.0f * (cb * a_x + cc * a_y));
+            unsafeAtomicAdd(a.acc + 2 * n + prim, a_xx);
+            unsafeAtomicAdd(a.acc + 3 * n + prim, a_xy);
+            unsafeAtomicAdd(a.acc + 4 * n + prim, a_yy);
+            // dL/dopacity = sum G dL/dalpha with G = alpha / opacity; through the sigmoid unless proper antialiasing (kb:462-466)
+            unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op));
+            unsafeAtomicAdd(a.acc + 6 * n + prim, a_c0 * f0);
+            unsafeAtomicAdd(a.acc + 7 * n + prim, a_c1 * f1);
+            unsafeAtomicAdd(a.acc + 8 * n + prim, a_c2 * f2);
+        }
+        wave_lds_fence();                                  // the next item restages the LDS slices
+    }
+}
+
+int g_backward_variant = 3;   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
+                              // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
+                              // fgs_debug_set_backward_variant()
 
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
@@ -302,6 +473,14 @@ hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
 
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
     if (a.n_buckets_cap == 0) return hipSuccess;
+    if (g_backward_variant == 3) {
+        hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(1024), 0, s, a);
+        // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
+        // for the launch of a quarter of a million empty ones
+        const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;
+        hipLaunchKernelGGL(blend_backward_compact_kernel, dim3(blocks), dim3(kWave), 0, s, a);
+        return hipGetLastError();
+    }
     if (g_backward_variant == 1) {
         hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(a.n_buckets_cap), dim3(kTilePixels), 0, s, a);
         return hipGetLastError();

@@ -32,6 +32,7 @@ constexpr int kPreprocessBackwardBlock = 256;
 constexpr int kInstanceBlock = 256;
 constexpr int kBlendBlock = kTilePixels;       // 3 waves
 constexpr int kBackwardWavesPerBlock = 1;      // 1 bucket per 64-thread workgroup: inactive buckets free their slot at once
+constexpr unsigned kBackwardMaxBlocks = 1u << 16;   // K11 walks the live-bucket list with at most this many single-wave workgroups
 constexpr int kSplatRecordWords = 14;          // sharded path: PrimRec (12 words) + depth key + tile count = FGS_SPLAT_RECORD_BYTES / 4
 constexpr int kMaxBatchViews = 8;              // sharded path: views handled by one K1 / K12 launch (grid.y / in-kernel loop)
 constexpr int kAccRecordWords = 9;             // sharded path: the 9 pixel-space accumulators = FGS_ACC_RECORD_BYTES / 4

@@ -81,6 +81,7 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
     float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket, written by the planning pass
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
 };
@@ -117,6 +118,8 @@ struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload
     int accumulate;                       // unfused only: grad_sh_rest += (sharded path, view batches after the first)
 };
 hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s);
+// single-view fused backward + Adam over all 59 floats of every Gaussian in one kernel (a: fused-mode arguments, sh: the SH-rest group)
+hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s);
 
 struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
 struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };
@@ -154,7 +157,7 @@ hipError_t launch_add_noise(const float* raw_scales, const float* raw_rotations,
 
 extern int g_adam_nontemporal;                                  // 0 | 1
 extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
-extern int g_backward_variant;                                  // 0 systolic, 1 strip (blend_backward.hip)
+extern int g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 
 }  // namespace fgs

@@ -39,28 +39,20 @@ constexpr int kGroupOffset[5] = {0, 3, 6, 7, 10};
 // every gradient element written once) instead of one launch and one read-modify-write of the gradients per view.
 template <bool MULTI> __device__ __forceinline__ void sum_into(float& dst, const float v) { dst = MULTI ? dst + v : v; }
 
-template <bool FUSED, bool MULTI>
-__global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
-    const unsigned i = blockIdx.x * kPreprocessBackwardBlock + threadIdx.x;
-    if (i >= a.n) return;
+// Gradient of the 14 small floats of Gaussian i (group order means 3, sh0 3, opacity 1, scales 3, rotations 4), summed over the
+// views of the launch; zeros if no view sees it. st_p: the parameters already in registers (fused mode). KEEP_DIR: the unit view
+// direction and the colour gradient of the (single) view stay in registers for the caller instead of going through the
+// view_dir scratch array.
+template <bool FUSED, bool MULTI, bool KEEP_DIR>
+__device__ __forceinline__ bool gaussian_backward(const PreprocessBackwardArgs& a, const unsigned i, const float (&st_p)[14],
+                                                  float (&grad)[14], float (&dir)[3], float (&gcol_out)[3]) {
     const size_t n = a.n;
     float g_mean[3] = {0.0f, 0.0f, 0.0f}, g_scale[3] = {0.0f, 0.0f, 0.0f}, g_rot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float g_op[1] = {0.0f}, g_sh0[3] = {0.0f, 0.0f, 0.0f};
-    float st_p[14], st_m[14], st_v[14];
-    if (FUSED) {
-#pragma unroll
-        for (int grp = 0; grp < 5; ++grp)
-#pragma unroll
-            for (int k = 0; k < kGroupWidth[grp]; ++k) {
-                const size_t e = (size_t)i * kGroupWidth[grp] + k;
-                st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
-            }
-    }
-
     bool visible = false;
     float m[3] = {0.0f, 0.0f, 0.0f}, s[3] = {0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int n_views = MULTI ? a.n_views : 1;
-    const Camera cam0 = load_camera(a.view[0].cam);     // single view: requested before the visibility test, as are the moments above
+    const Camera cam0 = load_camera(a.view[0].cam);     // single view: requested before the visibility test, as are the moments
     for (int vw = 0; vw < n_views; ++vw) {
         const BackwardView& V = a.view[MULTI ? vw : 0];
         if (V.n_touched[i] == 0) continue;                                             // kb:45
@@ -79,6 +71,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         const float* const accp = MULTI ? V.acc + (size_t)V.slot[i] * kAccRecordWords : V.acc + i;
         const size_t es = MULTI ? 1 : n;
         const float gcol[3] = {accp[6 * es], accp[7 * es], accp[8 * es]};
+        if (KEEP_DIR) { gcol_out[0] = gcol[0]; gcol_out[1] = gcol[1]; gcol_out[2] = gcol[2]; }
 
         // ---- SH backward w.r.t. sh0 and the view direction (sh_utils.cuh:84-153) ----
 #pragma unroll
@@ -89,7 +82,8 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
             const float xr = m[0] - cam.pos[0], yr = m[1] - cam.pos[1], zr = m[2] - cam.pos[2];
             const float inv = 1.0f / sqrtf(xr * xr + yr * yr + zr * zr);
             const float x = xr * inv, y = yr * inv, z = zr * inv;
-            V.view_dir[3 * (size_t)i] = x; V.view_dir[3 * (size_t)i + 1] = y; V.view_dir[3 * (size_t)i + 2] = z;
+            if (KEEP_DIR) { dir[0] = x; dir[1] = y; dir[2] = z; }
+            else { V.view_dir[3 * (size_t)i] = x; V.view_dir[3 * (size_t)i + 1] = y; V.view_dir[3 * (size_t)i + 2] = z; }
             const float* k = a.sh_rest + (size_t)i * cam.total_sh_rest * 3;
             float gdx[3], gdy[3], gdz[3];
 #pragma unroll
@@ -200,14 +194,33 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
 #pragma unroll
         for (int k = 0; k < 4; ++k) sum_into<MULTI>(g_rot[k], d_rot[k]);
     }
-
-    // group order: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations. Every element is written (zeros if invisible).
-    float grad[14];
+    // group order: 0 means, 1 sh0, 2 opacities, 3 scales, 4 rotations
 #pragma unroll
     for (int k = 0; k < 3; ++k) { grad[0 + k] = g_mean[k]; grad[3 + k] = g_sh0[k]; grad[7 + k] = g_scale[k]; }
     grad[6] = g_op[0];
 #pragma unroll
     for (int k = 0; k < 4; ++k) grad[10 + k] = g_rot[k];
+    return visible;
+}
+
+template <bool FUSED, bool MULTI>
+__global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_kernel(const PreprocessBackwardArgs a) {
+    const unsigned i = blockIdx.x * kPreprocessBackwardBlock + threadIdx.x;
+    if (i >= a.n) return;
+    float st_p[14], st_m[14], st_v[14];
+    if (FUSED) {
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                const size_t e = (size_t)i * kGroupWidth[grp] + k;
+                st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
+            }
+    }
+    float grad[14], dir[3], gcol[3];
+    const bool visible = gaussian_backward<FUSED, MULTI, false>(a, i, st_p, grad, dir, gcol);
+
+    // Every element is written (zeros if invisible).
     float* const outs[5] = {a.grad_means, a.grad_sh0, a.grad_opacities, a.grad_scales, a.grad_rotations};
 #pragma unroll
     for (int grp = 0; grp < 5; ++grp)
@@ -223,6 +236,108 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
                 a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
             }
         }
+}
+
+// ---- single-GPU fused backward + Adam (BASELINE.json configs[3]): ONE kernel for all 59 floats of a Gaussian -----------
+// A wave owns 64 consecutive Gaussians. Phase A, one lane per Gaussian: the 14 small floats and their moments are requested,
+// the gradient of the Gaussian is formed (gaussian_backward, which also gathers the lane's 45 SH-rest coefficients for the
+// view-direction term -- the only read of that tensor from HBM), Adam is applied to the 14 floats, and the 45 SH-rest
+// gradient floats basis_k(dir) * dL/dcolour (sh_utils.cuh:90-111) go to the wave's private LDS slice, which then holds the
+// gradient of the wave's CONTIGUOUS 64 x R x 3 block of the [N, R, 3] tensors. Phase B streams that block of parameter /
+// exp_avg / exp_avg_sq as non-temporal 16-byte accesses (the parameter block was just gathered: L2 hits). Compared with the
+// two-kernel form of round 1 the SH-rest parameters are read from HBM once instead of twice, the view direction never
+// leaves registers, and the 15 basis values are evaluated once per Gaussian instead of once per (Gaussian, basis) pair.
+// Bytes per Gaussian: 59 x 24 (state in / out) + 36 + 4 (accumulators, tile count) [+ 16 densification] = 1456.
+constexpr int kFusedUnroll = 3;          // 16-byte pieces of each of the three streams in flight per lane
+template <int RT>
+__global__ void __launch_bounds__(256) fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) {
+    __shared__ __attribute__((aligned(16))) float s_grad[256 / kWave][kWave * 15 * 3];
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : sh.total_sh_rest;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * 256u + wv * kWave;            // first Gaussian of this wave
+    if (first >= a.n) return;                                         // wave-uniform
+    const uint32_t i = first + lane;
+    const bool in_range = i < a.n;
+    const uint32_t ic = in_range ? i : a.n - 1u;                      // out-of-range lanes shadow the last Gaussian (loads only)
+
+    float st_p[14], st_m[14], st_v[14];
+#pragma unroll
+    for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+        for (int k = 0; k < kGroupWidth[grp]; ++k) {
+            const size_t e = (size_t)ic * kGroupWidth[grp] + k;
+            st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
+        }
+    float grad[14], dir[3] = {0.0f, 0.0f, 0.0f}, gcol[3] = {0.0f, 0.0f, 0.0f};
+    bool visible = false;
+    if (in_range) {
+        visible = gaussian_backward<true, false, true>(a, i, st_p, grad, dir, gcol);
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                const size_t e = (size_t)i * kGroupWidth[grp] + k;
+                const int o = kGroupOffset[grp] + k;
+                adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
+                a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
+            }
+    }
+    if (R == 0) return;
+
+    // ---- the wave's SH-rest gradient block -> LDS (skipped when no lane of the wave is visible: the block is zero) ----
+    const bool any_visible = wave_ballot(visible) != 0;
+    float* const slice = s_grad[wv];
+    if (any_visible) {
+        float B[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) B[k] = 0.0f;                     // degrees above the active one keep a zero gradient
+        if (visible && sh.active_sh_bases > 1) sh_basis(dir[0], dir[1], dir[2], sh.active_sh_bases, B);
+        float* const mine = slice + lane * R * 3u;
+#pragma unroll
+        for (int k = 0; k < 15; ++k)
+            if (static_cast<uint32_t>(k) < R) { mine[3 * k] = B[k] * gcol[0]; mine[3 * k + 1] = B[k] * gcol[1]; mine[3 * k + 2] = B[k] * gcol[2]; }
+        wave_lds_fence();
+    }
+
+    // ---- phase B: Adam over the wave's contiguous block, 3 streams x kFusedUnroll pieces in flight per lane ----
+    const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;      // floats this wave owns
+    const size_t base = (size_t)first * R * 3u;                                        // 64 * R * 12 bytes per wave: 16-byte aligned
+    float* const P = sh.p + base; float* const M = sh.m + base; float* const V = sh.v + base;
+    for (uint32_t e0 = 4u * lane; e0 < count; e0 += 4u * kWave * kFusedUnroll) {
+        float4 p4[kFusedUnroll], m4[kFusedUnroll], v4[kFusedUnroll];
+        bool full[kFusedUnroll];
+#pragma unroll
+        for (int u = 0; u < kFusedUnroll; ++u) {
+            const uint32_t e = e0 + 4u * kWave * static_cast<uint32_t>(u);
+            full[u] = e + 4u <= count;
+            if (full[u]) { p4[u] = load_float4_nt(P + e); m4[u] = load_float4_nt(M + e); v4[u] = load_float4_nt(V + e); }
+        }
+#pragma unroll
+        for (int u = 0; u < kFusedUnroll; ++u) {
+            const uint32_t e = e0 + 4u * kWave * static_cast<uint32_t>(u);
+            if (full[u]) {
+                const float4 g = any_visible ? *reinterpret_cast<const float4*>(slice + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                adam_update(p4[u].x, m4[u].x, v4[u].x, g.x, sh.h); adam_update(p4[u].y, m4[u].y, v4[u].y, g.y, sh.h);
+                adam_update(p4[u].z, m4[u].z, v4[u].z, g.z, sh.h); adam_update(p4[u].w, m4[u].w, v4[u].w, g.w, sh.h);
+                store_float4_nt(P + e, p4[u]); store_float4_nt(M + e, m4[u]); store_float4_nt(V + e, v4[u]);
+            } else if (e < count) {                                                    // ragged tail of the last wave: < 4 floats
+                for (uint32_t j = e; j < count; ++j) {
+                    float pp = P[j], mm = M[j], vv = V[j];
+                    adam_update(pp, mm, vv, any_visible ? slice[j] : 0.0f, sh.h);
+                    P[j] = pp; M[j] = mm; V[j] = vv;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
+    const dim3 grid((a.n + 255u) / 256u), block(256);
+    if (sh.total_sh_rest == 15) hipLaunchKernelGGL(fused_backward_adam_kernel<15>, grid, block, 0, s, a, sh);
+    else hipLaunchKernelGGL(fused_backward_adam_kernel<0>, grid, block, 0, s, a, sh);
+    return hipGetLastError();
 }
 
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s) {

@@ -582,6 +582,60 @@ void orc_blend_backward(int N, int n_buckets_total, int bucket_size,
     free(acc);
 }
 
+/*
+ * TEST SUPPORT (no reference counterpart): which outputs sit next to one of the blend's two hard thresholds?
+ * The blend passes decide `alpha >= 1/255` (kf:467, kb:421) and `T < 1e-4` (kf:477) on floats; an implementation whose exp /
+ * FMA contraction differs from this restatement by a few ULP can land on the other side for a (pixel, Gaussian) pair whose
+ * value lies within `eps` (relative) of the threshold, which moves that pixel by up to ~1/255 and that Gaussian's gradient by
+ * one pixel's contribution. Parity tests exclude exactly those entries (and count them) and hold everything else to 1e-4.
+ *   risk_pixel[P] : the pixel has a pair (any Gaussian in front of its last contributor, kb:412) within eps of the alpha
+ *                   threshold, or its transmittance passes within eps_T of the termination threshold
+ *   risk_prim[N]  : the Gaussian is the partner in such an alpha pair
+ *   near_prim[N]  : the Gaussian blends into a risky pixel (second-order: its gradient sees that pixel's changed T / colour)
+ */
+void orc_threshold_risk(const uint* ranges, const uint* inst_prims, const uint16_t* screen_bounds, const float* mean2d,
+                        const float* conic_opacity, const orc_settings* S, const uint* n_processed, float eps, float eps_T,
+                        uint8_t* risk_pixel, uint8_t* risk_prim, uint8_t* near_prim) {
+    const int W = S->width, H = S->height;
+    const int grid_w = (W + TILE_W - 1) / TILE_W, grid_h = (H + TILE_H - 1) / TILE_H;
+    const int T = grid_w * grid_h;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < T; tile++) {
+        const int tyi = tile / grid_w, txi = tile % grid_w;
+        const uint r0 = ranges[2 * tile];
+        for (int local = 0; local < BLOCK_BLEND; local++) {
+            const int px = txi * TILE_W + local % TILE_W, py = tyi * TILE_H + local / TILE_W;
+            if (px >= W || py >= H) continue;
+            const size_t pix = (size_t)W * py + px;
+            const int sx0 = txi * TILE_W + ((local % TILE_W) / SUBTILE_W) * SUBTILE_W;
+            const int sy0 = tyi * TILE_H + ((local / TILE_W) / SUBTILE_H) * SUBTILE_H;
+            const int sx1 = sx0 + SUBTILE_W, sy1 = sy0 + SUBTILE_H;
+            const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+            const int last = (int)n_processed[pix];
+            float Tr = 1.0f;
+            int risky = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1 && !risky) break;
+                for (int j = 0; j < last; j++) {
+                    const uint p = inst_prims[r0 + j];
+                    const float* co = conic_opacity + 4 * (size_t)p;
+                    const float dx = mean2d[2 * (size_t)p] - pxf, dy = mean2d[2 * (size_t)p + 1] - pyf;
+                    const float expo = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const float alpha = co[3] * expf(fminf(expo, 0.0f));
+                    if (pass == 1) { if (alpha >= MIN_ALPHA_THRESHOLD * (1.0f - eps)) near_prim[p] = 1; continue; }
+                    if (fabsf(alpha * MIN_ALPHA_THRESHOLD_RCP - 1.0f) < eps) { risky = 1; risk_prim[p] = 1; }
+                    const uint16_t* sb = screen_bounds + 4 * (size_t)p;
+                    if (!(sb[0] < sx1 && sx0 < sb[1] && sb[2] < sy1 && sy0 < sb[3])) continue;
+                    if (alpha < MIN_ALPHA_THRESHOLD) continue;
+                    Tr *= 1.0f - alpha;
+                    if (fabsf(Tr / TRANSMITTANCE_THRESHOLD - 1.0f) < eps_T) risky = 1;
+                }
+                if (risky) risk_pixel[pix] = 1;
+            }
+        }
+    }
+}
+
 /* sh:71-155 ; returns dcolor/dposition contribution, overwrites grad_sh0 with C0*g and writes grad_sh_rest */
 static void sh_to_color_backward(const float* sh_rest, float* grad_sh0, float* grad_sh_rest, const float pos[3],
                                  const float cam[3], uint idx, uint active, uint total_rest, float dpos[3]) {

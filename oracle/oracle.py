@@ -214,6 +214,21 @@ def backward(fwd: dict, settings: Settings, grad_image, densification_info: np.n
     return g
 
 
+def threshold_risk(fwd: dict, settings: Settings, eps: float = 1e-5, eps_T: float = 1e-4) -> dict:
+    """Test support (fgs_oracle.c: orc_threshold_risk): boolean masks of the pixels / Gaussians whose blend decisions lie within
+    `eps` (relative) of the alpha >= 1/255 threshold (or within eps_T of the T < 1e-4 termination), plus the Gaussians that
+    blend into such a pixel. Parity tests exclude and count exactly these entries."""
+    W, H, N = settings.width, settings.height, fwd['N']
+    risk_pixel = np.zeros(W * H, np.uint8)
+    risk_prim = np.zeros(max(N, 1), np.uint8)
+    near_prim = np.zeros(max(N, 1), np.uint8)
+    inst_prims = np.ascontiguousarray(fwd['inst_prims']) if fwd['I'] > 0 else np.zeros(1, np.uint32)
+    lib().orc_threshold_risk(_p(fwd['ranges']), _p(inst_prims), _p(fwd['screen_bounds']), _p(fwd['mean2d']), _p(fwd['conic_opacity']),
+                             C.byref(fwd['_S']), _p(fwd['n_processed']), C.c_float(eps), C.c_float(eps_T),
+                             _p(risk_pixel), _p(risk_prim), _p(near_prim))
+    return {'pixel': risk_pixel.reshape(H, W).astype(bool), 'prim': risk_prim[:N].astype(bool), 'near': near_prim[:N].astype(bool)}
+
+
 def adam_step(grad: np.ndarray, param: np.ndarray, exp_avg: np.ndarray, exp_avg_sq: np.ndarray, step: int, lr: float,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15) -> None:
     """In-place Adam update (adam.cu:10-71)."""

@@ -170,3 +170,51 @@ def poisoned(be):
             t.fill_(255)
             return t
     return Poisoned(be.lib)
+
+
+# ---- flip-aware parity ("what's weak" 3): count and exclude exactly the entries that sit on a hard threshold ------
+def flip_masks(oracle, f, S, dec=None, eps=1e-5):
+    """Masks of the outputs that an ULP-level difference in exp / FMA contraction can legitimately move by more than 1e-4:
+    pixels and Gaussians with a (pixel, Gaussian) pair within `eps` of the alpha >= 1/255 test or a transmittance within 1e-4 of
+    the termination test (oracle.threshold_risk), plus -- if the decoded HIP intermediates are given -- Gaussians whose integer
+    screen bounds / tile count differ (a floor / ceil / cull input within an ULP of its threshold in preprocess)."""
+    r = oracle.threshold_risk(f, S, eps)
+    prim = r['prim'].copy()
+    if dec is not None:
+        vis = (f['n_touched'] > 0) | (dec['n_touched'] > 0)
+        prim |= vis & ((dec['n_touched'] != f['n_touched']) | (dec['screen_bounds'] != f['screen_bounds']).any(axis=1))
+    return {'pixel': r['pixel'], 'prim': prim, 'near': r['near'] & ~prim}
+
+
+def masked_rel_inf(a, ref, keep):
+    """rel_inf over the rows selected by the boolean `keep` (first axis), normalised by max |ref| over ALL rows."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    if not keep.any():
+        return 0.0
+    return float(np.abs(a[keep] - ref[keep]).max() / (np.abs(ref).max() + 1e-30))
+
+
+def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label=''):
+    """image [3,H,W]; grads / g_ref: {name: array with the Gaussian index first}. Entries outside the masks must agree to `tol`
+    (max-abs error relative to the tensor's max-abs value); the masked fraction is bounded; masked entries stay within `loose`."""
+    report = {}
+    pm = masks['pixel']
+    frac_p, frac_g = float(pm.mean()), float(masks['prim'].mean()) if masks['prim'].size else 0.0
+    report['masked_pixels'], report['masked_gaussians'] = frac_p, frac_g
+    assert frac_p < max_masked and frac_g < max_masked, (label, 'masked fraction', frac_p, frac_g)
+    if image is not None:
+        err = np.abs(np.asarray(image, np.float64) - f_image).max(axis=0)
+        scale = max(1.0, float(np.abs(f_image).max()))
+        report['image'] = float(err[~pm].max() / scale) if (~pm).any() else 0.0
+        report['image_masked'] = float(err[pm].max() / scale) if pm.any() else 0.0
+        assert report['image'] < tol, (label, 'image', report)
+        assert report['image_masked'] < loose, (label, 'image (masked pixels)', report)
+    keep = ~masks['prim']
+    for k, a in grads.items():
+        ref = g_ref[k]
+        a = np.asarray(a).reshape(ref.shape)
+        report[k] = masked_rel_inf(a, ref, keep)
+        report[k + '_masked'] = masked_rel_inf(a, ref, masks['prim'])
+        assert report[k] < tol, (label, k, report)
+        assert report[k + '_masked'] < loose, (label, k + ' (masked Gaussians)', report)
+    return report

@@ -31,6 +31,7 @@ struct float4 { float x, y, z, w; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 namespace sim {

@@ -92,7 +92,7 @@ def test_strip_backward_variant(sim_backend, oracle):
         p['means'][:, :2] *= 0.3
         _run(sim_backend, oracle, p, v)
     finally:
-        sim_backend.lib.fgs_debug_set_backward_variant(2)
+        sim_backend.lib.fgs_debug_set_backward_variant(3)
 
 
 def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
@@ -103,12 +103,12 @@ def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
     p['opacities'] -= 2.5
     p['means'][:50, 2] = -10.0                      # invisible primitives: their records stay poisoned
     be = helpers.poisoned(sim_backend)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             _run(be, oracle, p, v)
         finally:
-            be.lib.fgs_debug_set_backward_variant(2)
+            be.lib.fgs_debug_set_backward_variant(3)
 
 
 def test_empty_and_fully_culled(sim_backend, oracle):

@@ -7,7 +7,7 @@ from FasterGSCudaBackend._backend import default_backend
 be = default_backend(); dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
 g = T.Gaussians(make_garden_like(n), dev)
-variants = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '0,1,2'.split(','))]
+variants = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '2,3'.split(','))]
 res = {v: [] for v in variants}
 views = [v.to(dev) for v in orbit_views(8)]
 for rnd in range(6):
@@ -23,5 +23,5 @@ for rnd in range(6):
         for _ in range(3): be.backward(*args)
         torch.cuda.synchronize(); t, c = be.profile_read()['blend_backward']; be.profile_enable(False)
         res[var].append(t / c)
-be.lib.fgs_debug_set_backward_variant(2)
+be.lib.fgs_debug_set_backward_variant(3)
 for var in variants: print('variant', var, 'median ms', round(statistics.median(res[var]), 4), 'min', round(min(res[var]), 4), 'max', round(max(res[var]), 4))

@@ -9,7 +9,7 @@ sys.argv = ['bench.py']
 params, views, _ = bench.build_scene(bench.parse())
 dev = torch.device('cuda:0'); be = default_backend()
 import itertools
-for off, variant in itertools.product((0.0, -1.5, -3.0), (2, 1)):
+for off, variant in itertools.product((0.0, -1.5, -3.0), (3, 2)):
     be.lib.fgs_debug_set_backward_variant(variant)
     p = {k: v.clone() for k, v in params.items()}; p['opacities'] = p['opacities'] + off
     g = T.Gaussians(p, dev); g.training_setup(training_cameras_extent=5.0)
