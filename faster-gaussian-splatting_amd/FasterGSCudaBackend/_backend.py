@@ -45,7 +45,14 @@ def _ptr(t: torch.Tensor | None) -> int | None:
 
 
 def _stream_of(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+    """The caller's current stream on the tensors' device. The library launches on the CURRENT device (it never switches
+    devices), so a mismatch is reported here instead of surfacing as an opaque HIP error later."""
+    if device.type != 'cuda':
+        return 0
+    if device.index is not None and device.index != torch.cuda.current_device():
+        raise RuntimeError(f'tensors live on {device} but the current device is cuda:{torch.cuda.current_device()}; '
+                           f'call under torch.cuda.device({device.index})')
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class Backend:

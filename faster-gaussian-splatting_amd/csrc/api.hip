@@ -208,16 +208,18 @@ int check_settings(const fgs_settings* s) {
     return FGS_OK;
 }
 
-uint32_t* pinned_counters() {          // 16 bytes of pinned host memory per host thread for the one D2H read
-    thread_local uint32_t* p = nullptr;
-    if (!p && hipHostMalloc(reinterpret_cast<void**>(&p), 16, hipHostMallocDefault) != hipSuccess) p = nullptr;
-    return p;
-}
-
-hipEvent_t counters_copied_event() {   // per host thread: marks the end of the counter copy so that later launches are not waited for
-    thread_local hipEvent_t e = nullptr;
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    return e;
+// The one D2H read of a forward pass goes through 16 bytes of pinned host memory and an event; both belong to the device that
+// was current when they were created, so they are kept per (host thread, device) -- a thread driving two GPUs gets two sets.
+constexpr int kMaxDevices = 64;
+struct CounterReadback { uint32_t* host = nullptr; hipEvent_t ready = nullptr; };
+CounterReadback* counter_readback() {
+    thread_local CounterReadback slots[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    CounterReadback& c = slots[dev];
+    if (!c.host && hipHostMalloc(reinterpret_cast<void**>(&c.host), 16, hipHostMallocDefault) != hipSuccess) c.host = nullptr;
+    if (!c.ready && hipEventCreateWithFlags(&c.ready, hipEventDisableTiming) != hipSuccess) c.ready = nullptr;
+    return (c.host && c.ready) ? &c : nullptr;
 }
 
 AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps) {   // adam.cu:52-54
@@ -275,9 +277,10 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
 
     // the one host read of the pass: V and I (fwd:99-102). The depth sort does not need them on the host (radix_sort.hip reads
     // the count on the device), so it is enqueued BEHIND the copy and runs while the host waits for the two words.
-    uint32_t* host = pinned_counters();
-    hipEvent_t ready = counters_copied_event();
-    if (!host || !ready) return fail(FGS_ERR_HIP, "pinned memory / event for the counter read-back unavailable");
+    CounterReadback* rb = counter_readback();
+    if (!rb) return fail(FGS_ERR_HIP, "pinned memory / event for the counter read-back unavailable on the current device");
+    uint32_t* host = rb->host;
+    hipEvent_t ready = rb->ready;
     FGS_HIP(hipMemcpyAsync(host, pb.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     FGS_HIP(hipEventRecord(ready, stream));
     int depth_sel = -1;

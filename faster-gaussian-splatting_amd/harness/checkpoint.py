@@ -27,12 +27,12 @@ def save_checkpoint(g: Gaussians, path, iteration: int = 0) -> None:
 
 
 def load_checkpoint(path, device) -> tuple[Gaussians, int]:
-    state = torch.load(path, map_location='cpu', weights_only=False)
+    state = torch.load(path, map_location='cpu', weights_only=True)      # tensors + plain containers only: never unpickle arbitrary objects
     if state.get('format') != 'fgs-checkpoint-1':
         raise ValueError(f'{path} is not an fgs checkpoint')
     g = Gaussians(state['params'], device, max_sh_degree=state['max_sh_degree'], active_sh_degree=state['active_sh_degree'])
-    if state['densification_info'] is not None:
-        g.densification_info = state['densification_info'].to(device)
+    # None = the state after the last densification iteration (Trainer.py:120-145): the constructor's zeros must not come back
+    g.densification_info = None if state['densification_info'] is None else state['densification_info'].to(device)
     if state['optimizer'] is not None:
         g.training_setup(training_cameras_extent=state['extent'], lr=state['lr'])
         for group in g.optimizer.param_groups:

@@ -134,10 +134,13 @@ class ViewParallelTrainer:
         return image
 
     def gather_densification_info(self) -> torch.Tensor:
-        """Sum of the per-rank statistics; every rank then takes identical densify / prune decisions (Model.py:312-366)."""
+        """Sum of the per-rank statistics; every rank then takes identical densify / prune decisions (Model.py:312-366).
+        Returns a NEW tensor: the local accumulator keeps only this rank's statistics, so calling this twice before a reset
+        does not count earlier steps G times."""
+        total = self.densification_info.clone()
         if self.world > 1:
-            dist.all_reduce(self.densification_info, group=self.group)
-        return self.densification_info
+            dist.all_reduce(total, group=self.group)
+        return total
 
     def set_learning_rates(self, lrs: dict) -> None:
         self.lrs.update(lrs)

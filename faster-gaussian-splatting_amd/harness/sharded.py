@@ -40,10 +40,29 @@ def shard_of(params: dict, rank: int, world: int) -> dict:
     return {k: v[rank::world].contiguous() for k, v in params.items()}
 
 
+def _merge_shards(parts: Sequence[torch.Tensor], strided: bool) -> torch.Tensor:
+    """Shards back into one tensor. While every shard is still the strided slice it was created from (rank r holds rows
+    r, r+G, ...) the rows are interleaved back into the global order; once any owner has densified / pruned / re-ordered its
+    shard (`rebuild_from`) there is no global order left to restore and the shards are concatenated in rank order (callers that
+    want locality Morton-sort the result)."""
+    world, total = len(parts), sum(int(p.shape[0]) for p in parts)
+    if strided and all(int(p.shape[0]) == len(range(s, total, world)) for s, p in enumerate(parts)):
+        full = torch.empty((total,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+        for s, p in enumerate(parts):
+            full[s::world] = p
+        return full
+    return torch.cat(list(parts), dim=0)
+
+
 class ShardedTrainer:
     def __init__(self, backend: Backend, shard_params: dict, lrs: dict, *, group=None, betas=(0.9, 0.999), eps: float = 1e-15,
-                 loss: str = 'l1_dssim', fused: bool = True) -> None:
+                 loss: str = 'l1_dssim', fused: bool = True, extent: float = 1.0, lr_config: dict | None = None,
+                 max_sh_degree: int | None = None) -> None:
         assert loss in ('l1', 'l1_dssim')
+        # what owner-side maintenance (as_gaussians -> harness.densify) needs to decide exactly like the single-GPU model:
+        # the training cameras' extent (Model.py:312-366: percent_dense * extent, prune-large threshold), the learning-rate
+        # configuration and the SH degree cap
+        self.extent, self.lr_config, self.max_sh_degree = float(extent), lr_config, max_sh_degree
         self.be, self.group, self.betas, self.eps, self.loss = backend, group, betas, eps, loss
         self.fused = fused            # phase C as ONE fused K12 + Adam pass (gradients never materialised) when the batch has <= 8 views
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -69,6 +88,7 @@ class ShardedTrainer:
             self.grads[k] = self.grad_arena[o:o + n].view(shape)
         self.lrs = dict(lrs)
         self.step_count = 0
+        self.strided = True           # still the slice rank::world of the scene it was created from (until rebuild_from)
         self.densification_info = torch.zeros((2, self.n), dtype=torch.float32, device=device)
         # send side of exchange #1: the shard's records for each view of the step, and their (V, I) counts
         self.records = torch.empty((self.world, max(self.n, 1), _lib.SPLAT_RECORD_BYTES), dtype=torch.uint8, device=device)
@@ -160,19 +180,17 @@ class ShardedTrainer:
         out = {}
         for k in SEGMENTS:
             mine = self.params[k]
-            sizes = torch.tensor([mine.shape[0]], dtype=torch.int64, device=self.device)
+            sizes = torch.tensor([mine.shape[0], int(self.strided)], dtype=torch.int64, device=self.device)
             all_sizes = [torch.empty_like(sizes) for _ in range(self.world)]
             dist.all_gather(all_sizes, sizes, group=self.group)
-            rows = [int(s) for s in all_sizes]
+            rows = [int(s[0]) for s in all_sizes]
+            strided = all(int(s[1]) for s in all_sizes)
             pad = max(rows)
             buf = torch.zeros((pad,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=self.device)
             buf[:mine.shape[0]] = mine
             parts = [torch.empty_like(buf) for _ in range(self.world)]
             dist.all_gather(parts, buf, group=self.group)
-            full = torch.empty((sum(rows),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=self.device)
-            for s in range(self.world):
-                full[s::self.world] = parts[s][:rows[s]]
-            out[k] = full
+            out[k] = _merge_shards([parts[s][:rows[s]] for s in range(self.world)], strided)
         return out
 
     def set_learning_rates(self, lrs: dict) -> None:
@@ -185,8 +203,12 @@ class ShardedTrainer:
         Every decision is per Gaussian and `densification_info` already holds the statistics of ALL views of the steps (the owner
         accumulates them), so owners densify independently -- no collective; only MCMC's global cap needs the total count."""
         from .trainer import Gaussians
-        g = Gaussians({k: self.params[k].clone() for k in SEGMENTS}, self.device)
-        g.training_setup(training_cameras_extent=1.0)
+        kw = {} if self.max_sh_degree is None else {'max_sh_degree': self.max_sh_degree}
+        g = Gaussians({k: self.params[k].clone() for k in SEGMENTS}, self.device, **kw)
+        if self.lr_config is not None:
+            g.training_setup(training_cameras_extent=self.extent, lr=self.lr_config)
+        else:
+            g.training_setup(training_cameras_extent=self.extent)
         for group in g.optimizer.param_groups:
             k = group['name']
             o, n, shape = self.layout[k]
@@ -201,6 +223,7 @@ class ShardedTrainer:
         new = {k: getattr(g, k).detach() for k in SEGMENTS}
         state = {group['name']: g.optimizer.state.get(group['params'][0], {}) for group in g.optimizer.param_groups}
         self.n = new['means'].shape[0]
+        self.strided = False
         self.layout, off = {}, 0
         for k in SEGMENTS:
             self.layout[k] = (off, new[k].numel(), tuple(new[k].shape))
@@ -258,8 +281,5 @@ class LocalShardGroup:
         out = {}
         for k in SEGMENTS:
             parts = [t.params[k] for t in self.ranks]
-            full = torch.empty((sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
-            for s, p in enumerate(parts):
-                full[s::self.world] = p
-            out[k] = full
+            out[k] = _merge_shards(parts, all(t.strided for t in self.ranks))
         return out

@@ -277,3 +277,13 @@ def test_owner_side_densification_between_steps():
     assert any(a != b for a, b in sizes)
     images = grp.step(settings, targets)                                        # the next step runs on the new shards
     assert all(torch.isfinite(im).all() for im in images) and all(torch.isfinite(t.param_arena).all() for t in grp.ranks)
+    # export after densification: shard sizes no longer follow the strided pattern -> shards are concatenated in rank order
+    full = grp.gather_parameters()
+    assert full['means'].shape[0] == sum(t.n for t in grp.ranks)
+    assert torch.equal(full['means'][:grp.ranks[0].n], grp.ranks[0].params['means'])
+    assert torch.equal(full['sh_coefficients_rest'][grp.ranks[0].n:], grp.ranks[1].params['sh_coefficients_rest'])
+    # the shard's maintenance view carries the scene extent / SH cap given to the trainer
+    t = grp.ranks[0]
+    t.extent, t.max_sh_degree = 5.0, 2
+    g2 = t.as_gaussians()
+    assert g2.max_sh_degree == 2 and abs(g2.optimizer.param_groups[0]['lr'] - t.lrs['means']) < 1e-12

@@ -4,11 +4,11 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline"
+B="python $R/bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o bench -- $B > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o bench -- $B > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o bench -- $B > $R/gpurun_out/${TAG}_write.log 2>&1
-S="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 $R/bench.py --gpus 1 --steps 8 --warmup 2 --no-extras --no-cpu-baseline --dp-mode sharded"
+S="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 $R/bench.py --gpus 1 --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-pmc --dp-mode sharded --force-dp"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_sharded_stats -o bench -- $S > $R/gpurun_out/${TAG}_sharded_stats.log 2>&1
 cd $R
 for k in stats sharded_stats; do db=$(find gpurun_out/${TAG}_$k -name '*.db' | head -1); python profiles/summarize_rocprof.py stats $db > gpurun_out/${TAG}_$k.txt; done
