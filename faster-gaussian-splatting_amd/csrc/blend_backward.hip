@@ -310,31 +310,54 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
 //      (kb:438), and dL/dmean2d = 2 [a b; b c] (sum(hh dx), sum(hh dy)) (kb:449-453) with hh = -alpha/2 dL/dalpha.
 //      About 50 VALU instructions per step remain.
 __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBackwardArgs a) {
-    __shared__ uint32_t s_wave_total[1024 / kWave];
+    // One workgroup; tiles are taken 1024 at a time (thread t <-> tile chunk * 1024 + t: coalesced, and the loads of up to
+    // kPlanChunks chunks are all issued before the first scan -- a thread that walked "its" 12 consecutive tiles with dependent
+    // loads made this pass latency-bound at 33 us). Per chunk: wave prefix sum + 16 wave totals through LDS, then every thread
+    // writes the (tile, bucket) pairs of its tile. List order = tile order.
+    constexpr int kPlanChunks = 16;                           // 16 Ki tiles (1080p: 12 240) per batch of loads
+    __shared__ uint32_t s_wave_total[2][1024 / kWave];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const unsigned per = (a.n_tiles + 1023u) / 1024u;
-    const unsigned t0 = tid * per, t1 = min(t0 + per, a.n_tiles);
-    uint32_t mine = 0;
-    for (unsigned t = t0; t < t1; ++t) mine += (a.max_n_processed[t] + kBucket - 1) / kBucket;      // live buckets of tile t (kb:295)
-    const uint32_t before_in_wave = wave_exclusive_sum(mine);
-    if (lane == 63u) s_wave_total[wv] = before_in_wave + mine;
-    __syncthreads();
-    uint32_t base = before_in_wave;
-    for (unsigned w = 0; w < wv; ++w) base += s_wave_total[w];
-    for (unsigned t = t0; t < t1; ++t) {
-        const uint32_t nl = (a.max_n_processed[t] + kBucket - 1) / kBucket;
-        for (uint32_t k = 0; k < nl; ++k) a.work_list[base + k] = make_uint2(t, k);
-        base += nl;
+    uint32_t base = 0;                                        // live buckets in front of the current chunk (uniform)
+    int parity = 0;
+    for (unsigned t0 = 0; t0 < a.n_tiles; t0 += 1024u * kPlanChunks) {
+        uint32_t nl[kPlanChunks];
+#pragma unroll
+        for (int c = 0; c < kPlanChunks; ++c) {
+            const unsigned t = t0 + static_cast<unsigned>(c) * 1024u + tid;
+            nl[c] = t < a.n_tiles ? (a.max_n_processed[t] + kBucket - 1) / kBucket : 0u;          // live buckets of the tile (kb:295)
+        }
+#pragma unroll
+        for (int c = 0; c < kPlanChunks; ++c) {
+            const unsigned t = t0 + static_cast<unsigned>(c) * 1024u + tid;
+            if (t0 + static_cast<unsigned>(c) * 1024u >= a.n_tiles) break;                          // uniform
+            const uint32_t before_in_wave = wave_exclusive_sum(nl[c]);
+            if (lane == 63u) s_wave_total[parity][wv] = before_in_wave + nl[c];
+            __syncthreads();
+            uint32_t mine = base + before_in_wave, total = 0;
+#pragma unroll
+            for (unsigned w = 0; w < 1024 / kWave; ++w) {
+                const uint32_t wt = s_wave_total[parity][w];
+                mine += w < wv ? wt : 0u;
+                total += wt;
+            }
+            for (uint32_t k = 0; k < nl[c]; ++k) a.work_list[mine + k] = make_uint2(t, k);
+            base += total;
+            parity ^= 1;                                      // the next chunk writes the other LDS row: one barrier per chunk
+        }
     }
-    if (tid == 1023u) *a.live_count = base;
+    if (tid == 0) *a.live_count = base;
 }
 
 __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const BlendBackwardArgs a) {
     const unsigned lane = threadIdx.x;
     __shared__ float4 s_pix[kTilePixels + 1];          // dL/dC rgb + packed (x | y << 8 | rel_last << 16); slot n_px = dead sentinel
-    __shared__ float2 s_inj[kTilePixels + 1];          // T_ckpt, S - g_w: enters the pipeline at lane 0
+    // T_ckpt, S - g_w: enters the pipeline at lane 0. Slots n_px .. n_px + 63 are zero: lane 0 reads slot (step + 1) without a clamp
+    // until the last step, and lanes 1..63 read slot n_px (zero) in every step, which makes "shift up by one lane, inject at lane 0"
+    // ONE DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
+    __shared__ float2 s_inj[kTilePixels + kWave];
     const unsigned n_live = *a.live_count;
     const float lane_f = static_cast<float>(lane);
+    const bool lane0 = lane == 0;
     for (unsigned item = blockIdx.x; item < n_live; item += gridDim.x) {            // wave-uniform
         const uint2 work = a.work_list[item];
         const unsigned tile = work.x, tb = work.y;
@@ -371,10 +394,8 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
                 }
                 n_px += static_cast<unsigned>(__popcll(m));
             }
-            if (lane == 0) {
-                s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));   // rel_last 0: never contributes
-                s_inj[n_px] = make_float2(0.0f, 0.0f);
-            }
+            if (lane0) s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));   // rel_last 0: never contributes
+            s_inj[n_px + lane] = make_float2(0.0f, 0.0f);
         }
 
         const unsigned tp = first_gaussian + lane;
@@ -399,52 +420,57 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         float a_h = 0.0f, a_x = 0.0f, a_y = 0.0f;                     // sum hh, sum hh dx, sum hh dy
         float a_xx = 0.0f, a_xy = 0.0f, a_yy = 0.0f;                  // sum hh dx^2, hh dx dy, hh dy^2   (kb:443-448)
         float sT = 0.0f, sS = 0.0f;                                   // the pixel state travelling through the lanes
-        const bool lane0 = lane == 0;
-        uint64_t ever = 0;
 
-        // software-pipelined LDS reads, one step ahead; lane l reads slot clamp(step - l, 0, n_px) (n_px = the dead sentinel)
-        const int n_px_i = static_cast<int>(n_px);
-        float2 inj_next = s_inj[0];
-        int idx_next = -static_cast<int>(lane);                       // pixel slot of this lane in the NEXT step to execute
-        float4 pix_next = s_pix[idx_next < 0 ? n_px_i : idx_next];
-        const int n_steps = n_px_i + kWave - 1;
-#pragma unroll 2
-        for (int i = 0; i < n_steps; ++i) {
-            sT = wave_shift_up1(sT); sS = wave_shift_up1(sS);                                   // kb:383-393
-            const float2 inj = inj_next;
-            const float4 px = pix_next;
-            inj_next = s_inj[min(i + 1, n_px_i)];                                               // wave-uniform address: LDS broadcast
-            ++idx_next;
-            pix_next = s_pix[static_cast<unsigned>(idx_next) < n_px ? idx_next : n_px_i];      // negative / beyond the list -> sentinel
-            sT = lane0 ? inj.x : sT; sS = lane0 ? inj.y : sS;                                   // kb:401-410
+        // One pipeline step. `inj` / `px`: what this lane read for THIS step (software pipelined: the reads of the following step
+        // are issued first). Contributions are made under the lane mask of `contrib` (EXEC), not by selects: a v_cndmask costs
+        // several times an FMA on this chip (tools/valu_rate.hip), and the empty-mask branch of the `if` is the wave-uniform skip.
+        unsigned inj_slot = lane0 ? 0u : n_px;                        // lane 0: slot of the step; other lanes: the zero slot
+        const unsigned inj_step = lane0 ? 1u : 0u;
+        int pix_idx = -static_cast<int>(lane);                        // pixel slot of this lane in the step whose reads are issued next
+        auto read_inj = [&]() { const float2 v = s_inj[inj_slot]; inj_slot += inj_step; return v; };
+        auto read_pix = [&]() { const float4 v = s_pix[min(static_cast<unsigned>(pix_idx), n_px)]; ++pix_idx; return v; };   // negative / past the list -> sentinel
+        auto step = [&](const float2 inj, const float4 px) {
+            sT = wave_shift_up1_zero(sT) + inj.x;                                               // kb:383-410
+            sS = wave_shift_up1_zero(sS) + inj.y;
             const unsigned packed = __float_as_uint(px.w);
             const float pxf = x0 + static_cast<float>(packed & 0xffu);
             const float pyf = y0 + static_cast<float>((packed >> 8) & 0xffu);
             const float rel = static_cast<float>((packed >> 16) & 0xffu);
             const float dx = mx - pxf, dy = my - pyf;
             const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float alpha_raw = op * __expf(fminf(power, 0.0f));
-            const bool contrib = lane_f < rel && alpha_raw >= kMinAlphaThreshold;               // kb:412,419-421
-            const uint64_t contrib_mask = wave_ballot(contrib);
-            if (contrib_mask == 0) continue;                                                    // wave-uniform
-            ever |= contrib_mask;
-            const float alpha = contrib ? alpha_raw : 0.0f;
-            const float T = sT;
-            const float w = T * alpha;
-            a_c0 += w * px.x; a_c1 += w * px.y; a_c2 += w * px.z;
-            const float cg = col0 * px.x + col1 * px.y + col2 * px.z;
-            sS -= w * cg;                                                                        // kb:429 projected on dL/dC
-            const float oma = 1.0f - alpha;
-            const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
-            const float dl_dalpha = T * cg - sS * oma_rcp;                                       // kb:434-436
-            const float hh = (-0.5f * alpha) * dl_dalpha;
-            const float t = hh * dx, u = hh * dy;
-            a_h += hh; a_x += t; a_y += u;
-            a_xx += t * dx; a_xy += t * dy; a_yy += u * dy;
-            sT = T * oma;
+            const float alpha = op * __expf(fminf(power, 0.0f));
+            if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
+                const float T = sT;
+                const float w = T * alpha;
+                a_c0 += w * px.x; a_c1 += w * px.y; a_c2 += w * px.z;
+                const float cg = col0 * px.x + col1 * px.y + col2 * px.z;
+                sS -= w * cg;                                                                    // kb:429 projected on dL/dC
+                const float oma = 1.0f - alpha;
+                const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+                const float dl_dalpha = T * cg - sS * oma_rcp;                                   // kb:434-436
+                const float hh = (-0.5f * alpha) * dl_dalpha;
+                const float t = hh * dx, u = hh * dy;
+                a_h += hh; a_x += t; a_y += u;
+                a_xx += t * dx; a_xy += t * dy; a_yy += u * dy;
+                sT = T * oma;
+            }
+        };
+        // two steps per trip with the read registers ping-ponged (no copies); an odd step count runs one extra step in which every
+        // lane sees the sentinel
+        float2 inj_a = read_inj(), inj_b;
+        float4 pix_a = read_pix(), pix_b;
+        const int n_steps = static_cast<int>(n_px) + kWave - 1;
+        for (int i = 0; i < n_steps; i += 2) {
+            inj_b = read_inj(); pix_b = read_pix();
+            step(inj_a, pix_a);
+            inj_a = read_inj(); pix_a = read_pix();
+            step(inj_b, pix_b);
         }
 
-        const bool silent = ((ever >> lane) & 1ull) == 0;
+        // A Gaussian whose nine sums are all zero has nothing to add (it never passed the alpha test, or only at pixels with a zero
+        // image gradient); the kernel's tail is bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles).
+        const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
+                            && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
         if (valid_prim && !silent) {                                                             // kb:459-470
             const size_t n = a.n;
             unsafeAtomicAdd(a.acc + prim, 2.0f * (ca * a_x + cb * a_y));

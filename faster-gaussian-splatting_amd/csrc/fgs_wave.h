@@ -65,6 +65,12 @@ __device__ __forceinline__ float wave_shift_up1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
 }
 
+// lane l takes lane l-1's value, lane 0 takes 0 (DPP wave_shr:1 bound_ctrl:0). Written so that the DPP combiner can fold the
+// move into the consuming VALU instruction (v_add_f32_dpp): shift + inject costs one instruction.
+__device__ __forceinline__ float wave_shift_up1_zero(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+
 // LDS written by some lanes of this wave and read by others: DS operations of one wave execute in order, this only stops
 // the compiler from moving the reads above the writes.
 __device__ __forceinline__ void wave_lds_fence() {

@@ -76,6 +76,11 @@ inline float wave_shift_up1(float v) {
     const float up = __uint_as_float(static_cast<unsigned>(sim_exchange(__float_as_uint(v), static_cast<int>((lane + 63u) % 64u))));
     return lane == 0 ? v : up;
 }
+inline float wave_shift_up1_zero(float v) {
+    const unsigned lane = lane_id();
+    const float up = __uint_as_float(static_cast<unsigned>(sim_exchange(__float_as_uint(v), static_cast<int>((lane + 63u) % 64u))));
+    return lane == 0 ? 0.0f : up;
+}
 inline void wave_lds_fence() { sim::sync_scope(true); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float4 load_float4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -71,7 +71,7 @@ def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, l
     inv = f['n_touched'] == 0
     if inv.any():
         k = 'means'
-        assert np.abs(dM[k].cpu().numpy()[inv] - M0[k].numpy()[inv] * 0.9 ** steps).max() < 1e-6 * np.abs(M0[k].numpy()).max() + 1e-12
+        assert np.abs(dM[k].cpu().numpy()[inv] - M0[k].numpy()[inv] * 0.9 ** steps).max() < 1e-5 * np.abs(M0[k].numpy()).max()   # fp32: m * 0.9 * 0.9 ...
         assert np.abs(dP[k].cpu().numpy()[inv] - P0[k].numpy()[inv]).max() > 0
     return report
 

@@ -32,6 +32,18 @@ __global__ void __launch_bounds__(256) rate_kernel(unsigned long long* cycles, f
             a0 = q0.x + q0.y; a1 = q1.x + q1.y; a2 = q2.x + q2.y; a3 = q3.x + q3.y;
         }
         if (KIND == 8) { REP8(asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
+        if (KIND == 10) { REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s20", "s21");) }
+        if (KIND == 11) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %4\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %4" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b) : "vcc");) }
+        if (KIND == 12) { REP8(asm volatile("v_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %2, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %3, %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
+        if (KIND == 13) { REP8(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
+        if (KIND == 14) { REP8(asm volatile("v_med3_i32 %0, %0, %4, %5\n v_med3_i32 %1, %1, %4, %5\n v_med3_i32 %2, %2, %4, %5\n v_med3_i32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+        if (KIND == 15) { REP8(asm volatile("v_max_f32 %0, %0, %4\n v_min_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
+        if (KIND == 16) { REP8(asm volatile("v_lshlrev_b32 %0, 4, %0\n v_and_b32 %1, 255, %1\n v_add_u32 %2, %2, %4\n v_sub_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u));) }
+        if (KIND == 17) {   // compare + exec-masked block of 2 FMAs + restore (what `if (lane-varying) {..}` costs around a short body)
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n s_or_b64 exec, exec, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc", "s20", "s21");) }
+        if (KIND == 18) { REP8(asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+        if (KIND == 19) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_lt_f32 s[20:21], %2, %4\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc", "s20", "s21");) }
+        if (KIND == 20) { REP8(asm volatile("v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s22, %2\n v_readfirstlane_b32 s23, %3" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23");) }
         if (KIND == 9) { REP8(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %0, %0, %4, %5" : "+v"(a0) : "v"(a1), "v"(a2), "v"(a3), "v"(b), "v"(c));) }   // dependent chain
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -78,5 +90,16 @@ int main() {
     run<4>("v_cndmask_b32");
     run<5>("v_mov_b32_dpp wave_shr:1");
     run<6>("v_cvt_f32_ubyteN");
+    run<10>("v_cndmask_b32_e64 sgpr mask");
+    run<19>("v_cmp + v_cndmask pairs");
+    run<11>("v_cmp_lt_f32 -> vcc");
+    run<12>("v_add_f32_dpp wave_shr:1");
+    run<13>("v_mov_b32");
+    run<14>("v_med3_i32");
+    run<15>("v_max/min_f32");
+    run<16>("int lshl/and/add/sub");
+    run<18>("v_fmac_f32");
+    run<20>("v_readfirstlane_b32");
+    run<17>("cmp+saveexec+2fma+restore (5)");
     return 0;
 }
