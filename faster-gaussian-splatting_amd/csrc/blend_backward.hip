@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         // lane sees the sentinel
         float2 inj_a = read_inj(), inj_b;
         float4 pix_a = read_pix(), pix_b;
-        const int n_steps = static_cast<int>(n_px) + kWave - 1;
+        const int n_steps = (a.ablate & 2) ? 0 : static_cast<int>(n_px) + kWave - 1;
         for (int i = 0; i < n_steps; i += 2) {
             inj_b = read_inj(); pix_b = read_pix();
             step(inj_a, pix_a);
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         // image gradient); the kernel's tail is bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles).
         const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
                             && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
-        if (valid_prim && !silent) {                                                             // kb:459-470
+        if (valid_prim && !silent && !(a.ablate & 1)) {                                          // kb:459-470
             const size_t n = a.n;
             unsafeAtomicAdd(a.acc + prim, 2.0f * (ca * a_x + cb * a_y));
             unsafeAtomicAdd(a.acc + n + prim, 2.0f * (cb * a_x + cc * a_y));
@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
     }
 }
 
+int g_backward_ablate = 0;    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
 int g_backward_variant = 3;   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
                               // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
                               // fgs_debug_set_backward_variant()
@@ -497,9 +498,12 @@ hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s) {
+hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
+    const BlendBackwardArgs& a = a_in;
     if (a.n_buckets_cap == 0) return hipSuccess;
     if (g_backward_variant == 3) {
+        BlendBackwardArgs a = a_in;
+        a.ablate = g_backward_ablate;
         hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(1024), 0, s, a);
         // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
         // for the launch of a quarter of a million empty ones

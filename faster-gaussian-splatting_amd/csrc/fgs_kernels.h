@@ -84,6 +84,7 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket, written by the planning pass
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
+    int ablate;                           // debug timing experiments (fgs_debug_set_option key 7); 0 in production
 };
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s);      // per-pixel staging pass
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);    // K11 proper
@@ -157,6 +158,7 @@ hipError_t launch_add_noise(const float* raw_scales, const float* raw_rotations,
 
 extern int g_adam_nontemporal;                                  // 0 | 1
 extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
+extern int g_backward_ablate;
 extern int g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 
