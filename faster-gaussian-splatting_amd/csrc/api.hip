@@ -90,6 +90,7 @@ struct Carver {                       // 256-byte aligned bump allocation inside
     size_t total() const { return (off + 255) & ~static_cast<size_t>(255); }
 };
 
+constexpr size_t kCounterWords = 8;      // PreprocessArgs::counters
 struct Geometry { uint32_t grid_w, grid_h, n_tiles; int end_bit, key_bytes; };
 Geometry geometry_of(int width, int height) {
     Geometry g;
@@ -102,7 +103,7 @@ Geometry geometry_of(int width, int height) {
 }
 
 struct PrimitiveBuffers {             // cf. bu:45-94
-    PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters;
+    PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters; uint32_t* hot_list;
     char* temp; size_t temp_bytes;
     static PrimitiveBuffers carve(Carver& c, uint32_t n) {
         PrimitiveBuffers b;
@@ -111,7 +112,8 @@ struct PrimitiveBuffers {             // cf. bu:45-94
         b.keys[0] = c.take<uint32_t>("depth_keys0", n); b.keys[1] = c.take<uint32_t>("depth_keys1", n);
         b.prims[0] = c.take<uint32_t>("prim_idx0", n); b.prims[1] = c.take<uint32_t>("prim_idx1", n);
         b.offsets = c.take<uint32_t>("offsets", n);
-        b.counters = c.take<uint32_t>("counters", 4);
+        b.counters = c.take<uint32_t>("counters", kCounterWords);
+        b.hot_list = c.take<uint32_t>("hot_list", kMaxHot);
         b.temp_bytes = depth_sort_temp_bytes(n);
         b.temp = c.take<char>("sort_temp", b.temp_bytes);
         return b;
@@ -158,10 +160,12 @@ struct BucketBuffers {                // cf. bu:154-163
     }
 };
 struct BackwardScratch {
-    float* acc; float* view_dir; float4* pixrec;
+    float* acc; float* acc_hot; float* view_dir; float4* pixrec;
+    static constexpr size_t kHotFloats = (size_t)kHotReplicas * 9 * kMaxHot;
     static BackwardScratch carve(Carver& c, uint32_t n, uint32_t t) {
         BackwardScratch b;
         b.acc = c.take<float>("acc", (size_t)n * 9);
+        b.acc_hot = c.take<float>("acc_hot", kHotFloats);
         b.view_dir = c.take<float>("view_dir", (size_t)n * 3);
         b.pixrec = c.take<float4>("pixrec", (size_t)t * kTilePixels * 2);
         return b;
@@ -267,10 +271,11 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
     Carver prim_c(prim_blob);
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
-    FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
+    FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
     PreprocessArgs pa{};
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
+    pa.hot_list = pb.hot_list;
     pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles; pa.seq_tiles = g_seq_tiles;
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
@@ -370,13 +375,15 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
 
 int run_blend_backward(const BackwardPlan& P, const float* grad_image, const float* image, int32_t n_primitives,
                        const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream) {
-    if (n_primitives > 0) FGS_HIP(hipMemsetAsync(P.sc.acc, 0, sizeof(float) * 9 * (size_t)n_primitives, stream));   // replaces api:127-134
+    // replaces api:127-134: only the 9-float accumulators (and the hot Gaussians' replicas behind them) are cleared
+    if (n_primitives > 0) FGS_HIP(hipMemsetAsync(P.sc.acc, 0, static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc)), stream));
     BlendBackwardArgs a{};
     a.ranges = P.tb.ranges; a.bucket_offsets = P.tb.bucket_offsets; a.inst_prims = P.ib.prims[state->selector]; a.rec = P.pb.rec;
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
     a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
     a.work_list = P.bb.work_list; a.live_count = P.tb.live_count;
+    a.acc_hot = P.sc.acc_hot; a.hot_list = P.pb.hot_list; a.hot_count = P.pb.counters + 4;
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
@@ -538,10 +545,10 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
             const int v = v0 + k;
             Carver c(prim_blob + per_view * v);
             const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
-            FGS_HIP(hipMemsetAsync(b.counters, 0, 4 * sizeof(uint32_t), stream));
+            FGS_HIP(hipMemsetAsync(b.counters, 0, kCounterWords * sizeof(uint32_t), stream));
             PreprocessArgs& pa = pb.v[k];
             pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
-            pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets;
+            pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets; pa.hot_list = b.hot_list;
             pa.count_appended = 1; pa.seq_tiles = g_seq_tiles;
             pa.n = n; pa.cam = camera_of(settings[v], geo); pa.ranges = nullptr; pa.n_tiles = 0;   // the tile ranges belong to the renderer of the view
             // slot table for fgs_shard_backward: the second depth-key buffer is free on this path (no sort on the owner)
@@ -575,9 +582,9 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
     if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
     Carver prim_c(prim_blob);
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
-    FGS_HIP(hipMemsetAsync(pb.counters, 0, 4 * sizeof(uint32_t), stream));
+    FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
-      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, stream)); }
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, stream)); }
     return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
@@ -832,7 +839,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
                 fgs::g_adam_unroll = value; return FGS_OK;
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
         case 3: g_fused_single_kernel = value ? 1 : 0; return FGS_OK;
-        case 7: fgs::g_backward_ablate = value & 3; return FGS_OK;
+        case 7: fgs::g_backward_ablate = value & 15; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 5: if (value < 1 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 1..32");
                 g_seq_tiles = value; return FGS_OK;

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     unsigned tx0, tx1, ty0, ty1;
     tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
     const unsigned tbw = tx1 - tx0;
-    const uint32_t mask = active ? __float_as_uint(r2.w) : 0u;
+    const uint32_t mask = (active && tbw * (ty1 - ty0) <= 32u) ? __float_as_uint(r2.w) : 0u;   // larger footprints keep a hot-accumulator slot there
     const uint32_t my_off = offsets[i];
     const uint32_t my_n = active ? n_touched[prim] : 0u;
 

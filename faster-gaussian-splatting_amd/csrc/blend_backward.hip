@@ -403,14 +403,21 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         uint32_t prim = 0;
         float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, op = 0.0f;
         float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+        unsigned footprint = 0;               // candidate tiles of this lane's Gaussian
+        uint32_t hot_slot_word = 0;
         if (valid_prim) {
             prim = a.inst_prims[range.x + tp];
             const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
             const float4 r0 = r[0], r1 = r[1];
-            const float raw2 = reinterpret_cast<const float*>(r + 2)[0];
+            const float4 r2 = r[2];
+            const float raw2 = r2.x;
             mx = r0.x; my = r0.y; ca = r0.z; cb = r0.w; cc = r1.x; op = r1.y;
             col0 = fmaxf(r1.z, 0.0f); col1 = fmaxf(r1.w, 0.0f); col2 = fmaxf(raw2, 0.0f);
             f0 = r1.z >= 0.0f ? 1.0f : 0.0f; f1 = r1.w >= 0.0f ? 1.0f : 0.0f; f2 = raw2 >= 0.0f ? 1.0f : 0.0f;   // kb:313-318
+            unsigned tx0, tx1, ty0, ty1;
+            tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
+            footprint = (tx1 - tx0) * (ty1 - ty0);
+            hot_slot_word = __float_as_uint(r2.w);
         }
         const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f;
         const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
@@ -472,20 +479,35 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
                             && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
         if (valid_prim && !silent && !(a.ablate & 1)) {                                          // kb:459-470
-            const size_t n = a.n;
-            unsafeAtomicAdd(a.acc + prim, 2.0f * (ca * a_x + cb * a_y));
-            unsafeAtomicAdd(a.acc + n + prim, 2.0f * (cb * a_x + cc * a_y));
-            unsafeAtomicAdd(a.acc + 2 * n + prim, a_xx);
-            unsafeAtomicAdd(a.acc + 3 * n + prim, a_xy);
-            unsafeAtomicAdd(a.acc + 4 * n + prim, a_yy);
+            // a hot Gaussian adds into its private replica (fgs_config.h); everybody else into the planes
+            const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
+            float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + prim;
+            const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
+            unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
+            unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
+            unsafeAtomicAdd(dst + 2 * plane, a_xx);
+            unsafeAtomicAdd(dst + 3 * plane, a_xy);
+            unsafeAtomicAdd(dst + 4 * plane, a_yy);
             // dL/dopacity = sum G dL/dalpha with G = alpha / opacity; through the sigmoid unless proper antialiasing (kb:462-466)
-            unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op));
-            unsafeAtomicAdd(a.acc + 6 * n + prim, a_c0 * f0);
-            unsafeAtomicAdd(a.acc + 7 * n + prim, a_c1 * f1);
-            unsafeAtomicAdd(a.acc + 8 * n + prim, a_c2 * f2);
+            unsafeAtomicAdd(dst + 5 * plane, a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op));
+            unsafeAtomicAdd(dst + 6 * plane, a_c0 * f0);
+            unsafeAtomicAdd(dst + 7 * plane, a_c1 * f1);
+            unsafeAtomicAdd(dst + 8 * plane, a_c2 * f2);
         }
         wave_lds_fence();                                  // the next item restages the LDS slices
     }
+}
+
+// after K11: the hot Gaussians' replicas are summed and added to their entries of the nine planes (one thread per (slot, plane))
+__global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendBackwardArgs a) {
+    const unsigned n_hot = min(*a.hot_count, kMaxHot);
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned slot = e % kMaxHot, k = e / kMaxHot;          // consecutive threads: consecutive slots of one plane
+    if (slot >= n_hot || k >= 9u) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (unsigned r = 0; r < kHotReplicas; ++r) sum += a.acc_hot[((size_t)r * 9u + k) * kMaxHot + slot];
+    if (sum != 0.0f) a.acc[(size_t)k * a.n + a.hot_list[slot]] += sum;      // one slot per primitive: no other writer at this point
 }
 
 int g_backward_ablate = 0;    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
@@ -509,6 +531,7 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
         // for the launch of a quarter of a million empty ones
         const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;
         hipLaunchKernelGGL(blend_backward_compact_kernel, dim3(blocks), dim3(kWave), 0, s, a);
+        hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     if (g_backward_variant == 1) {

@@ -32,6 +32,13 @@ constexpr int kPreprocessBackwardBlock = 256;
 constexpr int kInstanceBlock = 256;
 constexpr int kBlendBlock = kTilePixels;       // 3 waves
 constexpr int kBackwardWavesPerBlock = 1;      // 1 bucket per 64-thread workgroup: inactive buckets free their slot at once
+// "Hot" Gaussians: footprints above kHotFootprint candidate tiles (0.1 % of the visible ones at S2) are front-most in hundreds to
+// thousands of tiles, so K11 adds into their nine accumulators from as many waves -- and a 128-byte line of device memory retires
+// only ~1 atomic per ns (tools/atomic_rate.hip), with 32 Morton-neighbours sharing every line of a plane. They get kHotReplicas
+// private accumulator sets each (replica = tile mod kHotReplicas), folded into the planes after K11.
+constexpr unsigned kHotFootprint = 256;
+constexpr unsigned kMaxHot = 16384;            // more hot Gaussians than this: the rest accumulate directly (correct, only slower)
+constexpr unsigned kHotReplicas = 16;
 constexpr unsigned kBackwardMaxBlocks = 1u << 16;   // K11 walks the live-bucket list with at most this many single-wave workgroups
 constexpr int kSplatRecordWords = 14;          // sharded path: PrimRec (12 words) + depth key + tile count = FGS_SPLAT_RECORD_BYTES / 4
 constexpr int kMaxBatchViews = 8;              // sharded path: views handled by one K1 / K12 launch (grid.y / in-kernel loop)

@@ -15,8 +15,9 @@ struct PreprocessArgs {                 // K1
     const float* sh0; const float* sh_rest;
     PrimRec* rec; uint32_t* n_touched;
     uint32_t* depth_keys; uint32_t* prim_idx;     // compacted (unsorted) visible list
-    uint32_t* counters;                            // [0] n_visible, [1] n_instances (one packed 64-bit word), [2] K5 work list, [3] huge list
+    uint32_t* counters;                            // [0] n_visible, [1] n_instances (one packed 64-bit word), [2] K5 work list, [3] huge list, [4] hot slots
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
+    uint32_t* hot_list;                            // [kMaxHot] primitive index of hot-accumulator slot s (counters[4] = slots handed out)
     uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
     uint32_t n;
     int seq_tiles;                                 // candidate tiles each lane tests itself before the wave cooperates (1..32)
@@ -81,6 +82,8 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
     float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    float* acc_hot;                       // [kHotReplicas][9][kMaxHot]: private accumulators of the hot Gaussians
+    const uint32_t* hot_list; const uint32_t* hot_count;   // slot -> primitive, number of slots handed out (may exceed kMaxHot)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket, written by the planning pass
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
@@ -144,7 +147,7 @@ struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const ui
 struct PackRecordsBatch { int n_views; uint32_t capacity; PackRecordsView v[kMaxBatchViews]; };
 hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s);
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, hipStream_t s);
 hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s);
 
 // aux_ops.hip: the reference's remaining exported operators

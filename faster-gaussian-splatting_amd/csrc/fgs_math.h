@@ -49,7 +49,8 @@ struct alignas(16) PrimRec {
     float cc, opacity, r, g;       // conic.z (c), opacity, colour.rg
     float b;                       // colour.b
     uint32_t bx, by;               // screen bounds: x_min | x_max<<16, y_min | y_max<<16   (ushort4 of kf:168-175)
-    uint32_t hit_mask;             // exact-overlap bitmap over the (<= 32) candidate tiles of the bounding box, 0 if larger
+    uint32_t hit_mask;             // <= 32 candidate tiles: exact-overlap bitmap over them (row-major in the tile bounding box);
+                                   // > kHotFootprint candidates: hot-accumulator slot + 1 (0 = none); otherwise 0
 };
 static_assert(sizeof(PrimRec) == 48, "PrimRec must be 48 bytes");
 

@@ -112,6 +112,18 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
             }
 
             visible = active && cnt > 0;                                               // kf:190
+            // hot-accumulator slots for K11 (fgs_config.h): one counter atomic per wave that holds such a footprint
+            uint32_t slot_word = n_max <= 32u ? hit_mask : 0u;
+            const bool hot = (visible || huge) && n_max > kHotFootprint;
+            const uint64_t hot_mask = wave_ballot(hot);
+            if (hot_mask != 0) {
+                const int leader = __ffsll(static_cast<unsigned long long>(hot_mask)) - 1;
+                unsigned hot_base = 0;
+                if (lane == static_cast<unsigned>(leader)) hot_base = atomicAdd(&a.counters[4], static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hot_mask))));
+                hot_base = wave_read(hot_base, leader);
+                const unsigned slot = hot_base + lanes_below(hot_mask);
+                if (hot && slot < kMaxHot) { a.hot_list[slot] = idx; slot_word = slot + 1u; }
+            }
             if (visible || huge) {
                 float col[3];
                 const float* k = a.sh_rest + (size_t)idx * cam.total_sh_rest * 3;
@@ -121,8 +133,8 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 float4* dst = reinterpret_cast<float4*>(a.rec + idx);
                 dst[0] = make_float4(m2x, m2y, ca, cb);
                 dst[1] = make_float4(cc, opacity, col[0], col[1]);
-                // footprints of <= 32 candidate tiles hand their exact-overlap bitmap to the instance generator (0 = recompute)
-                dst[2] = make_float4(col[2], __uint_as_float(bx), __uint_as_float(by), __uint_as_float(n_max <= 32u ? hit_mask : 0u));
+                // footprints of <= 32 candidate tiles hand their exact-overlap bitmap to the instance generator; hot ones their slot
+                dst[2] = make_float4(col[2], __uint_as_float(bx), __uint_as_float(by), __uint_as_float(slot_word));
             }
             const uint64_t huge_mask = wave_ballot(huge);
             if (huge_mask != 0) {

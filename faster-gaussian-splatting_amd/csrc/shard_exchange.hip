@@ -10,6 +10,7 @@
 //   owner:    K1 on the shard  -> pack_splat_records  ==all-to-all==>  unpack_splat_records -> K2..K10   :renderer
 //   owner:    K12 (reads the records in place through K1's slot table), K13  <==all-to-all==  pack_acc <- K11  :renderer
 #include "fgs_kernels.h"
+#include <fgs_wave.h>
 
 namespace fgs {
 
@@ -48,16 +49,37 @@ __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecor
 // Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
 __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, PrimRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
-                                                                   uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles) {
+                                                                   uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles,
+                                                                   uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     for (uint32_t t = j; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
-    if (j >= n) return;
-    const uint2* m = reinterpret_cast<const uint2*>(records + (size_t)kSplatRecordWords * j);
-    const uint2 w0 = m[0], w1 = m[1], w2 = m[2], w3 = m[3], w4 = m[4], w5 = m[5], w6 = m[6];
+    const bool in_range = j < n;
+    uint2 w0{}, w1{}, w2{}, w3{}, w4{}, w5{}, w6{};
+    if (in_range) {
+        const uint2* m = reinterpret_cast<const uint2*>(records + (size_t)kSplatRecordWords * j);
+        w0 = m[0]; w1 = m[1]; w2 = m[2]; w3 = m[3]; w4 = m[4]; w5 = m[5]; w6 = m[6];
+    }
+    // hot-accumulator slots are local to a pipeline: the owners' slot numbers mean nothing here, the renderer hands out its own
+    unsigned tx0, tx1, ty0, ty1;
+    tile_rect(w4.y, w5.x, tx0, tx1, ty0, ty1);
+    const unsigned n_max = (tx1 - tx0) * (ty1 - ty0);
+    const bool hot = in_range && n_max > kHotFootprint;
+    uint32_t slot_word = n_max <= 32u ? w5.y : 0u;
+    const uint64_t hot_mask = wave_ballot(hot);
+    if (hot_mask != 0) {
+        const unsigned lane = lane_id();
+        const int leader = __ffsll(static_cast<unsigned long long>(hot_mask)) - 1;
+        unsigned base = 0;
+        if (lane == static_cast<unsigned>(leader)) base = atomicAdd(hot_count, static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hot_mask))));
+        base = wave_read(base, leader);
+        const unsigned slot = base + lanes_below(hot_mask);
+        if (hot && slot < kMaxHot) { hot_list[slot] = j; slot_word = slot + 1u; }
+    }
+    if (!in_range) return;
     uint4* r = reinterpret_cast<uint4*>(rec + j);
     r[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
     r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
-    r[2] = make_uint4(w4.x, w4.y, w5.x, w5.y);
+    r[2] = make_uint4(w4.x, w4.y, w5.x, slot_word);
     depth_keys[j] = w6.x; prim_idx[j] = j; n_touched[j] = w6.y;
 }
 
@@ -80,9 +102,9 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
 }
 
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, hipStream_t s) {
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, hipStream_t s) {
     const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count);
     return hipGetLastError();
 }
 

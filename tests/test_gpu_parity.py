@@ -169,6 +169,25 @@ def test_huge_footprints_workgroup_path(hip_backend, oracle):
     _forward_check(hip_backend, oracle, p, v)
 
 
+def test_hot_footprints_accumulate_through_replicas(hip_backend, oracle):
+    """Footprints above 256 candidate tiles use K11's replicated accumulators (and > 1024 the workgroup path of K1 / K5): forward
+    intermediates and all gradients against the oracle, with more hot Gaussians than one wave holds."""
+    p, v = make_s0(seed=13, n=400)
+    v = View(v.w2c, v.position, 960, 540, 700.0, 700.0, 480.0, 270.0, 0.2, 1e4, torch.zeros(3))
+    p['scales'][:90] = p['scales'][:90] + 2.2
+    p['scales'][:12] = p['scales'][:12] + 1.0
+    p['opacities'][:90] -= 1.5
+    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+    sb = f['screen_bounds'].astype(np.int64)
+    n_max = ((sb[:, 1] + 15) // 16 - sb[:, 0] // 16) * ((sb[:, 3] + 11) // 12 - sb[:, 2] // 12)
+    assert ((n_max > 256) & (f['n_touched'] > 0)).sum() > 64 and ((n_max > 1024) & (f['n_touched'] > 0)).sum() >= 4
+    gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g = oracle.backward(f, S, gi)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                 dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    _grads_close(grads, g)
+
+
 def test_known_answer_single_gaussian_on_device(hip_backend):
     """The hand-derived known answer of tests/test_oracle.py::test_known_answer_single_gaussian, against the HIP path directly
     (no oracle involved): one isotropic Gaussian on the optical axis, image and two analytic gradients."""

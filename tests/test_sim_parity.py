@@ -75,6 +75,19 @@ def test_huge_footprints_take_the_workgroup_path(sim_backend, oracle):
     assert (n_max > 1024).sum() >= 3 and ((n_max > 32) & (n_max <= 1024)).sum() >= 3 and (n_max <= 32).sum() >= 3
 
 
+def test_hot_footprints_accumulate_through_replicas(sim_backend, oracle):
+    """Footprints above 256 candidate tiles get private accumulator replicas in K11 (fgs_config.h: kHotFootprint), folded into the
+    planes afterwards: gradients must not notice. 25 x 25 tiles, a few Gaussians covering 300+ of them next to small ones."""
+    p, v = make_s0(seed=13, n=24)
+    v = View(v.w2c, v.position, 400, 300, 320.0, 320.0, 200.0, 150.0, 0.2, 1e4, torch.zeros(3))
+    p['scales'][:5] = p['scales'][:5] + 2.6          # hot: hundreds of tiles each
+    p['scales'][5:9] = p['scales'][5:9] + 1.5        # medium
+    _, f = _run(sim_backend, oracle, p, v)
+    sb = f['screen_bounds'].astype(np.int64)
+    n_max = ((sb[:, 1] + 15) // 16 - sb[:, 0] // 16) * ((sb[:, 3] + 11) // 12 - sb[:, 2] // 12)
+    assert ((n_max > 256) & (f['n_touched'] > 0)).sum() >= 3 and ((n_max <= 256) & (f['n_touched'] > 0)).sum() >= 5
+
+
 def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     """> 192 Gaussians per tile: multiple LDS batches and several buckets per tile."""
     p, v = make_s0(seed=11, n=1500)

@@ -18,7 +18,7 @@ for off in (0.0, -3.0):
         fw = be.forward(*g.tensors(), S)
         gi = torch.randn_like(fw.image) / fw.image.numel()
         args = (torch.empty(0, device=dev), gi, fw.image, g.means, g.scales, g.rotations, g.opacities, g.sh_coefficients_rest, fw.buffers, S, fw.state)
-        for ab in (0, 1, 2, 3):
+        for ab in (0, 1, 2, 4, 8):
             be.lib.fgs_debug_set_option(7, ab)
             be.backward(*args); torch.cuda.synchronize()
             be.profile_enable(True); be.profile_read()
@@ -37,5 +37,5 @@ for off in (0.0, -3.0):
                 sel = nb > tb
                 live_px += int((npx[sel] > tb * 64).sum())
             print(f'opacity offset {off}: live buckets {live_b}, mean live pixels per live bucket {live_px / max(live_b, 1):.1f} of 192')
-    for ab, name in ((0, 'full'), (1, 'no atomics'), (2, 'no step loop'), (3, 'neither')):
+    for ab, name in ((0, 'full'), (1, 'no atomics'), (2, 'no step loop'), (4, 'no atomics of >1024-tile footprints'), (8, 'no atomics of >256-tile footprints')):
         print(f'  offset {off} {name:14s} median {statistics.median(out[ab]):.4f} ms  min {min(out[ab]):.4f}')
