@@ -91,10 +91,13 @@ def live_pmc(args) -> dict:
             cols = [d[1] for d in db.execute('pragma table_info(pmc_events)')]
             name_col = 'counter_name' if 'counter_name' in cols else [c for c in cols if 'name' in c][-1]
             val_col = 'counter_value' if 'counter_value' in cols else [c for c in cols if 'value' in c][-1]
-            for kname, cname, avg in db.execute(f'select name, {name_col}, avg({val_col}) from pmc_events group by name, {name_col}'):
+            launches = dict(db.execute('select name, count(*) from kernels group by name').fetchall())
+            # SQ counters come as one row per shader engine and dispatch, TCC-derived ones as one row per dispatch: summing the rows
+            # and dividing by the number of dispatches (kernel trace) gives the per-launch total for both
+            for kname, cname, total in db.execute(f'select name, {name_col}, sum({val_col}) from pmc_events group by name, {name_col}'):
                 for key, sub in PMC_KERNELS.items():
-                    if sub in kname:
-                        out.setdefault(key, {})[cname] = float(avg)
+                    if sub in kname and launches.get(kname):
+                        out.setdefault(key, {})[cname] = float(total) / launches[kname]
     except Exception as exc:      # never take the bench line down
         return {'error': f'{type(exc).__name__}: {exc}'}
     finally:
@@ -248,14 +251,28 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    # Stage table: a separate, untimed pass of PROFILE_STEPS iterations with HIP events around every stage. The events themselves cost
+    # GPU idle time (~5 us each, ~0.2 ms per iteration with all ~15 stages bracketed: measured with rocprofv3 --kernel-trace), so the
+    # timed region below brackets only the dominant stage found here -- the `roofline` figure is still measured live, over the timed steps.
+    PROFILE_STEPS = 4
     be.profile_enable(True)
     be.profile_read()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(PROFILE_STEPS):
         step(args.warmup + i)
     fence()
-    elapsed = time.perf_counter() - t0
     prof = be.profile_read()
+    be.profile_enable(False)
+    n_prof = PROFILE_STEPS
+    dom_stage = max((k for k, v_ in prof.items() if v_[1] > 0), key=lambda k: prof[k][0] / prof[k][1])
+    be.profile_enable(True, only=dom_stage)
+    be.profile_read()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + PROFILE_STEPS + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof_dom = be.profile_read()
     be.profile_enable(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -290,7 +307,7 @@ def main():
                  'wire_bytes_per_rank_per_step': wire_bytes(other_mode)}
         del vp2
 
-    used = [my_views[(args.warmup + i) % len(my_views)] for i in range(args.steps)]
+    used = [my_views[(args.warmup + PROFILE_STEPS + i) % len(my_views)] for i in range(args.steps)]
     mean = lambda key: float(np.mean([stats[id(v)][key] for v in used]))
     V, I, B = mean('V'), mean('I'), mean('B')
     W_, H_ = views[0].width, views[0].height
@@ -324,9 +341,9 @@ def main():
                  'tile_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u16, 7> x 2 passes', 'sh_rest_backward': 'sh_rest_gradient_kernel<15, false>',
                  'preprocess_backward': 'preprocess_backward_kernel<false, false>',
                  'depth_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u32, 8> x 4 passes', 'fused_backward_adam': 'fused_backward_adam_kernel<15>'}
-    per_launch = {k: (v_[0] / max(v_[1], 1)) * (v_[1] / args.steps) for k, v_ in prof.items() if v_[1] > 0}   # ms per step
-    dom = max((k for k in per_launch if k in stage_bytes), key=per_launch.get)
-    dom_s = per_launch[dom] * 1e-3
+    per_launch = {k: v_[0] / n_prof for k, v_ in prof.items() if v_[1] > 0}   # ms per step, from the untimed stage-profile pass
+    dom = dom_stage
+    dom_s = prof_dom[dom][0] / max(prof_dom[dom][1], 1) * 1e-3            # average launch duration over the TIMED steps (HIP events on the launch stream)
     achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
     bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
     # live counters (rank 0, one GPU): HBM traffic of the dominant kernel; VALU instruction counts for the secondary ceiling
@@ -337,14 +354,16 @@ def main():
         # 'HBM', calibrated in round 1 on the Adam kernel: 2 x FETCH_SIZE + WRITE_SIZE = 4.956 GB = its algorithmic bytes)
         traffic = (2.0 * pmc[dom]['FETCH_SIZE'] + pmc[dom]['WRITE_SIZE']) * 1024.0
         traffic_note = 'live: rocprofv3 --pmc passes of a 3-step child run of this command; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch'
-    # Secondary ceiling: VALU issue. A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md
-    # 'Per-instruction cycle constants'), 1024 SIMDs at 2.4 GHz; frac = share of that issue capacity the kernel's own VALU stream takes.
+    # Secondary ceiling: VALU issue. Measured on this chip (tools/valu_rate.hip, profiles/r02_valu_rate.txt): a wave64
+    # v_fma/v_mul/v_add issues every 2.9 cycles of a 2.4 GHz clock per SIMD with 8 waves resident (MI355X_MICROARCH.md quotes 2), compares /
+    # selects / conversions / DPP moves 4.3, v_exp / v_rcp 8.3. frac = the kernel's VALU instructions (SQ_INSTS_VALU, all shader engines)
+    # over what 1024 SIMDs could issue in its run time at the plain-FMA rate -- a lower bound of how VALU-bound the kernel is.
     secondary = []
     for st in ('preprocess', 'blend_forward', 'blend_backward'):
         if st in pmc and 'SQ_INSTS_VALU' in pmc[st] and st in per_launch:
             insts = pmc[st]['SQ_INSTS_VALU']
             secondary.append({'bound': 'valu', 'stage': st, 'kernel': kernel_of[st], 'insts': insts, 'avg_kernel_ms': per_launch[st],
-                              'frac': insts * 2.0 / (1024 * 2.4e9 * per_launch[st] * 1e-3)})
+                              'cycles_per_inst': 2.9, 'frac': insts * 2.9 / (1024 * 2.4e9 * per_launch[st] * 1e-3)})
     out = {
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -362,7 +381,8 @@ def main():
                      'secondary': secondary,
                      'iteration_algorithmic_GB': bytes_iter / 1e9,
                      'iteration_frac_of_hbm_peak': bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
-        'stage_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+        'stage_ms_per_step': {k: v[0] / n_prof for k, v in prof.items() if v[1] > 0},
+        'stage_profile_steps': n_prof,
         'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes},
     }
 
@@ -391,15 +411,18 @@ def main():
         for _ in range(2):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
-        be.profile_enable(True)
-        be.profile_read()
         t0 = time.perf_counter()
         reps = 10
         for _ in range(reps):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
         out['fused_train_iters_per_sec'] = reps / (time.perf_counter() - t0)
-        out['fused_stage_ms_per_step'] = {k: v_[0] / reps for k, v_ in be.profile_read().items() if v_[1] > 0}
+        be.profile_enable(True)
+        be.profile_read()
+        for _ in range(PROFILE_STEPS):
+            fo.render_and_step(S, grad_fn, g.densification_info)
+        torch.cuda.synchronize(device)
+        out['fused_stage_ms_per_step'] = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
         out['fused_vs_unfused'] = out['fused_train_iters_per_sec'] / out['value']
         be.profile_enable(False)
         del fo
@@ -415,8 +438,6 @@ def main():
         for i in range(2):
             T.training_iteration(g2, my_views[i % len(my_views)], tg2[id(my_views[i % len(my_views)])], i)
         torch.cuda.synchronize(device)
-        be.profile_enable(True)
-        be.profile_read()
         t0 = time.perf_counter()
         reps = 8
         for i in range(reps):
@@ -424,6 +445,12 @@ def main():
             T.training_iteration(g2, vv, tg2[id(vv)], 2 + i)
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / reps
+        be.profile_enable(True)
+        be.profile_read()
+        for i in range(PROFILE_STEPS):
+            vv = my_views[(2 + i) % len(my_views)]
+            T.training_iteration(g2, vv, tg2[id(vv)], 10 + i)
+        torch.cuda.synchronize(device)
         pr = be.profile_read()
         be.profile_enable(False)
         res = be.forward(*g2.tensors(), settings_of[id(my_views[0])])
@@ -432,7 +459,7 @@ def main():
         out['layered_scene'] = {'what': 'S2 with every opacity logit lowered by 3.0 (deep semi-transparent layering, as in a trained scene)',
                                 'train_iters_per_sec': 1.0 / dt, 'ms_per_step': dt * 1e3, 'instances': res.state[1],
                                 'blended_buckets_per_tile': float(((mx + 63) // 64).float().mean()),
-                                'stage_ms_per_step': {k: v_[0] / reps for k, v_ in pr.items() if v_[1] > 0}}
+                                'stage_ms_per_step': {k: v_[0] / PROFILE_STEPS for k, v_ in pr.items() if v_[1] > 0}}
         del g2, tg2, res
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -367,8 +367,13 @@ class Backend:
         self._check(self.lib.fgs_add_noise(_ptr(raw_scales), _ptr(raw_rotations), _ptr(raw_opacities), _ptr(random_samples), _ptr(means),
                                            means.shape[0], float(current_lr), _stream_of(device)), 'fgs_add_noise')
 
-    def profile_enable(self, enable: bool) -> None:
-        self.lib.fgs_profile_enable(int(enable))
+    def profile_enable(self, enable, only: str | None = None) -> None:
+        """enable=True: HIP events around every stage; only='adam': around that one stage (far less intrusive); False: off."""
+        if enable and only is not None:
+            names = list(self.profile_read().keys())
+            self._check(self.lib.fgs_profile_enable(2 + names.index(only)), 'fgs_profile_enable')
+        else:
+            self.lib.fgs_profile_enable(int(bool(enable)))
 
     def profile_read(self) -> dict:
         """{stage: (total_ms, calls)} accumulated since the last read (HIP events on the launch stream)."""

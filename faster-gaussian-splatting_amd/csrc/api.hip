@@ -44,6 +44,7 @@ const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_
 struct StageRecord { int stage; hipEvent_t start, stop; };
 struct Profiler {
     bool enabled = false;
+    int only = -1;                     // >= 0: record this stage only (two events per launch of ONE stage perturb a timed loop far less than 30)
     std::vector<StageRecord> records;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -57,7 +58,7 @@ Profiler g_prof;
 struct StageScope {                    // records start now and stop at scope exit, both on `stream`
     hipStream_t stream; int idx = -1;
     StageScope(int stage, hipStream_t s) : stream(s) {
-        if (!g_prof.enabled) return;
+        if (!g_prof.enabled || (g_prof.only >= 0 && g_prof.only != stage)) return;
         StageRecord r{stage, g_prof.get(), g_prof.get()};
         if (!r.start || !r.stop) return;
         (void)hipEventRecord(r.start, stream);
@@ -809,6 +810,8 @@ int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width
 
 int32_t fgs_profile_enable(int32_t enable) {
     g_prof.enabled = enable != 0;
+    g_prof.only = enable >= 2 ? enable - 2 : -1;          // 1: every stage; 2 + k: stage k only (index into fgs_profile_read's table)
+    if (g_prof.only >= ST_COUNT) return fail(FGS_ERR_INVALID_ARGUMENT, "stage index %d", g_prof.only);
     return FGS_OK;
 }
 

@@ -214,7 +214,9 @@ size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height);
 int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
                           float* out3, float* grad_image, void* scratch, void* stream);
 
-/* Optional per-stage timing. While enabled, every pipeline stage is bracketed by hipEvents recorded on the caller's stream;
+/* Optional per-stage timing. While enabled (1), every pipeline stage is bracketed by hipEvents recorded on the caller's stream
+ * (each event costs a few microseconds of GPU idle time: ~0.2 ms per training iteration with all stages on); enable = 2 + k brackets
+ * only stage k (its index in the table fgs_profile_read returns), which leaves a timed loop practically undisturbed;
  * fgs_profile_read() waits for them, returns accumulated milliseconds + launch counts per stage since the last read and
  * clears the records. Not thread-safe; intended for bench.py (roofline) and tests. */
 typedef struct fgs_stage_time { const char* name; double total_ms; int64_t calls; } fgs_stage_time;
