@@ -80,3 +80,30 @@ def test_cpu_tensors_are_rejected_by_the_public_operators(hip_lib):
         B.rasterize(*[params[k] for k in helpers.NAMES], RS, True)
     with pytest.raises(RuntimeError, match='no CPU implementation'):
         B.add_noise(params['scales'], params['rotations'], params['opacities'], params['means'], 1e-3)
+
+
+def test_c_module_has_the_eight_reference_entry_points():
+    """`FasterGSCudaBackend._C` mirrors the pybind11 module of the reference (torch_bindings/bindings.cpp:12-21): same eight names,
+    same positional parameter lists (rasterization_api.h:8-106, adam.h:7-16, filter3d.h:7-20, densification_api.h:8-21)."""
+    import inspect
+    from FasterGSCudaBackend import _C
+    common = ['w2c', 'cam_position', 'bg_color', 'active_sh_bases', 'width', 'height', 'focal_x', 'focal_y', 'center_x', 'center_y',
+              'near_plane', 'far_plane', 'proper_antialiasing']
+    six = ['means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest']
+    expected = {
+        'forward': six + common,
+        'backward': ['densification_info', 'grad_image', 'image', 'means', 'scales', 'rotations', 'opacities', 'sh_coefficients_rest',
+                     'primitive_buffers', 'tile_buffers', 'instance_buffers', 'bucket_buffers'] + common +
+                    ['n_instances', 'n_buckets', 'instance_primitive_indices_selector'],
+        'inference': six + common + ['to_chw', 'clamp_output'],
+        'pruning_scores': ['scores'] + six + common,
+        'adam_step': ['param_grad', 'param', 'exp_avg', 'exp_avg_sq', 'step_count', 'learning_rate', 'beta1', 'beta2', 'epsilon'],
+        'update_3d_filter': ['positions', 'w2c', 'filter_3d', 'visibility_mask', 'width', 'height', 'focal_x', 'focal_y', 'center_x',
+                             'center_y', 'near_plane', 'clipping_tolerance', 'distance2filter'],
+        'relocation_adjustment': ['old_opacities', 'old_scales', 'n_samples_per_primitive'],
+        'add_noise': ['raw_scales', 'raw_rotations', 'raw_opacities', 'random_samples', 'means', 'current_lr'],
+    }
+    public = {n for n, f in vars(_C).items() if inspect.isfunction(f) and not n.startswith('_')}
+    assert public == set(expected), public ^ set(expected)
+    for name, params in expected.items():
+        assert list(inspect.signature(getattr(_C, name)).parameters) == params, name
