@@ -25,7 +25,8 @@ from __future__ import annotations
 
 import torch
 
-from ._backend import RasterizerSettings, default_backend
+from ._backend import RasterizerSettings
+from ._backend import default_backend as _backend
 
 
 def _settings(w2c, cam_position, bg_color, active_sh_bases, width, height, focal_x, focal_y, center_x, center_y, near_plane, far_plane,
@@ -40,7 +41,7 @@ def forward(means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor, 
             proper_antialiasing: bool):
     S = _settings(w2c, cam_position, bg_color, active_sh_bases, width, height, focal_x, focal_y, center_x, center_y, near_plane, far_plane,
                   proper_antialiasing)
-    res = default_backend().forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S)
+    res = _backend().forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S)
     _n_visible, n_instances, n_buckets, selector = res.state
     return (res.image, *res.buffers, n_instances, n_buckets, selector)
 
@@ -55,7 +56,7 @@ def backward(densification_info: torch.Tensor, grad_image: torch.Tensor, image: 
                   proper_antialiasing)
     # n_visible (state[0]) is not needed to re-derive the buffer layout (backward.cu:46-52 replays it from N, n_tiles, n_instances, n_buckets)
     state = (0, int(n_instances), int(n_buckets), int(instance_primitive_indices_selector))
-    return default_backend().backward(densification_info, grad_image, image, means, scales, rotations, opacities, sh_coefficients_rest,
+    return _backend().backward(densification_info, grad_image, image, means, scales, rotations, opacities, sh_coefficients_rest,
                                       (primitive_buffers, tile_buffers, instance_buffers, bucket_buffers), S, state)
 
 
@@ -65,7 +66,7 @@ def inference(means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor
               proper_antialiasing: bool, to_chw: bool, clamp_output: bool) -> torch.Tensor:
     S = _settings(w2c, cam_position, bg_color, active_sh_bases, width, height, focal_x, focal_y, center_x, center_y, near_plane, far_plane,
                   proper_antialiasing)
-    return default_backend().inference(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S, bool(to_chw),
+    return _backend().inference(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S, bool(to_chw),
                                        bool(clamp_output))
 
 
@@ -75,26 +76,26 @@ def pruning_scores(scores: torch.Tensor, means: torch.Tensor, scales: torch.Tens
                    center_y: float, near_plane: float, far_plane: float, proper_antialiasing: bool) -> None:
     S = _settings(w2c, cam_position, bg_color, active_sh_bases, width, height, focal_x, focal_y, center_x, center_y, near_plane, far_plane,
                   proper_antialiasing)
-    default_backend().pruning_scores(scores, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S)
+    _backend().pruning_scores(scores, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, S)
 
 
 def adam_step(param_grad: torch.Tensor, param: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step_count: int,
               learning_rate: float, beta1: float, beta2: float, epsilon: float) -> None:
-    default_backend().adam_step(param_grad, param, exp_avg, exp_avg_sq, int(step_count), float(learning_rate), float(beta1), float(beta2),
+    _backend().adam_step(param_grad, param, exp_avg, exp_avg_sq, int(step_count), float(learning_rate), float(beta1), float(beta2),
                                 float(epsilon))
 
 
 def update_3d_filter(positions: torch.Tensor, w2c: torch.Tensor, filter_3d: torch.Tensor, visibility_mask: torch.Tensor, width: int,
                      height: int, focal_x: float, focal_y: float, center_x: float, center_y: float, near_plane: float,
                      clipping_tolerance: float, distance2filter: float) -> None:
-    default_backend().update_3d_filter(positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
+    _backend().update_3d_filter(positions, w2c, filter_3d, visibility_mask, width, height, focal_x, focal_y, center_x, center_y,
                                        near_plane, clipping_tolerance, distance2filter)
 
 
 def relocation_adjustment(old_opacities: torch.Tensor, old_scales: torch.Tensor, n_samples_per_primitive: torch.Tensor):
-    return default_backend().relocation_adjustment(old_opacities, old_scales, n_samples_per_primitive)
+    return _backend().relocation_adjustment(old_opacities, old_scales, n_samples_per_primitive)
 
 
 def add_noise(raw_scales: torch.Tensor, raw_rotations: torch.Tensor, raw_opacities: torch.Tensor, random_samples: torch.Tensor,
               means: torch.Tensor, current_lr: float) -> None:
-    default_backend().add_noise(raw_scales, raw_rotations, raw_opacities, random_samples, means, float(current_lr))
+    _backend().add_noise(raw_scales, raw_rotations, raw_opacities, random_samples, means, float(current_lr))
