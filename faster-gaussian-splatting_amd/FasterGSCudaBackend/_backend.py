@@ -367,6 +367,65 @@ class Backend:
         self._check(self.lib.fgs_add_noise(_ptr(raw_scales), _ptr(raw_rotations), _ptr(raw_opacities), _ptr(random_samples), _ptr(means),
                                            means.shape[0], float(current_lr), _stream_of(device)), 'fgs_add_noise')
 
+    # -- maintenance of the Gaussian set with the Adam moments (include/fgs_hip.h, "Next" row rank 1; Model.py:275-366, 459-463) -------
+    def adaptive_density_control(self, densification_info, params: Sequence[torch.Tensor], exp_avgs, exp_avg_sqs, grad_threshold: float,
+                                 min_opacity: float, prune_large_gaussians: bool, percent_dense: float, extent: float, noise_fn=None):
+        """params (and optionally the two moment lists) in optimizer-group order: means, sh0, sh_rest, opacities, scales, rotations.
+        Returns (new_params, new_exp_avgs or None, new_exp_avg_sqs or None, counts) with counts = (survivors, clones, children per
+        copy, split). `noise_fn(n_rows)` supplies the [n_rows, 3] N(0,1) samples of the split (default torch.randn on the device)."""
+        device = self._check_params(tuple(params) + (densification_info,), ['parameter'] * 6 + ['densification_info'])
+        n = params[0].shape[0]
+        total_rest = params[2].shape[1] if params[2].dim() == 3 else 0
+        scratch = torch.empty(max(int(self.lib.fgs_adc_scratch_bytes(n)), 1), dtype=torch.uint8, device=device)
+        counts = (C.c_int32 * 4)()
+        self._check(self.lib.fgs_adc_plan(_ptr(densification_info), _ptr(params[4]), _ptr(params[5]), _ptr(params[3]), n, float(grad_threshold),
+                                          float(min_opacity), int(bool(prune_large_gaussians)), float(percent_dense), float(extent),
+                                          scratch.data_ptr(), counts, _stream_of(device)), 'fgs_adc_plan')
+        kept, clones, children, split = (int(c) for c in counts)
+        n_new = kept + clones + 2 * children
+        noise = (noise_fn(2 * split) if noise_fn is not None else torch.randn((2 * split, 3), device=device)).to(device=device, dtype=torch.float32).contiguous()
+        make = lambda t: torch.empty((n_new,) + tuple(t.shape[1:]), dtype=torch.float32, device=device)
+        out_p = [make(t) for t in params]
+        have_state = exp_avgs is not None
+        if have_state:
+            self._check_params(tuple(exp_avgs) + tuple(exp_avg_sqs), ['moment'] * 12)
+        out_m = [make(t) for t in params] if have_state else None
+        out_v = [make(t) for t in params] if have_state else None
+        arr = lambda ts: (C.c_void_p * 6)(*[_ptr(t) for t in ts]) if ts is not None else None
+        self._check(self.lib.fgs_adc_apply(arr(params), arr(exp_avgs), arr(exp_avg_sqs), arr(out_p), arr(out_m), arr(out_v), _ptr(noise),
+                                           scratch.data_ptr(), n, total_rest, _stream_of(device)), 'fgs_adc_apply')
+        return out_p, out_m, out_v, (kept, clones, children, split)
+
+    def gather_rows(self, tensors: Sequence[torch.Tensor], index: torch.Tensor) -> list:
+        """[t[index] for t in tensors] (float32, row-major) in one launch per 18 tensors: prune / sort of parameters and moments."""
+        if not tensors:
+            return []
+        device = self._check_params(tuple(tensors), ['tensor'] * len(tensors))
+        index = index.to(device=device, dtype=torch.int64).contiguous()
+        rows = index.shape[0]
+        outs = [torch.empty((rows,) + tuple(t.shape[1:]), dtype=torch.float32, device=device) for t in tensors]
+        for first in range(0, len(tensors), 18):
+            chunk, oc = tensors[first:first + 18], outs[first:first + 18]
+            k = len(chunk)
+            widths = [int(t.numel() // max(t.shape[0], 1)) if t.shape[0] > 0 else 0 for t in chunk]
+            self._check(self.lib.fgs_gather_rows(k, (C.c_void_p * k)(*[_ptr(t) for t in chunk]), (C.c_void_p * k)(*[_ptr(t) for t in oc]),
+                                                 (C.c_int32 * k)(*widths), _ptr(index), rows, _stream_of(device)), 'fgs_gather_rows')
+        return outs
+
+    def morton_order(self, means: torch.Tensor) -> torch.Tensor:
+        """int64 permutation that sorts the points along a 30-bit Z-curve over their bounding box (Model.py:459-463), stable."""
+        device = self._check_params((means,), ('means',))
+        n = means.shape[0]
+        order = torch.empty(n, dtype=torch.int64, device=device)
+        if n == 0:
+            return order
+        lo, hi = means.min(dim=0).values.contiguous(), means.max(dim=0).values.contiguous()      # stay on the device: no host sync
+        nbytes = int(self.lib.fgs_morton_order_temp_bytes(n))
+        temp = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._check(self.lib.fgs_morton_order(_ptr(means), lo.data_ptr(), hi.data_ptr(), order.data_ptr(), n, temp.data_ptr(), nbytes,
+                                              _stream_of(device)), 'fgs_morton_order')
+        return order
+
     def profile_enable(self, enable, only: str | None = None) -> None:
         """enable=True: HIP events around every stage; only='adam': around that one stage (far less intrusive); False: off."""
         if enable and only is not None:

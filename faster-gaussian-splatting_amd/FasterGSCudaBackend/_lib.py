@@ -72,6 +72,12 @@ _SIGNATURES = {
     'fgs_relocation_table': (C.c_int32, [C.POINTER(C.c_float)]),
     'fgs_relocation_adjustment': (C.c_int32, [_P] * 6 + [_I32, _P]),
     'fgs_add_noise': (C.c_int32, [_P] * 5 + [_I32, C.c_float, _P]),
+    'fgs_adc_scratch_bytes': (C.c_size_t, [_I32]),
+    'fgs_adc_plan': (C.c_int32, [_P] * 4 + [_I32, C.c_float, C.c_float, _I32, C.c_float, C.c_float, _P, C.POINTER(_I32), _P]),
+    'fgs_adc_apply': (C.c_int32, [C.POINTER(_P)] * 6 + [_P, _P, _I32, _I32, _P]),
+    'fgs_gather_rows': (C.c_int32, [_I32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I32), _P, _I32, _P]),
+    'fgs_morton_order_temp_bytes': (C.c_size_t, [_I32]),
+    'fgs_morton_order': (C.c_int32, [_P, _P, _P, _P, _I32, _P, C.c_size_t, _P]),
     'fgs_l1_dssim_scratch_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_l1_dssim_loss': (C.c_int32, [_P, _P, _I32, _I32, C.c_float, C.c_float, _P, _P, _P, _P]),
     'fgs_profile_enable': (C.c_int32, [_I32]),

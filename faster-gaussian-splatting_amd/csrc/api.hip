@@ -790,6 +790,113 @@ int32_t fgs_add_noise(const float* raw_scales, const float* raw_rotations, const
     return FGS_OK;
 }
 
+// ---- maintenance of the Gaussian set on the device (densify.hip; Model.py:275-366, 459-463) ----
+namespace {
+struct AdcScratch {
+    uint32_t* plan; uint4* offsets; uint32_t* totals; char* scan_temp; size_t scan_temp_bytes;
+    static AdcScratch carve(Carver& c, uint32_t n) {
+        AdcScratch b;
+        b.plan = c.take<uint32_t>("plan", n);
+        b.offsets = c.take<uint4>("offsets", n);
+        b.totals = c.take<uint32_t>("totals", 4);
+        b.scan_temp_bytes = adc_scan_temp_bytes(n);
+        b.scan_temp = c.take<char>("scan_temp", b.scan_temp_bytes);
+        return b;
+    }
+};
+}  // namespace
+
+size_t fgs_adc_scratch_bytes(int32_t n_primitives) {
+    if (n_primitives < 0) return 0;
+    Carver c(nullptr);
+    AdcScratch::carve(c, static_cast<uint32_t>(n_primitives));
+    return c.total();
+}
+
+int32_t fgs_adc_plan(const float* densification_info, const float* scales, const float* rotations, const float* opacities, int32_t n_primitives,
+                     float grad_threshold, float min_opacity, int32_t prune_large_gaussians, float percent_dense, float extent,
+                     void* scratch, int32_t* counts_out, void* stream_) {
+    if (n_primitives < 0 || !counts_out || !scratch) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n_primitives > 0 && (!densification_info || !scales || !rotations || !opacities)) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL tensor");
+    if (!(min_opacity > 0.0f && min_opacity < 1.0f) || !(percent_dense * extent > 0.0f)) return fail(FGS_ERR_INVALID_ARGUMENT, "min_opacity / percent_dense * extent out of range");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Carver c(scratch);
+    const AdcScratch sc = AdcScratch::carve(c, static_cast<uint32_t>(n_primitives));
+    AdcPlanArgs a{};
+    a.densification_info = densification_info; a.scales = scales; a.rotations = rotations; a.opacities = opacities;
+    a.n = static_cast<uint32_t>(n_primitives);
+    a.grad_threshold = grad_threshold;
+    a.min_opacity_logit = static_cast<float>(std::log(static_cast<double>(min_opacity) / (1.0 - static_cast<double>(min_opacity))));   // Model.py:360
+    a.log_small = static_cast<float>(std::log(static_cast<double>(percent_dense) * static_cast<double>(extent)));                         // :315
+    a.log_large = static_cast<float>(std::log(0.1 * static_cast<double>(extent)));                                                         // :363
+    a.prune_large = prune_large_gaussians ? 1 : 0;
+    a.plan = sc.plan; a.offsets = sc.offsets; a.totals = sc.totals; a.scan_temp = sc.scan_temp; a.scan_temp_bytes = sc.scan_temp_bytes;
+    FGS_HIP(launch_adc_plan(a, stream));
+    uint32_t host[4] = {0, 0, 0, 0};
+    FGS_HIP(hipMemcpyAsync(host, sc.totals, sizeof(host), hipMemcpyDeviceToHost, stream));     // the caller sizes the new tensors from these
+    FGS_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < 4; ++k) counts_out[k] = static_cast<int32_t>(host[k]);
+    return FGS_OK;
+}
+
+int32_t fgs_adc_apply(const float* const* params, const float* const* exp_avgs, const float* const* exp_avg_sqs,
+                      float* const* out_params, float* const* out_exp_avgs, float* const* out_exp_avg_sqs,
+                      const float* noise, const void* scratch, int32_t n_primitives, int32_t total_sh_bases_rest, void* stream_) {
+    if (n_primitives < 0 || !params || !out_params || !scratch || total_sh_bases_rest < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    if ((exp_avgs == nullptr) != (exp_avg_sqs == nullptr) || (exp_avgs && (!out_exp_avgs || !out_exp_avg_sqs))) return fail(FGS_ERR_INVALID_ARGUMENT, "moments: all four arrays or none");
+    if (n_primitives == 0) return FGS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Carver c(const_cast<void*>(scratch));
+    const AdcScratch sc = AdcScratch::carve(c, static_cast<uint32_t>(n_primitives));
+    // optimizer-group order (Model.py:238-245): means, sh0, sh_rest, opacities, scales, rotations
+    const uint32_t width[6] = {3u, 3u, 3u * static_cast<uint32_t>(total_sh_bases_rest), 1u, 3u, 4u};
+    const int kind[6] = {1, 0, 0, 0, 2, 0};
+    for (int k = 0; k < 6; ++k) {
+        if (width[k] == 0) continue;
+        if (!params[k] || !out_params[k]) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL tensor in group %d", k);
+        AdcScatterArgs a{};
+        a.in_p = params[k]; a.out_p = out_params[k];
+        if (exp_avgs && exp_avgs[k]) {
+            if (!exp_avg_sqs[k] || !out_exp_avgs[k] || !out_exp_avg_sqs[k]) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL moment tensor in group %d", k);
+            a.in_m = exp_avgs[k]; a.in_v = exp_avg_sqs[k]; a.out_m = out_exp_avgs[k]; a.out_v = out_exp_avg_sqs[k];
+        }
+        a.scales = params[4]; a.rotations = params[5]; a.noise = noise;
+        a.plan = sc.plan; a.offsets = sc.offsets; a.totals = sc.totals;
+        a.n = static_cast<uint32_t>(n_primitives); a.width = width[k];
+        FGS_HIP(launch_adc_scatter(kind[k], a, stream));
+    }
+    return FGS_OK;
+}
+
+int32_t fgs_gather_rows(int32_t n_tensors, const float* const* in, float* const* out, const int32_t* widths, const int64_t* index,
+                        int32_t n_rows, void* stream) {
+    if (n_tensors < 0 || n_tensors > kGatherTensors || n_rows < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "n_tensors %d (max %d) / n_rows %d", n_tensors, kGatherTensors, n_rows);
+    if (n_rows == 0 || n_tensors == 0) return FGS_OK;
+    if (!in || !out || !widths || !index) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL argument");
+    GatherArgs a{};
+    for (int k = 0; k < n_tensors; ++k) {
+        if (widths[k] < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "tensor %d: width %d", k, widths[k]);
+        if (widths[k] == 0) continue;
+        if (!in[k] || !out[k]) return fail(FGS_ERR_INVALID_ARGUMENT, "tensor %d: NULL", k);
+        GatherTensor& t = a.t[a.n_tensors++];
+        t.in = in[k]; t.out = out[k]; t.width = static_cast<uint32_t>(widths[k]);
+    }
+    a.n_rows = static_cast<uint32_t>(n_rows); a.index = index;
+    FGS_HIP(launch_gather_rows(a, static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
+size_t fgs_morton_order_temp_bytes(int32_t n_points) { return n_points < 0 ? 0 : morton_temp_bytes(static_cast<uint32_t>(n_points)); }
+
+int32_t fgs_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, int32_t n_points, void* temp, size_t temp_bytes,
+                         void* stream) {
+    if (n_points < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "n_points %d", n_points);
+    if (n_points == 0) return FGS_OK;
+    if (!means || !lo || !hi || !order_out || !temp || temp_bytes < morton_temp_bytes(static_cast<uint32_t>(n_points))) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL / short buffer");
+    FGS_HIP(run_morton_order(means, lo, hi, order_out, static_cast<uint32_t>(n_points), temp, temp_bytes, static_cast<hipStream_t>(stream)));
+    return FGS_OK;
+}
+
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
     return sizeof(float) * (9 * static_cast<size_t>(width) * static_cast<size_t>(height) + l1_dssim_partials(width, height));

@@ -159,6 +159,32 @@ hipError_t launch_relocation(const float* old_opacities, const float* old_scales
 hipError_t launch_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
                             float* means, unsigned n, float current_lr, hipStream_t s);
 
+// densify.hip: maintenance of the Gaussian set (adaptive density control, prune / sort gathers, Morton order) with the Adam moments
+struct AdcPlanArgs {
+    const float* densification_info;      // [2, N]
+    const float* scales; const float* rotations; const float* opacities;
+    uint32_t n;
+    float grad_threshold, min_opacity_logit, log_small, log_large; int prune_large;
+    uint32_t* plan; uint4* offsets; uint32_t* totals;      // scratch: [N], [N], [4] = survivors, clones, children per copy, split
+    void* scan_temp; size_t scan_temp_bytes;
+};
+size_t adc_scan_temp_bytes(uint32_t n);
+hipError_t launch_adc_plan(const AdcPlanArgs& a, hipStream_t s);
+struct AdcScatterArgs {
+    const float* in_p; const float* in_m; const float* in_v;     // moments may be NULL (no optimizer state yet)
+    float* out_p; float* out_m; float* out_v;
+    const float* scales; const float* rotations; const float* noise;   // KIND 1 (means) only; noise [2 * n_split, 3]
+    const uint32_t* plan; const uint4* offsets; const uint32_t* totals;
+    uint32_t n, width;
+};
+hipError_t launch_adc_scatter(int kind, const AdcScatterArgs& a, hipStream_t s);
+constexpr int kGatherTensors = 18;
+struct GatherTensor { const float* in; float* out; uint32_t width; uint32_t first_block; };
+struct GatherArgs { GatherTensor t[kGatherTensors]; int n_tensors; uint32_t n_rows; const int64_t* index; };
+hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
+size_t morton_temp_bytes(uint32_t n);
+hipError_t run_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
+
 extern int g_adam_nontemporal;                                  // 0 | 1
 extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
 extern int g_backward_ablate;

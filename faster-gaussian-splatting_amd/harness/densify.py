@@ -1,12 +1,17 @@
-"""Caller-side maintenance of the Gaussian set, restated from the reference's Model.py with plain
-device-side torch ops: adaptive density control (clone / split / prune), opacity reset, Morton re-ordering, SH degree
-schedule -- including the Adam-state surgery that NeRFICG's `Optim.adam_utils` helpers perform in the reference
-(`extend_param_groups`, `prune_param_groups`, `sort_param_groups`, `replace_param_group_data`; not vendored, semantics as in
-the original 3DGS code base: new entries start with zero moments, pruned/sorted entries keep theirs, replaced data resets
-its moments).
+"""Caller-side maintenance of the Gaussian set, following the reference's Model.py: adaptive density control
+(clone / split / prune), pruning, re-ordering, Morton order, opacity reset, SH degree schedule -- including the Adam-state surgery that
+NeRFICG's `Optim.adam_utils` helpers perform in the reference (`extend_param_groups`, `prune_param_groups`, `sort_param_groups`,
+`replace_param_group_data`; not vendored, semantics as in the original 3DGS code base: new entries start with zero moments,
+pruned/sorted entries keep theirs, replaced data resets its moments).
 
-Runs every 100 iterations, not per iteration (Trainer.py:120-139), so it is not a hot-path kernel; it consumes the
-`densification_info[2,N]` statistics that the backward pass accumulates (kernels_backward.cuh:194-201).
+On a ROCm device (or whenever a backend is passed as `ops_backend`) adaptive density control, prune, sort and the Morton order run as
+the device passes of csrc/densify.hip (classify -> scan -> one scatter of the 59 parameters and 2 x 59 moments per Gaussian; one
+gather launch for prune / sort; key + radix sort for Morton): every tensor is read once and written once. The torch-op formulation of
+the reference (mask / index / cat chains, ~80 ms per call at 0.5 M Gaussians in round 1) is kept for CPU tensors, where it doubles as
+the readable restatement of Model.py:312-366 that the CPU tests check.
+
+Runs every 100 iterations (Trainer.py:120-139); consumes the `densification_info[2,N]` statistics that the backward pass accumulates
+(kernels_backward.cuh:194-201).
 """
 from __future__ import annotations
 
@@ -31,7 +36,40 @@ def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
 
 
-def _rebind(g: Gaussians, new: dict, state_fn) -> None:
+def _device_backend(g: Gaussians, ops_backend=None):
+    """The backend whose densify.hip passes serve `g`: the one given, else the HIP library for device tensors, else None (torch ops)."""
+    if ops_backend is not None:
+        return ops_backend
+    if g.means.is_cuda:
+        from FasterGSCudaBackend._backend import default_backend
+        return default_backend()
+    return None
+
+
+def _moments(g: Gaussians):
+    """(exp_avgs, exp_avg_sqs) in PARAM_ORDER if every group has optimizer state, else (None, None)."""
+    opt = g.optimizer
+    if opt is None:
+        return None, None
+    states = [opt.state.get(group['params'][0]) for group in opt.param_groups]
+    if not all(states):
+        return None, None
+    by_name = {group['name']: st for group, st in zip(opt.param_groups, states)}
+    return [by_name[k]['exp_avg'] for k in PARAM_ORDER], [by_name[k]['exp_avg_sq'] for k in PARAM_ORDER]
+
+
+def _adopt(g: Gaussians, new_params, new_m, new_v) -> None:
+    """Installs new parameter tensors (PARAM_ORDER lists) and, if given, their moments; step counts are kept."""
+    pm = dict(zip(PARAM_ORDER, new_params))
+    mm = dict(zip(PARAM_ORDER, new_m)) if new_m is not None else None
+    vm = dict(zip(PARAM_ORDER, new_v)) if new_v is not None else None
+    if mm is not None:
+        _rebind(g, pm, None, moments=(mm, vm))
+    else:
+        _rebind(g, pm, lambda s, k: s)
+
+
+def _rebind(g: Gaussians, new: dict, state_fn, moments=None) -> None:
     """Replaces the six parameters (and their optimizer state via state_fn(old_state_tensor, name)) in place."""
     opt = g.optimizer
     for group in (opt.param_groups if opt is not None else []):
@@ -39,7 +77,9 @@ def _rebind(g: Gaussians, new: dict, state_fn) -> None:
         old = group['params'][0]
         param = torch.nn.Parameter(new[name].contiguous())
         state = opt.state.pop(old, None)
-        if state:
+        if state and moments is not None:
+            opt.state[param] = {'step': state['step'], 'exp_avg': moments[0][name], 'exp_avg_sq': moments[1][name]}
+        elif state:
             opt.state[param] = {'step': state['step'], 'exp_avg': state_fn(state['exp_avg'], name).contiguous(),
                                 'exp_avg_sq': state_fn(state['exp_avg_sq'], name).contiguous()}
         group['params'][0] = param
@@ -55,23 +95,43 @@ def extend(g: Gaussians, extra: dict) -> None:
     _rebind(g, new, lambda s, k: torch.cat([s, torch.zeros_like(extra[k])]))
 
 
-def prune(g: Gaussians, prune_mask: torch.Tensor) -> None:
+def _gather(g: Gaussians, index: torch.Tensor, be) -> None:
+    """Parameters and both moments through an index list in ONE gather launch (csrc/densify.hip)."""
+    params = [getattr(g, k).detach() for k in PARAM_ORDER]
+    m, v = _moments(g)
+    outs = be.gather_rows(params + (m or []) + (v or []), index)
+    _adopt(g, outs[:6], outs[6:12] if m else None, outs[12:18] if m else None)
+    if g.densification_info is not None:
+        g.densification_info = g.densification_info[:, index].contiguous()
+
+
+def prune(g: Gaussians, prune_mask: torch.Tensor, ops_backend=None) -> None:
     """Model.py:275-291."""
     keep = ~prune_mask
+    be = _device_backend(g, ops_backend)
+    if be is not None:
+        return _gather(g, torch.nonzero(keep).flatten(), be)
     _rebind(g, {k: getattr(g, k).detach()[keep] for k in PARAM_ORDER}, lambda s, k: s[keep])
     if g.densification_info is not None:
         g.densification_info = g.densification_info[:, keep].contiguous()
 
 
-def sort(g: Gaussians, ordering: torch.Tensor) -> None:
+def sort(g: Gaussians, ordering: torch.Tensor, ops_backend=None) -> None:
     """Model.py:293-306."""
+    be = _device_backend(g, ops_backend)
+    if be is not None:
+        return _gather(g, ordering, be)
     _rebind(g, {k: getattr(g, k).detach()[ordering] for k in PARAM_ORDER}, lambda s, k: s[ordering])
     if g.densification_info is not None:
         g.densification_info = g.densification_info[:, ordering].contiguous()
 
 
-def apply_morton_ordering(g: Gaussians) -> None:
-    """Model.py:459-463 (CudaUtils.MortonEncoding replaced by harness.scenes.morton_order)."""
+def apply_morton_ordering(g: Gaussians, ops_backend=None) -> None:
+    """Model.py:459-463 (CudaUtils.MortonEncoding is not vendored: the 10-bit-per-axis Z-curve of harness.scenes.morton_order, as
+    key + radix-sort passes on the device)."""
+    be = _device_backend(g, ops_backend)
+    if be is not None:
+        return sort(g, be.morton_order(g.means.detach()), be)
     sort(g, morton_order(g.means.detach().cpu()).to(g.means.device))
 
 
@@ -88,8 +148,23 @@ def reset_opacities(g: Gaussians) -> None:
 
 
 def adaptive_density_control(g: Gaussians, grad_threshold: float, min_opacity: float, prune_large_gaussians: bool,
-                             percent_dense: float = 0.01, generator: torch.Generator | None = None) -> dict:
+                             percent_dense: float = 0.01, generator: torch.Generator | None = None, ops_backend=None) -> dict:
     """Model.py:312-366: clone small / split large Gaussians whose mean screen-space gradient exceeds the threshold, then prune."""
+    be = _device_backend(g, ops_backend)
+    if be is not None:
+        params = [getattr(g, k).detach() for k in PARAM_ORDER]
+        m, v = _moments(g)
+        dev = g.means.device
+        noise_fn = None
+        if generator is not None:      # reproducible runs: the samples come from the given generator (CPU generators feed the device tensor)
+            noise_fn = lambda rows: torch.randn((rows, 3), generator=generator, device=generator.device).to(dev)
+        new_p, new_m, new_v, (kept, clones, children, split) = be.adaptive_density_control(
+            g.densification_info, params, m, v, grad_threshold, min_opacity, prune_large_gaussians, percent_dense, g.extent, noise_fn)
+        n_old = params[0].shape[0]
+        _adopt(g, new_p, new_m, new_v)
+        g.densification_info = None                                                        # Model.py:353-355
+        # cloned / children_per_copy count what SURVIVED the pruning that follows the densification; pruned = old Gaussians that are gone
+        return {'cloned': clones, 'split': split, 'pruned': n_old - kept, 'total': g.means.shape[0], 'kept': kept, 'children_per_copy': children}
     info = g.densification_info
     extent = g.extent
     means, scales, rotations = g.means.detach(), g.scales.detach(), g.rotations.detach()

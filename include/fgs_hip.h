@@ -205,6 +205,37 @@ int32_t fgs_relocation_adjustment(const float* old_opacities, const float* old_s
 int32_t fgs_add_noise(const float* raw_scales, const float* raw_rotations, const float* raw_opacities, const float* random_samples,
                       float* means, int32_t n_primitives, float current_lr, void* stream);
 
+/* "Next" row: maintenance of the Gaussian set between iterations, on the device and INCLUDING the Adam moments
+ * (the reference runs Model.py:275-366, 459-463 as torch mask / index / cat chains plus NeRFICG's extend / prune / sort_param_groups).
+ *
+ * Adaptive density control (Model.py:312-366) in two calls, because the caller owns the new tensors and must size them:
+ *   fgs_adc_plan   classifies every Gaussian (clone if small, split if large, above the mean-gradient threshold; prune by opacity,
+ *                  degenerate rotation and -- optionally -- size; the verdict for new Gaussians is taken on the values they will have)
+ *                  and scans the plan. counts_out [host, 4]: surviving old Gaussians, surviving clones, surviving children PER COPY
+ *                  (two copies), Gaussians that are split. New size = counts[0] + counts[1] + 2 * counts[2]. Synchronises the stream.
+ *   fgs_adc_apply  writes the new parameter tensors and Adam moments (arrays of 6 in optimizer-group order means, sh_coefficients_0,
+ *                  sh_coefficients_rest, opacities, scales, rotations; exp_avgs / exp_avg_sqs and their outputs may all be NULL): survivors
+ *                  in their order with their moments, then clones, then first children, then second children, all with zero moments.
+ *                  Children: means + R(q) (exp(s) * noise) with noise [2 * counts[3], 3] ~ N(0,1) from the caller (row = copy * counts[3]
+ *                  + rank among the split Gaussians, the layout of the reference's randn_like), scales log(0.625 exp(s)).
+ * scratch: fgs_adc_scratch_bytes(n) bytes, the same buffer for both calls. */
+size_t fgs_adc_scratch_bytes(int32_t n_primitives);
+int32_t fgs_adc_plan(const float* densification_info, const float* scales, const float* rotations, const float* opacities, int32_t n_primitives,
+                     float grad_threshold, float min_opacity, int32_t prune_large_gaussians, float percent_dense, float extent,
+                     void* scratch, int32_t* counts_out, void* stream);
+int32_t fgs_adc_apply(const float* const* params, const float* const* exp_avgs, const float* const* exp_avg_sqs,
+                      float* const* out_params, float* const* out_exp_avgs, float* const* out_exp_avg_sqs,
+                      const float* noise, const void* scratch, int32_t n_primitives, int32_t total_sh_bases_rest, void* stream);
+/* out[k][r, :] = in[k][index[r], :] for k < n_tensors <= 18 float tensors of row widths widths[k] in ONE launch: prune (index = the
+ * survivors, Model.py:275-291) and sort (index = the ordering, :293-306) of the six parameters and their twelve moment tensors. */
+int32_t fgs_gather_rows(int32_t n_tensors, const float* const* in, float* const* out, const int32_t* widths, const int64_t* index,
+                        int32_t n_rows, void* stream);
+/* Morton order of the means (Model.py:459-463): order_out[r] = index of the r-th point along a 30-bit Z-curve over the box lo..hi
+ * ([device] 3 floats each; 10 bits per axis, x most significant), equal keys in index order (stable). */
+size_t fgs_morton_order_temp_bytes(int32_t n_points);
+int32_t fgs_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, int32_t n_points, void* temp, size_t temp_bytes,
+                         void* stream);
+
 /* "Next" row: the loss between forward and backward of every iteration,
  *   loss = lambda_l1 * mean|image - target| + lambda_dssim * (1 - SSIM(image, target))        (Loss.py:15-16, Trainer.py:52-53)
  * replacing torch.nn.functional.l1_loss + NeRFICG's fused_dssim (Optim/Losses/DSSIM.py, not vendored). Writes three device

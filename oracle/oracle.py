@@ -326,3 +326,73 @@ def add_noise(raw_scales, raw_rotations, raw_opacities, random_samples, means, c
     opacity = f(1.0) / (f(1.0) + np.exp(-o))
     factor = f(current_lr) * (f(1.0) / (f(1.0) + np.exp(f(100.0) * opacity - f(0.5))))
     means[ok] += (factor[:, None] * t)[ok]
+
+
+# ---- maintenance of the Gaussian set, restated in numpy fp32 -------------------------------------------------
+def adaptive_density_control(params: dict, exp_avgs: dict | None, exp_avg_sqs: dict | None, densification_info: np.ndarray, noise: np.ndarray,
+                             grad_threshold: float, min_opacity: float, prune_large_gaussians: bool, percent_dense: float, extent: float):
+    """Model.py:312-366 line by line (with extend_param_groups / prune_param_groups of the un-vendored NeRFICG Optim.adam_utils: new
+    entries get zero moments, survivors keep theirs). params / moments: dicts of float32 arrays keyed means, sh_coefficients_0,
+    sh_coefficients_rest, opacities, scales, rotations; noise: the [2 * n_split, 3] samples of Model.py:331's randn_like.
+    Returns (new_params, new_exp_avgs, new_exp_avg_sqs, counts) with counts = (survivors, surviving clones, surviving children per copy, split)."""
+    f = np.float32
+    keys = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
+    P = {k: _f32(params[k]) for k in keys}
+    info = _f32(densification_info)
+    scales, rotations = P['scales'], P['rotations']
+    densification_mask = info[1] >= f(grad_threshold) * np.maximum(info[0], f(1.0))                                         # :314
+    is_small = scales.max(axis=1) <= f(np.log(percent_dense * extent))                                                        # :315
+    duplicate_mask = densification_mask & is_small                                                                            # :318
+    split_mask = densification_mask & ~is_small                                                                               # :328
+    n_split = int(split_mask.sum())
+    split_scales = np.tile(np.exp(scales[split_mask]), (2, 1))                                                                # :330  expand(2,...).flatten
+    split_rotations = np.tile(rotations[split_mask], (2, 1))                                                                  # :331
+    q = split_rotations / np.sqrt((split_rotations * split_rotations).sum(axis=1, keepdims=True))                             # quaternion_to_rotation_matrix
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([f(1) - f(2) * (y * y + z * z), f(2) * (x * y - r * z), f(2) * (x * z + r * y),
+                  f(2) * (x * y + r * z), f(1) - f(2) * (x * x + z * z), f(2) * (y * z - r * x),
+                  f(2) * (x * z - r * y), f(2) * (y * z + r * x), f(1) - f(2) * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    t = split_scales * _f32(noise).reshape(2 * n_split, 3)
+    offsets = (R[:, :, 0] * t[:, None, 0] + R[:, :, 1] * t[:, None, 1]) + R[:, :, 2] * t[:, None, 2]                         # :332 (R @ t)
+    extra = {
+        'means': np.concatenate([P['means'][duplicate_mask], np.tile(P['means'][split_mask], (2, 1)) + offsets]),          # :333
+        'sh_coefficients_0': np.concatenate([P['sh_coefficients_0'][duplicate_mask], np.tile(P['sh_coefficients_0'][split_mask], (2, 1, 1))]),
+        'sh_coefficients_rest': np.concatenate([P['sh_coefficients_rest'][duplicate_mask], np.tile(P['sh_coefficients_rest'][split_mask], (2, 1, 1))]),
+        'opacities': np.concatenate([P['opacities'][duplicate_mask], np.tile(P['opacities'][split_mask], (2, 1))]),
+        'scales': np.concatenate([scales[duplicate_mask], np.log(split_scales * f(0.625))]),                                 # :334
+        'rotations': np.concatenate([rotations[duplicate_mask], split_rotations]),
+    }
+    n_new = extra['means'].shape[0]
+    full = {k: np.concatenate([P[k], extra[k]]) for k in keys}                                                                # :340-347 extend_param_groups
+    prune_mask = np.concatenate([split_mask, np.zeros(n_new, bool)])                                                          # :359
+    prune_mask |= full['opacities'].reshape(-1) < f(np.log(min_opacity / (1 - min_opacity)))                                  # :360
+    prune_mask |= (full['rotations'] * full['rotations']).sum(axis=1) < f(1e-8)                                               # :361
+    if prune_large_gaussians:
+        prune_mask |= full['scales'].max(axis=1) > f(np.log(0.1 * extent))                                                    # :362-363
+    keep = ~prune_mask                                                                                                        # :364 prune()
+    new_p = {k: np.ascontiguousarray(full[k][keep]) for k in keys}
+    new_m = new_v = None
+    if exp_avgs is not None:
+        new_m = {k: np.ascontiguousarray(np.concatenate([_f32(exp_avgs[k]), np.zeros_like(extra[k])])[keep]) for k in keys}
+        new_v = {k: np.ascontiguousarray(np.concatenate([_f32(exp_avg_sqs[k]), np.zeros_like(extra[k])])[keep]) for k in keys}
+    n_old, n_dup = P['means'].shape[0], int(duplicate_mask.sum())
+    counts = (int(keep[:n_old].sum()), int(keep[n_old:n_old + n_dup].sum()), int(keep[n_old + n_dup:n_old + n_dup + n_split].sum()), n_split)
+    return new_p, new_m, new_v, counts
+
+
+def morton_order(means: np.ndarray) -> np.ndarray:
+    """Model.py:459-463 with the 30-bit Z-curve that stands in for NeRFICG's CudaUtils.MortonEncoding (harness/scenes.py:67-80):
+    10 bits per axis over the bounding box, x most significant, stable argsort."""
+    f = np.float32
+    m = _f32(means)
+    lo, hi = m.min(axis=0), m.max(axis=0)
+    q = ((m - lo) / np.maximum(hi - lo, f(1e-12)) * f(1023.0)).astype(np.int64).clip(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    code = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+    return np.argsort(code, kind='stable')

@@ -2,11 +2,15 @@
 CPU tests of the tensor semantics; the GPU end-to-end run is tests/test_gpu_training.py."""
 import math
 
+import numpy as np
+import pytest
+
 import torch
 
 import helpers  # noqa: F401  (sets up import paths)
 from harness import densify as D
 from harness.scenes import make_s0
+from harness import trainer as T
 from harness.trainer import PARAM_ORDER, Gaussians
 
 
@@ -218,3 +222,95 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
     for ga, gb in zip(a.optimizer.param_groups, b.optimizer.param_groups):
         sa, sb = a.optimizer.state[ga['params'][0]], b.optimizer.state[gb['params'][0]]
         assert sa['step'] == sb['step'] == 5 and torch.equal(sa['exp_avg'], sb['exp_avg']) and ga['lr'] == gb['lr']
+
+
+# ---- the device passes of csrc/densify.hip (through the CPU simulation of the library) against the numpy restatement of Model.py ----
+ORDER = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
+
+
+def _adc_case(n=700, seed=4, device='cpu'):
+    """A scene in which every branch of Model.py:312-366 fires: clones, splits, dead opacities, degenerate rotations, oversized Gaussians."""
+    params, _ = make_s0(seed=seed, n=n)
+    gen = torch.Generator().manual_seed(seed)
+    params['scales'][: n // 3] += 2.0                                   # large ones: split candidates / too large after the opacity reset
+    params['scales'][n // 3: n // 3 + 20] += 3.2                        # oversized (pruned when prune_large_gaussians)
+    params['opacities'][5:n:17] = -7.0                                  # dead
+    params['rotations'][9:n:41] = 0.0                                   # degenerate
+    info = torch.zeros(2, n)
+    info[0] = torch.randint(0, 30, (n,), generator=gen).float()
+    info[1] = torch.rand(n, generator=gen) * 6e-4 * info[0].clamp_min(1.0)      # mean gradients around the 2e-4 threshold
+    m = {k: torch.randn(params[k].shape, generator=gen) * 1e-3 for k in ORDER}
+    v = {k: torch.rand(params[k].shape, generator=gen) * 1e-6 for k in ORDER}
+    return {k: params[k].to(device) for k in ORDER}, {k: m[k].to(device) for k in ORDER}, {k: v[k].to(device) for k in ORDER}, info.to(device)
+
+
+def check_adc_against_restatement(be, oracle, device, n=700, prune_large=True, with_state=True, atol=0.0):
+    P, M, V, info = _adc_case(n=n, device=device)
+    noise_holder = {}
+
+    def noise_fn(rows):
+        noise_holder['z'] = torch.randn((rows, 3), generator=torch.Generator().manual_seed(11))
+        return noise_holder['z'].to(device)
+    out_p, out_m, out_v, counts = be.adaptive_density_control(info, [P[k] for k in ORDER], [M[k] for k in ORDER] if with_state else None,
+                                                              [V[k] for k in ORDER] if with_state else None, 2e-4, 0.005, prune_large, 0.01, 5.0, noise_fn)
+    np_of = lambda d: {k: d[k].cpu().numpy() for k in ORDER}
+    ref_p, ref_m, ref_v, ref_counts = oracle.adaptive_density_control(np_of(P), np_of(M) if with_state else None, np_of(V) if with_state else None,
+                                                                      info.cpu().numpy(), noise_holder['z'].numpy(), 2e-4, 0.005, prune_large, 0.01, 5.0)
+    assert counts == ref_counts and min(counts) > 0, (counts, ref_counts)
+    for i, k in enumerate(ORDER):
+        a = out_p[i].cpu().numpy()
+        assert a.shape == ref_p[k].shape, k
+        if k in ('means', 'scales'):      # children: exp / log / sqrt of different libms; everything else is a copy
+            assert np.abs(a - ref_p[k]).max() <= 2e-6 * (1.0 + np.abs(ref_p[k]).max()) + atol, k
+        else:
+            assert np.array_equal(a, ref_p[k]), k
+        if with_state:
+            assert np.array_equal(out_m[i].cpu().numpy(), ref_m[k]) and np.array_equal(out_v[i].cpu().numpy(), ref_v[k]), k
+    return counts
+
+
+@pytest.mark.parametrize('prune_large,with_state', [(True, True), (False, True), (True, False)])
+def test_device_adaptive_density_control_matches_model_py(sim_backend, oracle, prune_large, with_state):
+    check_adc_against_restatement(sim_backend, oracle, 'cpu', prune_large=prune_large, with_state=with_state)
+
+
+def test_device_gather_and_morton_order(sim_backend, oracle):
+    P, M, V, _ = _adc_case(n=500)
+    order = sim_backend.morton_order(P['means'])
+    assert np.array_equal(order.numpy(), oracle.morton_order(P['means'].numpy()))                  # Model.py:459-463
+    idx = torch.randperm(500, generator=torch.Generator().manual_seed(1))[:321]
+    tensors = [P[k] for k in ORDER] + [M[k] for k in ORDER] + [V[k] for k in ORDER] + [P['means']]   # 19 tensors: two launches
+    outs = sim_backend.gather_rows(tensors, idx)
+    for t, o in zip(tensors, outs):
+        assert torch.equal(o, t[idx])
+
+
+def test_harness_densify_uses_the_device_passes(sim_backend):
+    """harness.densify with a backend: same Gaussians as the torch-op formulation of Model.py:312-366, moments carried along."""
+    params, _ = make_s0(seed=2, n=300)
+    info = torch.zeros(2, 300); info[0] = 10.0; info[1, :60] = 10.0 * 1e-3
+    make = lambda: T.Gaussians({k: v.clone() for k, v in params.items()}, 'cpu')
+    ga, gb = make(), make()
+    for g in (ga, gb):
+        g.training_setup(training_cameras_extent=5.0)
+        for group in g.optimizer.param_groups:
+            p = group['params'][0]
+            g.optimizer.state[p] = {'step': 3, 'exp_avg': torch.full_like(p, 0.5), 'exp_avg_sq': torch.full_like(p, 0.25)}
+        g.densification_info = info.clone()
+    sa = D.adaptive_density_control(ga, 2e-4, 0.005, True, generator=torch.Generator().manual_seed(5))
+    sb = D.adaptive_density_control(gb, 2e-4, 0.005, True, generator=torch.Generator().manual_seed(5), ops_backend=sim_backend)
+    assert sa['total'] == sb['total'] and sa['split'] == sb['split'] and gb.densification_info is None
+    for k in ORDER:
+        assert torch.allclose(getattr(ga, k), getattr(gb, k), rtol=0, atol=2e-6), k
+        sta, stb = ga.optimizer.state[getattr(ga, k)], gb.optimizer.state[getattr(gb, k)]
+        assert torch.equal(sta['exp_avg'], stb['exp_avg']) and torch.equal(sta['exp_avg_sq'], stb['exp_avg_sq']) and stb['step'] == 3
+    # re-ordering and pruning start from bit-identical sets (the split children above differ in the last bit between libms)
+    with torch.no_grad():
+        for k in ORDER:
+            getattr(ga, k).copy_(getattr(gb, k))
+    D.apply_morton_ordering(ga)
+    D.apply_morton_ordering(gb, ops_backend=sim_backend)
+    assert torch.equal(ga.means, gb.means) and torch.equal(ga.optimizer.state[ga.means]['exp_avg'], gb.optimizer.state[gb.means]['exp_avg'])
+    mask = torch.zeros(ga.means.shape[0], dtype=torch.bool); mask[::3] = True
+    D.prune(ga, mask); D.prune(gb, mask, ops_backend=sim_backend)
+    assert torch.equal(ga.sh_coefficients_rest, gb.sh_coefficients_rest)
