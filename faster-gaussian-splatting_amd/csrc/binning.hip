@@ -145,23 +145,23 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     if (pending != 0) {
         const float4* rr = reinterpret_cast<const float4*>(rec + prim);
         const float4 r0 = rr[0], r1 = rr[1];
-        const float sx = r0.x - 0.5f, sy = r0.y - 0.5f;
-        const float ca = r0.z, cb = r0.w, cc = r1.x;
-        const float pt = logf(r1.y * kMinAlphaThresholdRcp);                      // kf:267
+        const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
         while (pending != 0) {
             const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
             pending &= pending - 1;
             const unsigned o_tx0 = wave_read(tx0, src), o_ty0 = wave_read(ty0, src);
             const unsigned o_tbw = wave_read(tbw, src), o_cnt = wave_read(count, src);
-            const float o_sx = wave_read(sx, src), o_sy = wave_read(sy, src);
-            const float o_ca = wave_read(ca, src), o_cb = wave_read(cb, src), o_cc = wave_read(cc, src);
-            const float o_pt = wave_read(pt, src);
+            TileTest ot;
+            ot.sx = wave_read(tt.sx, src); ot.sy = wave_read(tt.sy, src);
+            ot.ca = wave_read(tt.ca, src); ot.cb = wave_read(tt.cb, src); ot.cc = wave_read(tt.cc, src); ot.pt = wave_read(tt.pt, src);
+            ot.den_x = wave_read(tt.den_x, src); ot.den_y = wave_read(tt.den_y, src);
+            ot.rcp_x = wave_read(tt.rcp_x, src); ot.rcp_y = wave_read(tt.rcp_y, src);
             const unsigned o_prim = wave_read(prim, src);
             unsigned o_w = wave_read(my_off, src);
             for (unsigned base = 0; base < o_cnt; base += kWave) {
                 const unsigned t = base + lane;
                 const unsigned tx = o_tx0 + t % o_tbw, ty = o_ty0 + t / o_tbw;
-                const bool hit = t < o_cnt && tile_contributes(o_sx, o_sy, o_ca, o_cb, o_cc, tx, ty, o_pt);
+                const bool hit = t < o_cnt && tile_contributes(ot, tx, ty);
                 const uint64_t hits = wave_ballot(hit);
                 if (hit) {
                     const unsigned slot = o_w + lanes_below(hits);
@@ -203,9 +203,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
         const uint32_t prim = sorted_prims[i];
         const float4* r = reinterpret_cast<const float4*>(rec + prim);
         const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-        const float sx = r0.x - 0.5f, sy = r0.y - 0.5f;
-        const float ca = r0.z, cb = r0.w, cc = r1.x;
-        const float pt = logf(r1.y * kMinAlphaThresholdRcp);                      // kf:267
+        const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
         unsigned tx0, tx1, ty0, ty1;
         tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
         const unsigned tbw = tx1 - tx0;
@@ -215,7 +213,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
         for (unsigned base = 0; base < count; base += kInstanceBlock, parity ^= 1u) {
             const unsigned t = base + threadIdx.x;
             const unsigned tx = tx0 + t % tbw, ty = ty0 + t / tbw;
-            const bool hit = t < count && tile_contributes(sx, sy, ca, cb, cc, tx, ty, pt);
+            const bool hit = t < count && tile_contributes(tt, tx, ty);
             const uint64_t hits = wave_ballot(hit);
             if (lane == 0) s_hits[parity][wv] = static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
             __syncthreads();                                                       // double-buffered counts: one barrier per step

@@ -26,7 +26,8 @@ constexpr int kSubtileH = 4;                  // one wave64 covers a 16x4 strip 
 constexpr int kWave = 64;
 constexpr int kBucket = 64;            // Gaussians per backward bucket = one wavefront (reference: 32 = one warp)
 constexpr unsigned kHugeFootprint = 1024;   // candidate tiles above which a footprint gets its own workgroup (K1 and K5)
-constexpr int kSeqTiles = 16;          // candidate tiles each lane tests itself before the wave cooperates (reference: 4, cfg:54; measured 4: 0.355 ms, 8: 0.300, 12: 0.252, 16: 0.248, 24: 0.256, 32: 0.269 on S2)
+constexpr int kSeqTiles = 0;           // 0 (default): K1 counts small footprints in flattened (Gaussian, candidate) order (preprocess.hip); n > 0: A/B reference,
+// the reference's scheme with n sequential candidates per lane --          // candidate tiles each lane tests itself before the wave cooperates (reference: 4, cfg:54; measured 4: 0.355 ms, 8: 0.300, 12: 0.252, 16: 0.248, 24: 0.256, 32: 0.269 on S2)
 constexpr int kPreprocessBlock = 512;           // one packed counter atomic per workgroup (see preprocess.hip)
 constexpr int kPreprocessBackwardBlock = 256;
 constexpr int kInstanceBlock = 256;

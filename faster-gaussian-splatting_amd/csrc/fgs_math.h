@@ -87,27 +87,51 @@ __device__ __forceinline__ void quat_to_rotation_backward(float r, float x, floa
     out[3] = two * (r * drz + x * dxz + y * dyz - 2.0f * z * dzz - z * h);
 }
 
-// Exact tile/Gaussian overlap (StopThePop), kernel_utils.cuh:72-114. (mx,my) is the mean shifted by -0.5.
-__device__ __forceinline__ bool tile_contributes(float mx, float my, float ca, float cb, float cc,
-                                                 unsigned tile_x, unsigned tile_y, float power_threshold) {
+// Exact tile/Gaussian overlap (StopThePop), kernel_utils.cuh:72-114: the closest point of the tile rectangle (pixel centres) to the
+// Gaussian centre along the conic; the tile contributes iff the power there stays within the threshold. (sx, sy) is the mean shifted by -0.5.
+// Per-Gaussian invariants are hoisted: the reference's two IEEE divisions have denominators (dx ca) dx and (dy cc) dy with
+// dx = +-15, dy = +-11, i.e. (15 ca) 15 and (11 cc) 11 whatever the signs (a sign flip is exact), so they depend on the Gaussian only.
+// With r = RN(1 / den) taken once per Gaussian, each quotient is formed by two FMA-residual corrections of q = num * r (Markstein's
+// theorem: q' = RN(q + r (num - den q)) is the correctly rounded quotient when r is the correctly rounded reciprocal and q is within
+// an ulp), which reproduces the division bit for bit in the normal range at 5 full-rate instructions instead of the ~11 instruction
+// v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence. Explicit fmaf: this header is compiled with -ffp-contract=off.
+struct TileTest {
+    float sx, sy, ca, cb, cc, pt;      // mean shifted by -0.5, conic, power threshold
+    float den_x, den_y, rcp_x, rcp_y;
+};
+__device__ __forceinline__ TileTest make_tile_test(float sx, float sy, float ca, float cb, float cc, float pt) {
+    TileTest t;
+    t.sx = sx; t.sy = sy; t.ca = ca; t.cb = cb; t.cc = cc; t.pt = pt;
+    const float wx = static_cast<float>(kTileW - 1), wy = static_cast<float>(kTileH - 1);
+    t.den_x = (wx * ca) * wx; t.den_y = (wy * cc) * wy;
+    t.rcp_x = 1.0f / t.den_x; t.rcp_y = 1.0f / t.den_y;
+    return t;
+}
+__device__ __forceinline__ float exact_quotient(float num, float den, float rcp) {
+    float q = num * rcp;
+    q = fmaf(fmaf(-den, q, num), rcp, q);
+    q = fmaf(fmaf(-den, q, num), rcp, q);
+    return q;
+}
+__device__ __forceinline__ bool tile_contributes(const TileTest& g, unsigned tile_x, unsigned tile_y) {
     const float min_x = static_cast<float>(tile_x * kTileW), min_y = static_cast<float>(tile_y * kTileH);
     const float max_x = static_cast<float>((tile_x + 1) * kTileW - 1), max_y = static_cast<float>((tile_y + 1) * kTileH - 1);
-    const float x_min_diff = min_x - mx, y_min_diff = min_y - my;
+    const float x_min_diff = min_x - g.sx, y_min_diff = min_y - g.sy;
     const float x_left = x_min_diff >= 0.0f ? 1.0f : 0.0f;
     const float y_above = y_min_diff >= 0.0f ? 1.0f : 0.0f;
-    const float out_x = x_left + (mx > max_x ? 1.0f : 0.0f);
-    const float out_y = y_above + (my > max_y ? 1.0f : 0.0f);
+    const float out_x = x_left + (g.sx > max_x ? 1.0f : 0.0f);
+    const float out_y = y_above + (g.sy > max_y ? 1.0f : 0.0f);
     if (out_y + out_x == 0.0f) return true;
-    const float corner_x = max_x + x_left * (min_x - max_x);     // lerp(max, min, t) = max + t*(min-max)
+    const float corner_x = max_x + x_left * (min_x - max_x);
     const float corner_y = max_y + y_above * (min_y - max_y);
-    const float diff_x = mx - corner_x, diff_y = my - corner_y;
+    const float diff_x = g.sx - corner_x, diff_y = g.sy - corner_y;
     const float dx = copysignf(static_cast<float>(kTileW - 1), x_min_diff);
     const float dy = copysignf(static_cast<float>(kTileH - 1), y_min_diff);
-    const float tx = out_y * saturate_f((dx * ca * diff_x + dx * cb * diff_y) / (dx * ca * dx));
-    const float ty = out_x * saturate_f((dy * cb * diff_x + dy * cc * diff_y) / (dy * cc * dy));
-    const float ex = mx - (corner_x + tx * dx), ey = my - (corner_y + ty * dy);
-    const float max_power = 0.5f * (ca * ex * ex + cc * ey * ey) + cb * ex * ey;
-    return max_power <= power_threshold;
+    const float tx = out_y * saturate_f(exact_quotient(dx * g.ca * diff_x + dx * g.cb * diff_y, g.den_x, g.rcp_x));
+    const float ty = out_x * saturate_f(exact_quotient(dy * g.cb * diff_x + dy * g.cc * diff_y, g.den_y, g.rcp_y));
+    const float ex = g.sx - (corner_x + tx * dx), ey = g.sy - (corner_y + ty * dy);
+    const float max_power = 0.5f * (g.ca * ex * ex + g.cc * ey * ey) + g.cb * ex * ey;
+    return max_power <= g.pt;
 }
 
 // SH basis constants, sh_utils.cuh:8-28

@@ -78,35 +78,92 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 
         if (wave_ballot(active) != 0) {                                                // kf:181
             // ---- exact tile count (kernel_utils.cuh:117-180), wave64 version ----
-            const float sx = m2x - 0.5f, sy = m2y - 0.5f;
-            const unsigned seq_tiles = static_cast<unsigned>(a.seq_tiles);
-            uint32_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 32
             // Footprints above kHugeFootprint candidate tiles are counted by preprocess_huge_kernel (a workgroup each):
             // Morton order keeps the Gaussians nearest to the camera in the same wave, and counting their tens of
             // thousands of candidates here would stall that wave and the workgroup barrier below for ~0.3 ms.
             const bool huge = active && n_max > kHugeFootprint;
             if (huge) active = false;
-            if (active) {
-                const unsigned n_seq = n_max < seq_tiles ? n_max : seq_tiles;
-                for (unsigned t = 0; t < n_seq; ++t)
-                    if (tile_contributes(sx, sy, ca, cb, cc, tx0 + t % tbw, ty0 + t / tbw, power_threshold)) { ++cnt; hit_mask |= 1u << t; }
+            const TileTest tt = make_tile_test(m2x - 0.5f, m2y - 0.5f, ca, cb, cc, power_threshold);
+            uint32_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 32
+            unsigned first_shared = 0;      // candidates below this index were handled by one of the first two schemes
+            if (a.seq_tiles > 0) {
+                // (A/B reference, fgs_debug_set_option(5, n)) the reference's scheme: every lane tests the first n candidates of its
+                // own Gaussian (cfg:54: 4), the wave cooperates on the rest. At a mean footprint of 9 candidates a wave runs all n
+                // rounds with half of its lanes idle.
+                first_shared = static_cast<unsigned>(a.seq_tiles);
+                if (active) {
+                    const unsigned n_seq = n_max < first_shared ? n_max : first_shared;
+                    for (unsigned t = 0; t < n_seq; ++t)
+                        if (tile_contributes(tt, tx0 + t % tbw, ty0 + t / tbw)) { ++cnt; hit_mask |= 1u << t; }
+                }
+            } else {
+                // Flattened: the (Gaussian, candidate) pairs of all footprints of <= 64 candidates are laid end to end (prefix sum of
+                // the counts) and the wave takes 64 PAIRS per round, every lane busy: lane l of round r handles pair 64 r + l, finds its
+                // owner with a 6-step search over the prefix array in the wave's LDS slice, and each owner picks its own bits out of
+                // the round's ballot. ~9 rounds per wave at S2 instead of 16 half-empty ones.
+                __shared__ uint32_t s_pre[kPreprocessBlock / kWave][kWave];
+                __shared__ float4 s_g0[kPreprocessBlock / kWave][kWave], s_g1[kPreprocessBlock / kWave][kWave];   // sx sy ca cb | cc pt rcp_x rcp_y
+                __shared__ uint2 s_box[kPreprocessBlock / kWave][kWave];                                          // tx0 | ty0 << 16, width | ceil(2^16 / width) << 8
+                first_shared = kWave;
+                const bool flat = active && n_max <= static_cast<unsigned>(kWave);
+                const uint32_t n_flat = flat ? n_max : 0u;
+                const uint32_t my_pre = wave_exclusive_sum(n_flat);
+                const uint32_t total = wave_read(my_pre + n_flat, kWave - 1);
+                s_pre[wave][lane] = my_pre;
+                s_g0[wave][lane] = make_float4(tt.sx, tt.sy, tt.ca, tt.cb);
+                s_g1[wave][lane] = make_float4(tt.cc, tt.pt, tt.rcp_x, tt.rcp_y);
+                s_box[wave][lane] = make_uint2(tx0 | (ty0 << 16), tbw | (((65536u + tbw - 1u) / (tbw ? tbw : 1u)) << 8));
+                wave_lds_fence();
+                for (uint32_t r0 = 0; r0 < total; r0 += kWave) {                       // wave-uniform
+                    const uint32_t p = r0 + lane;
+                    unsigned o = 0;                                                    // largest lane with s_pre <= p (ties: the owning lane is last)
+#pragma unroll
+                    for (unsigned step = 32; step >= 1; step >>= 1) {
+                        const unsigned mid = o + step;
+                        if (mid < static_cast<unsigned>(kWave) && s_pre[wave][mid] <= p) o = mid;
+                    }
+                    const uint32_t t = p - s_pre[wave][o];
+                    const float4 g0 = s_g0[wave][o], g1 = s_g1[wave][o];
+                    const uint2 box = s_box[wave][o];
+                    const unsigned w = box.y & 0xffu, row = (t * (box.y >> 8)) >> 16, col = t - row * w;      // t / w, t % w for t < 64, w <= 64
+                    TileTest ot;
+                    ot.sx = g0.x; ot.sy = g0.y; ot.ca = g0.z; ot.cb = g0.w; ot.cc = g1.x; ot.pt = g1.y; ot.rcp_x = g1.z; ot.rcp_y = g1.w;
+                    ot.den_x = (static_cast<float>(kTileW - 1) * ot.ca) * static_cast<float>(kTileW - 1);
+                    ot.den_y = (static_cast<float>(kTileH - 1) * ot.cc) * static_cast<float>(kTileH - 1);
+                    const bool hit = p < total && tile_contributes(ot, (box.x & 0xffffu) + col, (box.x >> 16) + row);
+                    const uint64_t hits = wave_ballot(hit);
+                    // owner side: my pairs are [my_pre, my_pre + n_flat); their part inside this round is lanes [lo, hi)
+                    const int rel = static_cast<int>(my_pre) - static_cast<int>(r0);
+                    const int lo = min(max(rel, 0), kWave), hi = min(max(rel + static_cast<int>(n_flat), 0), kWave);
+                    if (hi > lo) {
+                        const int len = hi - lo;
+                        const uint64_t mine = (hits >> lo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+                        cnt += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(mine)));
+                        const int first_t = lo - rel;                                  // candidate index of the pair at lane lo
+                        if (first_t < 32) hit_mask |= static_cast<uint32_t>(mine << first_t);
+                    }
+                }
             }
-            uint64_t pending = wave_ballot(active && n_max > seq_tiles);
+            uint64_t pending = wave_ballot(active && n_max > first_shared);
             while (pending != 0) {                              // wave-uniform loop over lanes with large footprints
                 const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
                 pending &= pending - 1;
                 const unsigned o_tx0 = wave_read(tx0, src), o_ty0 = wave_read(ty0, src);
                 const unsigned o_tbw = wave_read(tbw, src), o_cnt = wave_read(n_max, src);
-                const float o_sx = wave_read(sx, src), o_sy = wave_read(sy, src);
-                const float o_ca = wave_read(ca, src), o_cb = wave_read(cb, src), o_cc = wave_read(cc, src);
-                const float o_pt = wave_read(power_threshold, src);
+                TileTest ot;
+                ot.sx = wave_read(tt.sx, src); ot.sy = wave_read(tt.sy, src);
+                ot.ca = wave_read(tt.ca, src); ot.cb = wave_read(tt.cb, src); ot.cc = wave_read(tt.cc, src);
+                ot.pt = wave_read(tt.pt, src);
+                ot.den_x = wave_read(tt.den_x, src); ot.den_y = wave_read(tt.den_y, src);
+                ot.rcp_x = wave_read(tt.rcp_x, src); ot.rcp_y = wave_read(tt.rcp_y, src);
+                const unsigned first = a.seq_tiles > 0 ? first_shared : 0u;
                 unsigned found = 0;
-                for (unsigned base = seq_tiles; base < o_cnt; base += kWave) {
+                for (unsigned base = first; base < o_cnt; base += kWave) {
                     const unsigned t = base + lane;
-                    const bool hit = t < o_cnt && tile_contributes(o_sx, o_sy, o_ca, o_cb, o_cc, o_tx0 + t % o_tbw, o_ty0 + t / o_tbw, o_pt);
+                    const bool hit = t < o_cnt && tile_contributes(ot, o_tx0 + t % o_tbw, o_ty0 + t / o_tbw);
                     const uint64_t hits = wave_ballot(hit);
                     found += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
-                    if (base == seq_tiles && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << seq_tiles);
+                    if (base == first && first < 32u && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << first);
                 }
                 if (lane == static_cast<unsigned>(src)) cnt += found;
             }
@@ -192,14 +249,13 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
         const uint32_t idx = a.huge_list[h];
         const float4* r = reinterpret_cast<const float4*>(a.rec + idx);
         const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-        const float sx = r0.x - 0.5f, sy = r0.y - 0.5f;
-        const float pt = logf(r1.y * kMinAlphaThresholdRcp);
+        const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));
         unsigned tx0, tx1, ty0, ty1;
         tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
         const unsigned tbw = tx1 - tx0, count = tbw * (ty1 - ty0);
         unsigned mine = 0;
         for (unsigned t = threadIdx.x; t < count; t += 256u)
-            mine += tile_contributes(sx, sy, r0.z, r0.w, r1.x, tx0 + t % tbw, ty0 + t / tbw, pt) ? 1u : 0u;
+            mine += tile_contributes(tt, tx0 + t % tbw, ty0 + t / tbw) ? 1u : 0u;
         const unsigned wsum = wave_sum(mine);
         if (lane == 0) s_cnt[wv] = wsum;
         __syncthreads();

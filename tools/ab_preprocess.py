@@ -11,7 +11,7 @@ g = T.Gaussians(params, dev)
 S = [T.extract_settings(v.to(dev), g.active_sh_bases, v.to(dev).background_color) for v in views]
 res = {}
 for rnd in range(3):
-    for L in (4, 8, 12, 16, 24, 32):
+    for L in (16, 0, 8):
         be.lib.fgs_debug_set_option(5, L)
         for s in S[:2]: be.inference(*g.tensors(), s, True, True)
         torch.cuda.synchronize(); be.profile_enable(True); be.profile_read()
@@ -19,3 +19,4 @@ for rnd in range(3):
         torch.cuda.synchronize(); pr = be.profile_read(); be.profile_enable(False)
         res.setdefault(L, []).append(pr['preprocess'][0] / pr['preprocess'][1])
 for L, v in res.items(): print('seq_tiles', L, 'preprocess ms', [round(x, 4) for x in v])
+be.lib.fgs_debug_set_option(5, 0)
