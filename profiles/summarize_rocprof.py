@@ -38,10 +38,14 @@ def pmc(path):
     name_col = 'counter_name' if 'counter_name' in cols else [c for c in cols if 'name' in c][-1]
     val_col = 'counter_value' if 'counter_value' in cols else [c for c in cols if 'value' in c][-1]
     kcol = 'name'
-    q = f"select {kcol}, {name_col}, count(*), avg({val_col}), sum({val_col}) from pmc_events group by {kcol}, {name_col} order by sum({val_col}) desc"
-    print(f'{"kernel":72s} {"counter":>12s} {"dispatches":>10s} {"avg/dispatch":>16s}')
-    for k, cn, c, a, s in db.execute(q):
-        print(f'{short(k):72s} {cn:>12s} {c:10d} {a:16.1f}')
+    # SQ_* counters come as one row per shader engine and dispatch, TCC-derived ones (FETCH_SIZE, WRITE_SIZE: KiB) as one row per
+    # dispatch: total per launch = sum over the rows / number of dispatches of that kernel in the kernel trace
+    launches = dict(db.execute('select name, count(*) from kernels group by name').fetchall())
+    q = f"select {kcol}, {name_col}, count(*), sum({val_col}) from pmc_events group by {kcol}, {name_col} order by sum({val_col}) desc"
+    print(f'{"kernel":72s} {"counter":>14s} {"dispatches":>10s} {"total/dispatch":>18s}')
+    for k, cn, c, s in db.execute(q):
+        n = launches.get(k, 0) or 1
+        print(f'{short(k):72s} {cn:>14s} {n:10d} {s / n:18.1f}')
 
 
 if __name__ == '__main__':
