@@ -264,11 +264,15 @@ int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
 size_t fgs_debug_radix_sort_temp_bytes(int32_t n, int32_t end_bit);
 int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, int32_t key_bytes, int32_t end_bit,
                              void* temp, size_t temp_bytes, void* stream);
-/* Selects the blend-backward formulation: 0 = systolic (lane = Gaussian), 1 = strip (lane = pixel, default). A/B switch for
- * tests and bench; both must give the same gradients. */
+/* Selects the blend-backward formulation: 3 (default) = live-bucket list + compacted pixels + two-value pipeline state, 2 / 0 =
+ * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel). A/B switch for tests and bench: process-wide,
+ * unsynchronised; all variants must give the same gradients. */
 int32_t fgs_debug_set_backward_variant(int32_t variant);
-/* Tuning switches for A/B measurements inside one process: key 0 = blend-backward variant, key 1 = Adam float4 pieces per
- * thread (1, 2, 4). Results never depend on them. */
+/* Tuning switches for A/B measurements inside one process (process-wide, unsynchronised: bench / test processes only):
+ * key 0 = blend-backward variant, 1 = Adam float4 pieces per thread (1, 2, 4), 2 = Adam non-temporal accesses, 3 = fused
+ * backward+Adam as one kernel (1, default) or round 1's two (0), 5 = K1 tile counting: 0 flattened (default) or n sequential
+ * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop).
+ * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
 #ifdef __cplusplus
