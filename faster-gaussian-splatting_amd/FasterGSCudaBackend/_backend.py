@@ -97,7 +97,10 @@ class Backend:
         return buffers, _lib.RESIZE_FN(resize)
 
     # -- entry points -----------------------------------------------------------------------------------------------
-    def forward(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings) -> ForwardResult:
+    def forward(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings,
+                instance_capacity: int | None = None) -> ForwardResult:
+        """instance_capacity: None = fgs_forward (one host read of the counts); an int = fgs_forward_async, no host wait -- state then
+        holds bounds (N, capacity, ...) and `forward_counts` tells later whether the capacity was enough."""
         device = self._check_params((means, scales, rotations, opacities, sh0, sh_rest),
                                     ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_0', 'sh_coefficients_rest'))
         keep: list = []
@@ -105,10 +108,27 @@ class Backend:
         image = torch.empty((3, settings.height, settings.width), dtype=torch.float32, device=device)
         buffers, cb = self._make_resizer(device, 4)
         st = _lib.ForwardState()
-        self._check(self.lib.fgs_forward(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest),
-                                         means.shape[0], C.byref(S), image.data_ptr(), cb, None, C.byref(st), _stream_of(device)),
-                    'fgs_forward')
+        if instance_capacity is None:
+            self._check(self.lib.fgs_forward(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest),
+                                             means.shape[0], C.byref(S), image.data_ptr(), cb, None, C.byref(st), _stream_of(device)),
+                        'fgs_forward')
+        else:
+            self._check(self.lib.fgs_forward_async(_ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(sh0), _ptr(sh_rest),
+                                                   means.shape[0], C.byref(S), image.data_ptr(), int(instance_capacity), cb, None, C.byref(st),
+                                                   _stream_of(device)), 'fgs_forward_async')
         return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
+
+    def forward_counts(self, result: ForwardResult, n_primitives: int):
+        """Enqueues the read-back of (n_visible, n_instances, capacity_exceeded) of a forward pass; returns (pinned int32[3] tensor, event).
+        The values are valid after event.synchronize() -- typically free by the time backward runs."""
+        host = torch.empty(3, dtype=torch.int32, pin_memory=result.image.is_cuda)
+        self._check(self.lib.fgs_forward_counts(_ptr(result.buffers[0]), int(n_primitives), host.data_ptr(), _stream_of(result.image.device)),
+                    'fgs_forward_counts')
+        event = None
+        if result.image.is_cuda:
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(result.image.device))
+        return host, event
 
     def inference(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings, to_chw: bool,
                   clamp_output: bool, return_state: bool = False):

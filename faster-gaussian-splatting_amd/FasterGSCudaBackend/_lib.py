@@ -52,6 +52,8 @@ _SIGNATURES = {
     'fgs_last_error': (C.c_char_p, []),
     'fgs_build_info': (C.c_char_p, []),
     'fgs_forward': (C.c_int32, [_P] * 6 + [_I32, C.POINTER(Settings), _P, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
+    'fgs_forward_async': (C.c_int32, [_P] * 6 + [_I32, C.POINTER(Settings), _P, _I32, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
+    'fgs_forward_counts': (C.c_int32, [_P, _I32, _P, _P]),
     'fgs_backward_scratch_bytes': (C.c_size_t, [_I32, _I32, _I32]),
     'fgs_backward': (C.c_int32, [_P] * 2 + [_P] * 5 + [_P] * 4 + [_P] * 6 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
     'fgs_inference': (C.c_int32, [_P] * 6 + [_I32, C.POINTER(Settings), _P, _I32, _I32, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),

@@ -22,6 +22,26 @@ def set_gradient_buffers(provider) -> None:
     _GRAD_OUT = provider
 
 
+# ---- host-synchronisation-free training forward (fgs_forward_async) ------------------------------------------------------------------
+# The reference blocks the host three times per forward pass (forward.cu:100,102,234) to size its buffers; fgs_forward once. With
+# `set_async_forward(True)` the training path sizes the instance stages from what earlier passes needed -- the largest instances-per-
+# Gaussian ratio seen so far x the current Gaussian count x `headroom` -- and reads the counts back asynchronously; they are looked at in
+# `backward` (by then the copy has long completed). If a pass ever needs more than its capacity, its image was incomplete: backward repeats
+# the forward pass synchronously for the gradients and reports it (RuntimeWarning) -- with the default 25 % headroom that takes a jump of the
+# instance count between two consecutive iterations that training does not produce (densification grows N, and the bound scales with N).
+_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0}
+
+
+def set_async_forward(enabled: bool, headroom: float = 1.25) -> None:
+    _ASYNC.update(enabled=bool(enabled), headroom=float(headroom))
+    if not enabled:
+        _ASYNC.update(ratio=0.0)
+
+
+def async_forward_stats() -> dict:
+    return dict(_ASYNC)
+
+
 def _require_gpu(t: torch.Tensor) -> None:
     if not t.is_cuda:
         # Renderer.py:58-59 raises in CPU mode as well; there is no CPU implementation behind this package
@@ -35,7 +55,17 @@ class _Rasterize(torch.autograd.Function):
     def forward(ctx: Any, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, densification_info,
                 rasterizer_settings: RasterizerSettings) -> torch.Tensor:
         _require_gpu(means)
-        res = default_backend().forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings)
+        be, n = default_backend(), means.shape[0]
+        capacity = None
+        if _ASYNC['enabled'] and _ASYNC['ratio'] > 0.0 and n > 0:
+            capacity = int(_ASYNC['ratio'] * n * _ASYNC['headroom']) + 65536
+        res = be.forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings, capacity)
+        if capacity is None:
+            if n > 0:
+                _ASYNC['ratio'] = max(_ASYNC['ratio'], res.state[1] / n)
+            ctx.async_check = None
+        else:
+            ctx.async_check = be.forward_counts(res, n) + (sh_coefficients_0,)
         ctx.rasterizer_settings = rasterizer_settings
         ctx.buffer_state = res.state
         ctx.save_for_backward(res.image, means, scales, rotations, opacities, sh_coefficients_rest, *res.buffers)
@@ -47,8 +77,22 @@ class _Rasterize(torch.autograd.Function):
     @once_differentiable
     def backward(ctx: Any, grad_image: torch.Tensor):
         image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
+        state = ctx.buffer_state
+        if ctx.async_check is not None:
+            host, event, sh0 = ctx.async_check
+            if event is not None:
+                event.synchronize()
+            n = means.shape[0]
+            _ASYNC['ratio'] = max(_ASYNC['ratio'], int(host[1]) / max(n, 1))
+            if int(host[2]) != 0:          # the capacity was too small: the image (and the loss gradient) missed the instances beyond it
+                import warnings
+                _ASYNC['overflows'] += 1
+                warnings.warn(f'FasterGS async forward: {int(host[1])} instances exceeded the capacity {state[1]}; repeating the pass synchronously',
+                              RuntimeWarning)
+                res = default_backend().forward(means, scales, rotations, opacities, sh0, sh_rest, ctx.rasterizer_settings)
+                image, buffers, state = res.image, list(res.buffers), res.state
         grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
-                                           buffers, ctx.rasterizer_settings, ctx.buffer_state,
+                                           buffers, ctx.rasterizer_settings, state,
                                            out=_GRAD_OUT() if _GRAD_OUT is not None else None)
         return (*grads, None, None)   # densification_info, rasterizer_settings
 

@@ -242,12 +242,12 @@ enum ForwardMode { MODE_TRAINING, MODE_INFERENCE, MODE_SCORES };
 
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
                  uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
-                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores);
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts = false);
 
 int run_forward(ForwardMode mode, const float* means, const float* scales, const float* rotations, const float* opacities,
                 const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
                 int to_chw, int clamp_output, fgs_resize_fn resize, void* user, fgs_forward_state* state_out, void* stream_,
-                float* scores = nullptr) {
+                float* scores = nullptr, int32_t instance_capacity = 0) {
     const bool training = mode == MODE_TRAINING;
     if (int rc = check_settings(settings)) return rc;
     if (n_primitives < 0 || (!image && mode != MODE_SCORES) || (!scores && mode == MODE_SCORES) || !resize || !state_out) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_primitives=%d)", n_primitives);
@@ -281,6 +281,20 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
+    if (instance_capacity > 0) {
+        // Host-synchronisation-free form (fgs_forward_async): nothing is read back. Every launch behind K1 is sized by a bound -- the
+        // primitive count for the visible list, the caller's capacity for the instance stages -- and reads the exact count on the device.
+        if (!depth_sort_takes_device_count() || !tile_sort_takes_device_count())
+            return fail(FGS_ERR_INVALID_ARGUMENT, "the synchronisation-free forward needs the built-in radix sort for both sorts (fgs_debug_set_option(6, 3))");
+        int depth_sel = 0;
+        if (n > 0) {
+            StageScope t(ST_DEPTH_SORT, stream);
+            FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, stream));
+        }
+        return forward_tail(mode, pb, tb, geo, n, static_cast<uint32_t>(instance_capacity), depth_sel, settings, image, to_chw, clamp_output, resize, user,
+                            state_out, stream, scores, true);
+    }
+
     // the one host read of the pass: V and I (fwd:99-102). The depth sort does not need them on the host (radix_sort.hip reads
     // the count on the device), so it is enqueued BEHIND the copy and runs while the host waits for the two words.
     CounterReadback* rb = counter_readback();
@@ -304,13 +318,17 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
 // already depth-sorted, the sorted half is depth_sel)
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
                  uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
-                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores) {
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts) {
     const bool training = mode == MODE_TRAINING;
     PrimitiveBuffers pb = pb_in;
+    // device_counts: n_visible / n_instances are BOUNDS (primitive count / caller's instance capacity); the exact counts stay on the device:
+    // counters[0] = visible, counters[5] = min(instances, capacity) (written by K5), counters[6] = the capacity was exceeded
+    const uint32_t* const visible_ptr = device_counts ? pb.counters : nullptr;
+    const uint32_t* const instances_ptr = device_counts ? pb.counters + 5 : nullptr;
     // K2-K4 (fwd:104-127)
     if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
-    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, stream)); }
+    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, visible_ptr, stream)); }
 
     // K5-K7 (fwd:179-216)
     Carver inst_size(nullptr);
@@ -320,11 +338,12 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
     { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.n_touched, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
+                                                                                 visible_ptr, device_counts ? n_instances : 0xffffffffu, pb.counters,
                                                                                  pb.keys[depth_sel ^ 1], pb.counters + 2, stream)); }
     int tile_sel = 0;
-    { StageScope t(ST_TILE_SORT, stream); FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, geo.end_bit, stream)); }
+    { StageScope t(ST_TILE_SORT, stream); FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, instances_ptr, geo.end_bit, stream)); }
     // the key double buffer flips together with the value double buffer
-    { StageScope t(ST_RANGES, stream); FGS_HIP(launch_extract_ranges(geo.key_bytes, ib.keys[tile_sel], tb.ranges, n_instances, stream)); }
+    { StageScope t(ST_RANGES, stream); FGS_HIP(launch_extract_ranges(geo.key_bytes, ib.keys[tile_sel], tb.ranges, n_instances, instances_ptr, stream)); }
 
     BlendArgs ba{};
     ba.ranges = tb.ranges; ba.inst_prims = ib.prims[tile_sel]; ba.rec = pb.rec; ba.bg = settings->bg_color; ba.image = image;
@@ -408,6 +427,26 @@ int32_t fgs_forward(const float* means, const float* scales, const float* rotati
                     fgs_forward_state* state_out, void* stream) {
     return run_forward(MODE_TRAINING, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
                        image, 1, 0, resize, resize_user, state_out, stream);
+}
+
+int32_t fgs_forward_async(const float* means, const float* scales, const float* rotations, const float* opacities,
+                          const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                          const fgs_settings* settings, float* image, int32_t instance_capacity, fgs_resize_fn resize, void* resize_user,
+                          fgs_forward_state* state_out, void* stream) {
+    if (instance_capacity <= 0) return fail(FGS_ERR_INVALID_ARGUMENT, "instance_capacity %d", instance_capacity);
+    return run_forward(MODE_TRAINING, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, n_primitives, settings,
+                       image, 1, 0, resize, resize_user, state_out, stream, nullptr, instance_capacity);
+}
+
+int32_t fgs_forward_counts(const void* primitive_buffers, int32_t n_primitives, int32_t* host_out, void* stream_) {
+    if (!primitive_buffers || n_primitives < 0 || !host_out) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    Carver c(const_cast<void*>(primitive_buffers));
+    const PrimitiveBuffers pb = PrimitiveBuffers::carve(c, static_cast<uint32_t>(n_primitives));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // counters: [0] visible, [1] instances; [6] overflow flag of fgs_forward_async. Two small copies, no synchronisation here.
+    FGS_HIP(hipMemcpyAsync(host_out, pb.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FGS_HIP(hipMemcpyAsync(host_out + 2, pb.counters + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return FGS_OK;
 }
 
 int32_t fgs_inference(const float* means, const float* scales, const float* rotations, const float* opacities,

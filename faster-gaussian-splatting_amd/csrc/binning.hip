@@ -12,6 +12,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/types/double_buffer.hpp>
 
@@ -52,9 +53,19 @@ hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* 
     return own_sort_pairs_u32_device_count(temp, temp_bytes, keys, vals, selector, capacity, n_visible_ptr, 32, s);
 }
 
+// the same input when the host does not know the visible count: entries at and beyond *count contribute nothing
+struct TouchedGuarded {
+    const uint32_t* sorted_prims; const uint32_t* n_touched; const uint32_t* count;
+    __host__ __device__ uint32_t operator()(uint32_t i) const { return i < *count ? n_touched[sorted_prims[i]] : 0u; }
+};
+
 hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
-                            uint32_t n_visible, hipStream_t s) {
+                            uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;
+    if (n_visible_ptr != nullptr) {       // n_visible is a bound (the primitive count), the exact count lives on the device
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TouchedGuarded{sorted_prims, n_touched, n_visible_ptr});
+        return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
+    }
     auto in = rocprim::make_transform_iterator(sorted_prims, TouchedFromRec{n_touched});
     return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
 }
@@ -81,7 +92,17 @@ template <typename KeyT>
 __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     const uint32_t* __restrict__ sorted_prims, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ n_touched,
     const PrimRec* __restrict__ rec, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w,
-    const uint32_t n_visible, uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
+    const uint32_t n_visible_value, const uint32_t* __restrict__ n_visible_ptr, const uint32_t capacity, uint32_t* __restrict__ counters,
+    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
+    // The visible count by value, or (host-synchronisation-free forward) through n_visible_ptr with the grid sized by a bound. `capacity` =
+    // size of the instance arrays: exact in the first case; in the second a caller-side estimate -- stores beyond it are dropped, and
+    // the clamped instance count / an overflow flag are left in counters[5] / counters[6] for the sort and for the caller to check.
+    const uint32_t n_visible = n_visible_ptr != nullptr ? *n_visible_ptr : n_visible_value;
+    if (n_visible_ptr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t n_instances = counters[1];
+        counters[5] = n_instances < capacity ? n_instances : capacity;
+        counters[6] = n_instances > capacity ? 1u : 0u;
+    }
     constexpr int kWaves = kInstanceBlock / kWave;
     __shared__ uint32_t s_off[kWaves][kWave];         // global write offset of each primitive
     __shared__ uint32_t s_loc[kWaves][kWave];         // wave-local slot of each bitmap primitive's first instance
@@ -133,8 +154,10 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         const unsigned w = dv & 0xffu, row = (pos * (dv >> 8)) >> 16, col = pos - row * w;
         const unsigned tx = (org & 0xffffu) + col, ty = (org >> 16) + row;
         const uint32_t o = s_off[wv][lo] + rank;
-        inst_keys[o] = static_cast<KeyT>(ty * grid_w + tx);
-        inst_prims[o] = s_prim[wv][lo];
+        if (o < capacity) {
+            inst_keys[o] = static_cast<KeyT>(ty * grid_w + tx);
+            inst_prims[o] = s_prim[wv][lo];
+        }
     }
 
     // ---- medium footprints (33 .. kHugeFootprint candidate tiles): re-tested by this wave, 64 candidates per step, with
@@ -165,8 +188,10 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
                 const uint64_t hits = wave_ballot(hit);
                 if (hit) {
                     const unsigned slot = o_w + lanes_below(hits);
-                    inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
-                    inst_prims[slot] = o_prim;
+                    if (slot < capacity) {
+                        inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
+                        inst_prims[slot] = o_prim;
+                    }
                 }
                 o_w += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
             }
@@ -193,7 +218,7 @@ template <typename KeyT>
 __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
     const uint32_t* __restrict__ sorted_prims, const uint32_t* __restrict__ offsets, const PrimRec* __restrict__ rec,
     const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
-    KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w) {
+    KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w, const uint32_t capacity) {
     constexpr int kWaves = kInstanceBlock / kWave;
     __shared__ unsigned s_hits[2][kWaves];
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
@@ -222,8 +247,10 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
             for (int k = 0; k < kWaves; ++k) { const unsigned c = s_hits[parity][k]; total += c; if (k < static_cast<int>(wv)) before += c; }
             if (hit) {
                 const unsigned slot = w + before + lanes_below(hits);
-                inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
-                inst_prims[slot] = prim;
+                if (slot < capacity) {
+                    inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
+                    inst_prims[slot] = prim;
+                }
             }
             w += total;
         }
@@ -233,20 +260,21 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
 
 hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const uint32_t* n_touched,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
+                                   const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;
     const dim3 grid((n_visible + kInstanceBlock - 1) / kInstanceBlock), block(kInstanceBlock);
     const dim3 big_grid(n_visible < 1024u ? n_visible : 1024u);       // grid-stride over the (short) device-side work list
     if (key_bytes == 2) {
         hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, sorted_prims, offsets, n_touched, rec,
-                           static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, n_visible, big_list, big_count);
+                           static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint16_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
-                           static_cast<uint16_t*>(inst_keys), inst_prims, grid_w);
+                           static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, capacity);
     } else {
         hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, sorted_prims, offsets, n_touched, rec,
-                           static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, n_visible, big_list, big_count);
+                           static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint32_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
-                           static_cast<uint32_t*>(inst_keys), inst_prims, grid_w);
+                           static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, capacity);
     }
     return hipGetLastError();
 }
@@ -275,25 +303,29 @@ static hipError_t run_tile_sort_t(void* temp, size_t temp_bytes, void* keys[2], 
     selector = (v.current() == vals[0]) ? 0 : 1;      // fwd:205 records which half holds the sorted list
     return hipSuccess;
 }
+bool tile_sort_takes_device_count() { return (g_sort_implementation & 1) != 0; }
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
-                         uint32_t n_instances, int end_bit, hipStream_t s) {
+                         uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s) {
     selector = 0;
     if (n_instances == 0) return hipSuccess;
-    if (g_sort_implementation & 1) {
+    if (g_sort_implementation & 1) {       // n_instances_ptr != nullptr: n_instances is the capacity, the count lives on the device
         if (key_bytes == 2) {
             uint16_t* k16[2] = {static_cast<uint16_t*>(keys[0]), static_cast<uint16_t*>(keys[1])};
-            return own_sort_pairs_u16(temp, temp_bytes, k16, vals, selector, n_instances, end_bit, s);
+            return own_sort_pairs_u16_device_count(temp, temp_bytes, k16, vals, selector, n_instances, n_instances_ptr, end_bit, s);
         }
         uint32_t* k32[2] = {static_cast<uint32_t*>(keys[0]), static_cast<uint32_t*>(keys[1])};
-        return own_sort_pairs_u32(temp, temp_bytes, k32, vals, selector, n_instances, end_bit, s);
+        return own_sort_pairs_u32_device_count(temp, temp_bytes, k32, vals, selector, n_instances, n_instances_ptr, end_bit, s);
     }
+    if (n_instances_ptr != nullptr) return hipErrorInvalidValue;
     return key_bytes == 2 ? run_tile_sort_t<uint16_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s)
                           : run_tile_sort_t<uint32_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s);
 }
 
 // ---- K7 (kf:331-348); ranges are pre-zeroed by the host (fwd:54) ----------------------------------------------
 template <typename KeyT>
-__global__ void __launch_bounds__(256) extract_ranges_kernel(const KeyT* __restrict__ keys, uint2* __restrict__ ranges, const uint32_t n) {
+__global__ void __launch_bounds__(256) extract_ranges_kernel(const KeyT* __restrict__ keys, uint2* __restrict__ ranges, const uint32_t n_value,
+                                                             const uint32_t* __restrict__ n_ptr) {
+    const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const KeyT t = keys[i];
@@ -304,11 +336,11 @@ __global__ void __launch_bounds__(256) extract_ranges_kernel(const KeyT* __restr
     }
     if (i == n - 1) ranges[t].y = n;
 }
-hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, hipStream_t s) {
+hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s) {
     if (n_instances == 0) return hipSuccess;
     const dim3 grid((n_instances + 255) / 256), block(256);
-    if (key_bytes == 2) hipLaunchKernelGGL(extract_ranges_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t*>(sorted_keys), ranges, n_instances);
-    else hipLaunchKernelGGL(extract_ranges_kernel<uint32_t>, grid, block, 0, s, static_cast<const uint32_t*>(sorted_keys), ranges, n_instances);
+    if (key_bytes == 2) hipLaunchKernelGGL(extract_ranges_kernel<uint16_t>, grid, block, 0, s, static_cast<const uint16_t*>(sorted_keys), ranges, n_instances, n_instances_ptr);
+    else hipLaunchKernelGGL(extract_ranges_kernel<uint32_t>, grid, block, 0, s, static_cast<const uint32_t*>(sorted_keys), ranges, n_instances, n_instances_ptr);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@
 // Output order of adaptive density control (identical to the reference's cat / boolean-index result): the surviving old Gaussians in
 // their order, then the surviving clones in the order of their originals, then the surviving first children of the split Gaussians,
 // then the surviving second children. New Gaussians start with zero Adam moments (extend_param_groups), survivors keep theirs.
-// Built with -ffp-contract=off (Makefile): keys and thresholds reproduce the numpy restatement in oracle/oracle.py bit for bit.
+// Built with -ffp-contract=off (Makefile): keys and thresholds reproduce the numpy restatement of Model.py that the tests compare with, bit for bit.
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 #include <rocprim/device/device_scan.hpp>

@@ -38,17 +38,22 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
 bool depth_sort_takes_device_count();
 hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
                                        uint32_t capacity, const uint32_t* n_visible_ptr, hipStream_t s);
+// n_visible_ptr != nullptr: n_visible is a bound (the primitive count) and the exact count is read on the device
 hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
-                            uint32_t n_visible, hipStream_t s);
+                            uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s);
 
 // K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
+// The *_ptr forms serve the host-synchronisation-free forward pass: counts are bounds / capacities, the exact ones are read on the device
+// (n_visible from counters[0]; the instance count clamped to `capacity` is written to counters[5], an overflow flag to counters[6]).
 hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const uint32_t* n_touched,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
+                                   const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s);
+bool tile_sort_takes_device_count();
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
-                         uint32_t n_instances, int end_bit, hipStream_t s);
-hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, hipStream_t s);
+                         uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s);
+hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s);
 
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
 extern int g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
@@ -57,6 +62,8 @@ hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], 
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 // the item count lives on the device (*n_ptr <= capacity): lets the depth sort start before the host has read the counters back
 hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
+                                           const uint32_t* n_ptr, int end_bit, hipStream_t s);
+hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s);
 
 // K8+K9: inclusive scan of ceil(len/kBucket) per tile

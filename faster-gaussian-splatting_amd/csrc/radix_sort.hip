@@ -258,5 +258,9 @@ hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s) {
     return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, end_bit, s);
 }
+hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
+                                           const uint32_t* n_ptr, int end_bit, hipStream_t s) {
+    return sort_pairs<uint16_t>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, end_bit, s);
+}
 
 }  // namespace fgs

@@ -88,6 +88,21 @@ int32_t fgs_backward(const float* grad_image, const float* image,
                      float* densification_info, void* scratch,
                      int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream);
 
+/* fgs_forward WITHOUT its host synchronisation (the reference blocks three times per forward pass, forward.cu:100,102,234; fgs_forward
+ * once): nothing is read back. The instance-stage buffers and launches are sized by `instance_capacity` -- the caller's bound, e.g. 1.25 x
+ * the largest count fgs_forward_counts() has reported, scaled with the primitive count -- and every kernel reads the exact counts on the
+ * device. state_out: n_visible = n_primitives and n_instances = instance_capacity (bounds; pass them back to fgs_backward unchanged).
+ * If the real instance count exceeds the capacity the excess instances are DROPPED (incomplete image) and a flag is raised that
+ * fgs_forward_counts() reports: the caller repeats the pass with fgs_forward or a larger capacity. All work is enqueued on `stream`;
+ * together with fgs_backward / fgs_adam_step_multi a whole iteration is free of host waits (and capturable, resize callback aside). */
+int32_t fgs_forward_async(const float* means, const float* scales, const float* rotations, const float* opacities,
+                          const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
+                          const fgs_settings* settings, float* image, int32_t instance_capacity, fgs_resize_fn resize, void* resize_user,
+                          fgs_forward_state* state_out, void* stream);
+/* Enqueues the copy of (n_visible, n_instances, capacity_exceeded) of the forward pass that filled `primitive_buffers` into
+ * host_out[3] (pinned memory recommended); valid once `stream` has reached this point. No synchronisation. */
+int32_t fgs_forward_counts(const void* primitive_buffers, int32_t n_primitives, int32_t* host_out, void* stream);
+
 /* replaces _C.inference (rasterization_api.cu:181-247 -> rasterization/src/inference.cu:11-226).
  * image: [3,H,W] if to_chw else [H,W,3]. Only FGS_BUF_PRIMITIVE/TILE/INSTANCE are requested. */
 int32_t fgs_inference(const float* means, const float* scales, const float* rotations, const float* opacities,

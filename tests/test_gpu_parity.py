@@ -422,3 +422,41 @@ def test_full_size_properties(hip_backend):
     invisible = torch.from_numpy(dec['n_touched'] == 0).to(DEV)
     for a in g1:
         assert float(a[invisible].abs().max()) == 0.0
+
+
+def test_async_forward_through_the_public_operators(hip_backend, oracle):
+    """set_async_forward(True): after one synchronous pass the training forward issues no host wait (fgs_forward_async, capacity from the
+    instances-per-Gaussian ratio seen so far); image and gradients stay those of the synchronous path. With a headroom below 1 the capacity
+    is exceeded: backward notices, repeats the pass synchronously (RuntimeWarning) and still returns the right gradients."""
+    import warnings
+    from FasterGSCudaBackend import async_forward_stats, diff_rasterize, set_async_forward
+    params, view = make_s0(n=3000)
+    S, RS = helpers.settings_pair(view, device=DEV)
+    f = oracle.forward(*helpers.np_params(params), S)
+    gi = torch.randn(3, view.height, view.width, generator=torch.Generator().manual_seed(0))
+    g = oracle.backward(f, S, gi.numpy())
+
+    def step():
+        P = [torch.nn.Parameter(params[k].to(DEV)) for k in helpers.NAMES]
+        image = diff_rasterize(*P, torch.empty(0, device=DEV), RS)
+        (image * gi.to(DEV)).sum().backward()
+        return image.detach(), [p.grad for p in P]
+    set_async_forward(False)
+    ref_image, _ = step()
+    try:
+        set_async_forward(True)
+        step()                                   # synchronous: establishes the ratio
+        assert async_forward_stats()['ratio'] > 0
+        for _ in range(2):
+            image, grads = step()                # asynchronous
+            assert torch.equal(image, ref_image)
+            _grads_close(grads, g)
+        assert async_forward_stats()['overflows'] == 0
+        set_async_forward(True, headroom=0.4)    # capacity < need
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            _, grads = step()
+        assert any('exceeded the capacity' in str(x.message) for x in w) and async_forward_stats()['overflows'] == 1
+        _grads_close(grads, g)
+    finally:
+        set_async_forward(False)

@@ -239,3 +239,30 @@ def test_models_with_fewer_sh_bands(sim_backend, oracle, sh_bases):
     for k, t, m in zip(order, P, M):                # first Adam step: m = (1 - beta1) * g
         assert t.shape == p[k].shape
         assert torch.allclose(m, 0.1 * gmap[k], rtol=1e-4, atol=1e-9), k
+
+
+def test_forward_without_host_synchronisation(sim_backend, oracle):
+    """fgs_forward_async: buffers and launches sized by an instance capacity, counts read on the device. With enough capacity every result
+    equals the synchronous pass; with too little the excess instances are dropped, the flag is raised, nothing is written out of bounds."""
+    p, v = make_s0(seed=11, n=900)
+    p['means'][:, :2] *= 0.3
+    S, RS = helpers.settings_pair(v)
+    args = [p[k] for k in helpers.NAMES]
+    sync = sim_backend.forward(*args, RS)
+    n_inst = sync.state[1]
+    res = sim_backend.forward(*args, RS, instance_capacity=int(1.3 * n_inst) + 1000)
+    host, _ = sim_backend.forward_counts(res, 900)
+    assert host.tolist() == [sync.state[0], n_inst, 0] and res.state[:2] == (900, int(1.3 * n_inst) + 1000)
+    assert torch.equal(res.image, sync.image)
+    gi = torch.randn(3, v.height, v.width, generator=torch.Generator().manual_seed(0))
+    back = lambda r: sim_backend.backward(torch.zeros(2, 900), gi, r.image, p['means'], p['scales'], p['rotations'], p['opacities'],
+                                          p['sh_coefficients_rest'], r.buffers, RS, r.state)
+    for a, b in zip(back(res), back(sync)):
+        assert torch.equal(a, b)
+    exact = sim_backend.forward(*args, RS, instance_capacity=n_inst)                  # exactly enough
+    assert sim_backend.forward_counts(exact, 900)[0].tolist()[2] == 0 and torch.equal(exact.image, sync.image)
+    small = helpers.poisoned(sim_backend).forward(*args, RS, instance_capacity=n_inst // 2)
+    host, _ = sim_backend.forward_counts(small, 900)
+    assert host.tolist() == [sync.state[0], n_inst, 1] and torch.isfinite(small.image).all()
+    grads = back(small)                                                                # backward over the truncated lists stays in bounds
+    assert all(torch.isfinite(g).all() for g in grads)
