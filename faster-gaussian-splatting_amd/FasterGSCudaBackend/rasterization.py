@@ -58,7 +58,7 @@ class _Rasterize(torch.autograd.Function):
         be, n = default_backend(), means.shape[0]
         capacity = None
         if _ASYNC['enabled'] and _ASYNC['ratio'] > 0.0 and n > 0:
-            capacity = int(_ASYNC['ratio'] * n * _ASYNC['headroom']) + 65536
+            capacity = int(_ASYNC['ratio'] * n * _ASYNC['headroom']) + 4096
         res = be.forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings, capacity)
         if capacity is None:
             if n > 0:
