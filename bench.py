@@ -63,7 +63,7 @@ def build_scene(args):
 PMC_KERNELS = {       # stage -> substring of the kernel name in the rocprofv3 trace
     'adam': 'adam_kernel', 'blend_backward': 'blend_backward_compact_kernel', 'blend_forward': 'blend_kernel<true>',
     'preprocess': 'preprocess_kernel<false>', 'create_instances': 'create_instances_kernel', 'fused_backward_adam': 'fused_backward_adam_kernel',
-    'preprocess_backward': 'preprocess_backward_kernel', 'sh_rest_backward': 'sh_rest_gradient_kernel', 'tile_sort': 'radix_scatter_kernel<unsigned short',
+    'preprocess_backward': 'backward_gradients_kernel', 'sh_rest_backward': 'sh_rest_gradient_kernel', 'tile_sort': 'radix_scatter_kernel<unsigned short',
 }
 
 
@@ -336,7 +336,9 @@ def main():
         # instead of the reference's zero-fill + accumulate): the geometry kernel reads the tile count, the Gaussian (44 B), its 9
         # accumulators and its sh_rest coefficients (view-direction term), writes the 14 small gradients and the view direction;
         # the SH-rest kernel reads tile count, direction and colour gradient and writes the [N,K-1,3] gradient.
-        'preprocess_backward': 4.0 * n + (12.0 * (K_ - 1) + 44.0 + 36.0 + 12.0) * V + 56.0 * n,
+        # round 2: ONE kernel (tile count, Gaussian 44 B, 9 accumulators, sh_rest coefficients in; all 59 gradient floats out, written once);
+        # the round-1 split (fgs_debug_set_option(3, 0)) shows up as a separate 'sh_rest_backward' stage: 4 N + 24 V + 12 (K - 1) N
+        'preprocess_backward': 4.0 * n + (12.0 * (K_ - 1) + 44.0 + 36.0) * V + 236.0 * n,
         'sh_rest_backward': 4.0 * n + 24.0 * V + 12.0 * (K_ - 1) * n,
         'fused_backward_adam': 1416.0 * n + 4.0 * n + 52.0 * V,           # 59 floats x 24 B of state + tile count + accumulators / densification
         'adam': 1652.0 * n / (world if (vp is not None and args.dp_mode != 'allreduce') else 1),     # zero1 / sharded: Adam on 1/G
@@ -345,7 +347,7 @@ def main():
     kernel_of = {'preprocess': 'preprocess_kernel<false>', 'blend_backward': 'blend_backward_compact_kernel', 'adam': 'adam_kernel<1, true>',
                  'blend_forward': 'blend_kernel<true>', 'create_instances': 'create_instances_kernel<u16>',
                  'tile_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u16, 7> x 2 passes', 'sh_rest_backward': 'sh_rest_gradient_kernel<15, false>',
-                 'preprocess_backward': 'preprocess_backward_kernel<false, false>',
+                 'preprocess_backward': 'backward_gradients_kernel<15>',
                  'depth_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u32, 8> x 4 passes', 'fused_backward_adam': 'fused_backward_adam_kernel<15>'}
     per_launch = {k: v_[0] / n_prof for k, v_ in prof.items() if v_[1] > 0}   # ms per step, from the untimed stage-profile pass
     dom = dom_stage

@@ -174,7 +174,7 @@ struct BackwardScratch {
 };
 
 int g_seq_tiles = kSeqTiles;           // fgs_debug_set_option key 5
-int g_fused_single_kernel = 1;         // fgs_debug_set_option key 3: fgs_backward_adam_fused as one kernel (1) or as round 1's two (0)
+int g_fused_single_kernel = 1;         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
@@ -495,14 +495,17 @@ int32_t fgs_backward(const float* grad_image, const float* image,
     a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
     a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
     a.n = static_cast<uint32_t>(n_primitives);
-    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }   // K12 (bwd:94)
-    if (settings->total_sh_bases_rest > 0) {
-        if (!grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
-        ShRestArgs s{};
-        s.n_views = 1; s.view[0] = sh_rest_view(a.view[0]); s.grad_sh_rest = grad_sh_coefficients_rest;
-        s.n = a.n; s.total_sh_rest = settings->total_sh_bases_rest; s.active_sh_bases = settings->active_sh_bases;
-        { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, s, stream)); }
+    if (settings->total_sh_bases_rest > 0 && !grad_sh_coefficients_rest) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL grad_sh_coefficients_rest");
+    ShRestArgs sh{};
+    sh.n_views = 1; sh.view[0] = sh_rest_view(a.view[0]); sh.grad_sh_rest = grad_sh_coefficients_rest;
+    sh.n = a.n; sh.total_sh_rest = settings->total_sh_bases_rest; sh.active_sh_bases = settings->active_sh_bases;
+    if (g_fused_single_kernel) {           // K12 (bwd:94) as one kernel
+        StageScope t(ST_PREPROCESS_BACKWARD, stream);
+        FGS_HIP(launch_backward_gradients(a, sh, stream));
+        return FGS_OK;
     }
+    { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }   // round-1 form: geometry kernel + SH-rest kernel
+    if (settings->total_sh_bases_rest > 0) { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, sh, stream)); }
     return FGS_OK;
 }
 

@@ -131,6 +131,8 @@ struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload
 hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStream_t s);
 // single-view fused backward + Adam over all 59 floats of every Gaussian in one kernel (a: fused-mode arguments, sh: the SH-rest group)
 hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s);
+// single-view unfused K12 in one kernel: all six gradients written once (sh: grad_sh_rest + SH layout)
+hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s);
 
 struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
 struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };

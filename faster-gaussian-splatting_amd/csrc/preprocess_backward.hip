@@ -331,6 +331,65 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
     }
 }
 
+// Unfused single-view K12 as ONE kernel (the form fgs_backward uses): the same wave layout as fused_backward_adam_kernel, with the
+// gradients written instead of applied. Against round 1's two kernels it drops the view-direction round trip through HBM and the second
+// read of tile counts / colour gradients, and keeps the fully coalesced 16-byte stores of the [N, R, 3] gradient (every element of every
+// gradient is written exactly once, zeros for invisible Gaussians: no zero-fill, rasterization_api.cu:127-134).
+template <int RT>
+__global__ void __launch_bounds__(256) backward_gradients_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) {
+    __shared__ __attribute__((aligned(16))) float s_grad[256 / kWave][kWave * 15 * 3];
+    const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : sh.total_sh_rest;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * 256u + wv * kWave;
+    if (first >= a.n) return;                                         // wave-uniform
+    const uint32_t i = first + lane;
+    const bool in_range = i < a.n;
+    float grad[14], dir[3] = {0.0f, 0.0f, 0.0f}, gcol[3] = {0.0f, 0.0f, 0.0f};
+    const float unused[14] = {};
+    bool visible = false;
+    if (in_range) {
+        visible = gaussian_backward<false, false, true>(a, i, unused, grad, dir, gcol);
+        float* const outs[5] = {a.grad_means, a.grad_sh0, a.grad_opacities, a.grad_scales, a.grad_rotations};
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) outs[grp][(size_t)i * kGroupWidth[grp] + k] = grad[kGroupOffset[grp] + k];
+    }
+    if (R == 0) return;
+    const bool any_visible = wave_ballot(visible) != 0;
+    float* const slice = s_grad[wv];
+    if (any_visible) {
+        float B[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) B[k] = 0.0f;
+        if (visible && sh.active_sh_bases > 1) sh_basis(dir[0], dir[1], dir[2], sh.active_sh_bases, B);
+        float* const mine = slice + lane * R * 3u;
+#pragma unroll
+        for (int k = 0; k < 15; ++k)
+            if (static_cast<uint32_t>(k) < R) { mine[3 * k] = B[k] * gcol[0]; mine[3 * k + 1] = B[k] * gcol[1]; mine[3 * k + 2] = B[k] * gcol[2]; }
+        wave_lds_fence();
+    }
+    const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;
+    float* const out = sh.grad_sh_rest + (size_t)first * R * 3u;
+    for (uint32_t e = 4u * lane; e < count; e += 4u * kWave) {
+        if (e + 4u <= count) {
+            const float4 g = any_visible ? *reinterpret_cast<const float4*>(slice + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            *reinterpret_cast<float4*>(out + e) = g;
+        } else {
+            for (uint32_t j = e; j < count; ++j) out[j] = any_visible ? slice[j] : 0.0f;
+        }
+    }
+}
+
+hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
+    const dim3 grid((a.n + 255u) / 256u), block(256);
+    if (sh.total_sh_rest == 15) hipLaunchKernelGGL(backward_gradients_kernel<15>, grid, block, 0, s, a, sh);
+    else hipLaunchKernelGGL(backward_gradients_kernel<0>, grid, block, 0, s, a, sh);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
