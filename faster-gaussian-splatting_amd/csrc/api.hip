@@ -992,6 +992,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
         case 3: g_fused_single_kernel = value ? 1 : 0; return FGS_OK;
         case 7: fgs::g_backward_ablate = value & 15; return FGS_OK;
+        case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;

@@ -135,7 +135,7 @@ hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShR
 hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s);
 
 struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
-struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; };
+struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; int reverse; };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);   // K13, all groups in one launch
 
 struct LossArgs {                       // fused L1 + DSSIM loss and its image gradient (loss.hip)
@@ -194,6 +194,7 @@ hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
 size_t morton_temp_bytes(uint32_t n);
 hipError_t run_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 
+extern int g_adam_reverse;
 extern int g_adam_nontemporal;                                  // 0 | 1
 extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
 extern int g_backward_ablate;

@@ -625,6 +625,7 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
 
 // ---- K13: Adam for all parameter groups in one launch (adam.cu:10-34), float4-vectorised, U pieces per thread ----------
 int g_adam_unroll = 1;   // 16-byte pieces per thread (fgs_debug_set_option(1, u)); measured on MI355X: 1, 2 and 4 are within 2 %
+int g_adam_reverse = 1;       // fgs_debug_set_option(8, 0|1): reversed workgroup order (measured 0.837 vs 0.855 ms at S2, tools/ab_adam_order.py)
 int g_adam_nontemporal = 1;   // fgs_debug_set_option(2, 0|1): non-temporal loads / stores (state is streamed once per step: +2.3 % measured)
 
 template <bool NT> __device__ __forceinline__ float4 load4(const float* p) { return NT ? load_float4_nt(p) : *reinterpret_cast<const float4*>(p); }
@@ -635,11 +636,14 @@ template <bool NT> __device__ __forceinline__ void store4(float* p, const float4
 
 template <int U, bool NT>
 __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
+    // a.reverse: workgroups walk the arenas from the end -- the gradient elements the backward pass wrote LAST are the ones most likely to
+    // still sit in the 256 MB memory-side cache
+    const uint32_t blk = a.reverse ? a.total_blocks - 1u - blockIdx.x : blockIdx.x;
     int gidx = 0;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) if (j < a.n_groups && blockIdx.x >= a.g[j].first_block) gidx = j;
+    for (int j = 1; j < 8; ++j) if (j < a.n_groups && blk >= a.g[j].first_block) gidx = j;
     const AdamGroup& G = a.g[gidx];
-    const int64_t block_base = (int64_t)(blockIdx.x - G.first_block) * (256 * 4 * U);
+    const int64_t block_base = (int64_t)(blk - G.first_block) * (256 * 4 * U);
     float4 g4[U], p4[U], m4[U], v4[U];
     bool full[U];
 #pragma unroll
@@ -678,6 +682,7 @@ hipError_t launch_adam(const AdamArgs& a_in, hipStream_t s) {
     uint32_t blocks = 0;                                  // first_block / total_blocks depend on the elements per workgroup
     for (int k = 0; k < a.n_groups; ++k) { a.g[k].first_block = blocks; blocks += static_cast<uint32_t>((a.g[k].n + 1024 * u - 1) / (1024 * u)); }
     a.total_blocks = blocks;
+    a.reverse = g_adam_reverse;
     if (blocks == 0) return hipSuccess;
     if (g_adam_nontemporal) hipLaunchKernelGGL((adam_kernel<1, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (u == 1) hipLaunchKernelGGL((adam_kernel<1, false>), dim3(blocks), dim3(256), 0, s, a);
