@@ -173,8 +173,8 @@ struct BackwardScratch {
     }
 };
 
-int g_seq_tiles = kSeqTiles;           // fgs_debug_set_option key 5
-int g_fused_single_kernel = 1;         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
+std::atomic<int> g_seq_tiles{kSeqTiles};           // fgs_debug_set_option key 5
+std::atomic<int> g_fused_single_kernel{1};         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);

@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendB
     if (sum != 0.0f) a.acc[(size_t)k * a.n + a.hot_list[slot]] += sum;      // one slot per primitive: no other writer at this point
 }
 
-int g_backward_ablate = 0;    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
-int g_backward_variant = 3;   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
+std::atomic<int> g_backward_ablate{0};    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
+std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
                               // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
                               // fgs_debug_set_backward_variant()
 

@@ -2,6 +2,7 @@
 // stage ids K0..K13 refer to SURVEY.md section 2.1.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -56,7 +57,9 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* key
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s);
 
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
-extern int g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
+// The A/B switches behind fgs_debug_set_option are process-wide; atomics make concurrent set / launch well defined (a launch sees the
+// old or the new value, never a torn one).
+extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
@@ -194,11 +197,11 @@ hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
 size_t morton_temp_bytes(uint32_t n);
 hipError_t run_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 
-extern int g_adam_reverse;
-extern int g_adam_nontemporal;                                  // 0 | 1
-extern int g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
-extern int g_backward_ablate;
-extern int g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
+extern std::atomic<int> g_adam_reverse;
+extern std::atomic<int> g_adam_nontemporal;                                  // 0 | 1
+extern std::atomic<int> g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
+extern std::atomic<int> g_backward_ablate;
+extern std::atomic<int> g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 
 }  // namespace fgs

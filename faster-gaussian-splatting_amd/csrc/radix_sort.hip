@@ -241,7 +241,7 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
 }  // namespace sortimpl
 using namespace sortimpl;
 
-int g_sort_implementation = 3;          // bit 0: tile sort here, bit 1: depth sort here; cleared bit = rocPRIM onesweep (fgs_debug_set_option key 6)
+std::atomic<int> g_sort_implementation{3};          // bit 0: tile sort here, bit 1: depth sort here; cleared bit = rocPRIM onesweep (fgs_debug_set_option key 6)
 
 size_t own_sort_temp_bytes(uint32_t n, int end_bit) {
     const SortPlan p = plan_sort(n, end_bit);
