@@ -95,7 +95,9 @@ def training_iteration(g: Gaussians, view: View, target: torch.Tensor, iteration
     optimizer.step -> zero_grad. `before_step` (if given) runs between backward and step (gradient exchange hook)."""
     g.update_learning_rate(iteration + 1)
     image = render_image_training(g, view, update_densification_info=iteration < densification_end, bg_color=view.background_color)
-    loss = loss_fn(image, target) * loss_scale
+    loss = loss_fn(image, target)
+    if loss_scale != 1.0:                 # (two elementwise launches per iteration otherwise)
+        loss = loss * loss_scale
     loss.backward()
     if before_step is not None:
         before_step()
