@@ -48,10 +48,14 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;
     unsigned n_used = 0;
-    bool done = !inside;
+    // "done" (kf:424,477) is not carried as a flag: a pixel is finished exactly when its transmittance has dropped below the threshold
+    // (T only ever decreases and the flag is set right after the update that takes it there), or when it lies outside the image. A
+    // divergent flag carried through the per-Gaussian loop lives in a scalar register pair that has to be merged after every
+    // conditional update (three scalar instructions per merge), and this loop is bound by the ONE scalar unit of the CU.
+#define FGS_PIXEL_DONE (!inside || T < kTransmittanceThreshold)
 
     for (unsigned batch_start = 0; batch_start < n_total; batch_start += kBlendBlock) {
-        if (__syncthreads_and(done ? 1 : 0)) break;                                    // kf:424
+        if (__syncthreads_and(FGS_PIXEL_DONE ? 1 : 0)) break;                          // kf:424
         const unsigned batch = min(static_cast<unsigned>(kBlendBlock), n_total - batch_start);
         if (tid < batch) {
             const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
@@ -68,6 +72,7 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
         }
         __syncthreads();
         for (unsigned chunk = 0; chunk < batch; chunk += kBucket) {
+            const bool done = FGS_PIXEL_DONE;
             if (TRAINING && !done)                                                     // kf:436-442, every 64 instead of 32
                 a.ckpt[(size_t)(bucket_base + (batch_start + chunk) / kBucket) * kTilePixels + local] = make_float4(cr, cg, cb, T);
             bool in_l = false, in_r = false;
@@ -80,28 +85,32 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
                 in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
             }
             const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
-            const uint64_t mine = half ? mask_r : mask_l;
+            const uint64_t mine = inside ? (half ? mask_r : mask_l) : 0ull;            // pixels outside the image never blend
             uint64_t pending = mask_l | mask_r;
             if (wave_ballot(!done) == 0) pending = 0;
             while (pending != 0) {                                                     // wave-uniform scalar loop
                 const int k = __ffsll(static_cast<unsigned long long>(pending)) - 1;
                 pending &= pending - 1;
-                if (done || !((mine >> k) & 1ull)) continue;
                 const unsigned jj = chunk + static_cast<unsigned>(k);
                 const float4 ga = s_a[jj], gb = s_b[jj];
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
                 const float gauss = __expf(fminf(power, 0.0f));
                 const float alpha = gb.y * gauss;
-                if (alpha < kMinAlphaThreshold) continue;
-                const float w = T * alpha;
-                cr += w * gb.z; cg += w * gb.w; cb += w * s_c[jj].x;
-                T *= 1.0f - alpha;
-                n_used = batch_start + jj + 1;                                         // kf:474
-                if (T < kTransmittanceThreshold) done = true;                          // kf:477
+                // ONE predicate per (pixel, Gaussian) pair -- own sub-tile overlaps (kf:445-451), pixel not finished (kf:424,477), alpha
+                // test (kf:467) -- instead of three nested early-outs: every nested `continue` costs an EXEC save / branch / restore on
+                // the scalar unit (rocprofv3 on the layered scene, round 2: SQ_INSTS_SALU = SQ_INSTS_VALU = 457 M per launch, i.e. 0.74 ms
+                // of the kernel's 1.13 ms at one scalar instruction per cycle and CU).
+                if (((mine >> k) & 1ull) != 0 && T >= kTransmittanceThreshold && alpha >= kMinAlphaThreshold) {
+                    const float w = T * alpha;
+                    cr += w * gb.z; cg += w * gb.w; cb += w * s_c[jj].x;
+                    T *= 1.0f - alpha;
+                    n_used = batch_start + jj + 1;                                     // kf:474
+                }
             }
         }
     }
+#undef FGS_PIXEL_DONE
 
     if (inside) {
         cr += T * a.bg[0]; cg += T * a.bg[1]; cb += T * a.bg[2];                      // kf:483
