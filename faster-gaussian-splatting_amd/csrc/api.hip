@@ -123,6 +123,7 @@ struct PrimitiveBuffers {             // cf. bu:45-94
 struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed are tile-major here
     uint2* ranges; uint32_t* bucket_offsets; uint32_t* max_n_processed; float* final_T; uint32_t* n_processed;
     uint32_t* live_count;             // backward: number of live buckets (K11 planning pass)
+    uint32_t* live_offsets;           // backward: first slot of each tile in the live-bucket list
     char* temp; size_t temp_bytes;
     static TileBuffers carve(Carver& c, uint32_t t, bool training) {
         TileBuffers b{};
@@ -135,6 +136,7 @@ struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed a
             b.temp_bytes = bucket_scan_temp_bytes(t);
             b.temp = c.take<char>("scan_temp", b.temp_bytes);
             b.live_count = c.take<uint32_t>("live_count", 4);
+            b.live_offsets = c.take<uint32_t>("live_offsets", t);
         }
         return b;
     }
@@ -402,7 +404,7 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
     a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
-    a.work_list = P.bb.work_list; a.live_count = P.tb.live_count;
+    a.work_list = P.bb.work_list; a.live_count = P.tb.live_count; a.live_offsets = P.tb.live_offsets;
     a.acc_hot = P.sc.acc_hot; a.hot_list = P.pb.hot_list; a.hot_count = P.pb.counters + 4;
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);

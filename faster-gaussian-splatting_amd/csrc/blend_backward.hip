@@ -36,6 +36,13 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
     }
     a.pixrec[((size_t)tile * kTilePixels + local) * 2] = g;
     a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1] = c;
+    // the tile's entries of the live-bucket list (variant 3): the planning pass has scanned the per-tile counts, the entries are written here,
+    // by 12 k workgroups instead of one
+    if (a.live_offsets != nullptr) {
+        const unsigned nl = (a.max_n_processed[tile] + kBucket - 1) / kBucket;              // kb:295
+        const unsigned base = a.live_offsets[tile];
+        for (unsigned k = local; k < nl; k += kTilePixels) a.work_list[base + k] = make_uint2(tile, k);
+    }
 }
 
 template <bool GLOBAL_GRAD>
@@ -310,10 +317,10 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
 //      (kb:438), and dL/dmean2d = 2 [a b; b c] (sum(hh dx), sum(hh dy)) (kb:449-453) with hh = -alpha/2 dL/dalpha.
 //      About 50 VALU instructions per step remain.
 __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBackwardArgs a) {
-    // One workgroup; tiles are taken 1024 at a time (thread t <-> tile chunk * 1024 + t: coalesced, and the loads of up to
-    // kPlanChunks chunks are all issued before the first scan -- a thread that walked "its" 12 consecutive tiles with dependent
-    // loads made this pass latency-bound at 33 us). Per chunk: wave prefix sum + 16 wave totals through LDS, then every thread
-    // writes the (tile, bucket) pairs of its tile. List order = tile order.
+    // One workgroup: exclusive scan of the live-bucket count of every tile (tiles taken 1024 at a time: thread t <-> tile chunk * 1024 + t,
+    // coalesced; the loads of up to kPlanChunks chunks are all issued before the first scan -- a thread that walked "its" 12 consecutive
+    // tiles with dependent loads made this pass latency-bound at 33 us). live_offsets[tile] = first list slot of the tile; the entries
+    // themselves are written by stage_pixels_kernel (a single workgroup writing 115 k entries took 58 us on the layered scene).
     constexpr int kPlanChunks = 16;                           // 16 Ki tiles (1080p: 12 240) per batch of loads
     __shared__ uint32_t s_wave_total[2][1024 / kWave];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBa
                 mine += w < wv ? wt : 0u;
                 total += wt;
             }
-            for (uint32_t k = 0; k < nl[c]; ++k) a.work_list[mine + k] = make_uint2(t, k);
+            if (t < a.n_tiles) a.live_offsets[t] = mine;
             base += total;
             parity ^= 1;                                      // the next chunk writes the other LDS row: one barrier per chunk
         }
@@ -515,7 +522,10 @@ std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted 
                               // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
                               // fgs_debug_set_backward_variant()
 
-hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s) {
+hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
+    BlendBackwardArgs a = a_in;
+    if (g_backward_variant == 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(1024), 0, s, a);
+    else a.live_offsets = nullptr;                            // the other variants walk all buckets: no list
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
     return hipGetLastError();
 }
@@ -526,7 +536,6 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
     if (g_backward_variant == 3) {
         BlendBackwardArgs a = a_in;
         a.ablate = g_backward_ablate;
-        hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(1024), 0, s, a);
         // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
         // for the launch of a quarter of a million empty ones
         const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;

@@ -161,9 +161,10 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
 
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) { galpha = T * -(a.bg[0] + a.bg[1] + a.bg[2]); T = 1.0f; }                 // kp:441-444
-        bool done = !inside;
+        // "done" derived from T as in blend_kernel (the loop is bound by the scalar unit; a carried divergent flag costs scalar merges)
+#define FGS_PIXEL_DONE (!inside || T < kTransmittanceThreshold)
         for (unsigned batch_start = 0; batch_start < n_total; batch_start += kBlendBlock) {
-            if (__syncthreads_and(done ? 1 : 0)) break;
+            if (__syncthreads_and(FGS_PIXEL_DONE ? 1 : 0)) break;
             const unsigned batch = min(static_cast<unsigned>(kBlendBlock), n_total - batch_start);
             if (tid < batch) {
                 const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
                 const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
                 const uint64_t mine = half ? mask_r : mask_l;
                 uint64_t pending = mask_l | mask_r;
-                if (wave_ballot(!done) == 0) pending = 0;
+                if (wave_ballot(!FGS_PIXEL_DONE) == 0) pending = 0;
                 while (pending != 0) {
                     const int k = __ffsll(static_cast<unsigned long long>(pending)) - 1;
                     pending &= pending - 1;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
                     const float dx = ga.x - pxf, dy = ga.y - pyf;
                     const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
                     const float alpha = gb.y * __expf(fminf(power, 0.0f));
-                    const bool contrib = !done && ((mine >> k) & 1ull) && alpha >= kMinAlphaThreshold;
+                    const bool contrib = inside && ((mine >> k) & 1ull) != 0 && T >= kTransmittanceThreshold && alpha >= kMinAlphaThreshold;
                     float score = 0.0f;
                     if (contrib) {
                         const float w = T * alpha;
@@ -207,7 +208,6 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
                             score = dl_dg * dl_dg;                                                   // kp:487-488
                         }
                         T *= 1.0f - alpha;
-                        if (T < kTransmittanceThreshold) done = true;
                     }
                     if (pass == 1 && wave_ballot(contrib) != 0) {                                   // wave-uniform
                         const float total = wave_sum_to_lane63(score);
@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
             }
         }
     }
+#undef FGS_PIXEL_DONE
 }
 
 hipError_t launch_pruning_scores(const BlendArgs& a, hipStream_t s) {

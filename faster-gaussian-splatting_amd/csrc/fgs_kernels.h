@@ -94,7 +94,8 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
     float* acc_hot;                       // [kHotReplicas][9][kMaxHot]: private accumulators of the hot Gaussians
     const uint32_t* hot_list; const uint32_t* hot_count;   // slot -> primitive, number of slots handed out (may exceed kMaxHot)
-    uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket, written by the planning pass
+    uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket and their number
+    uint32_t* live_offsets;                   // [T] first list slot of each tile (planning pass -> stage_pixels_kernel)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
     int ablate;                           // debug timing experiments (fgs_debug_set_option key 7); 0 in production
