@@ -5,8 +5,8 @@
 // C2 = 0.03^2, mean over channels and pixels); tests/test_loss.py pins it against a torch conv2d + autograd implementation.
 //
 // Two launches replace the ~30 elementwise/conv kernels of a framework-level SSIM:
-//   ssim_forward_kernel : 32x16 output tile per 256-thread workgroup, x/y tile + 5-pixel halo staged in LDS, separable
-//                         filtering (11 horizontal taps into LDS, 11 vertical taps), SSIM value + the three partial
+//   ssim_forward_kernel : 32x32 output tile per 256-thread workgroup, x/y tile + 5-pixel halo staged in LDS, separable
+//                         register-blocked filtering (11 horizontal taps into LDS, 11 vertical taps), SSIM value + the three partial
 //                         derivative maps (d/dmu1, d/dE[x^2], d/dE[xy]); per-workgroup sums leave through two atomics.
 //   ssim_backward_kernel: filters the three derivative maps with the same (self-adjoint) window and combines them with
 //                         x, y and the L1 sign: dloss/dimage, no dependence on the loss value -> no host sync anywhere.
@@ -15,8 +15,16 @@
 
 namespace fgs {
 
-constexpr int kLossTileW = 32, kLossTileH = 16, kHalo = 5, kTaps = 11;
-constexpr int kRegionW = kLossTileW + 2 * kHalo, kRegionH = kLossTileH + 2 * kHalo;   // 42 x 26
+#ifndef FGS_LOSS_TILE_W
+#define FGS_LOSS_TILE_W 32   // tools/ab_loss_tiles.sh, 1080p, one box, loss stage: unblocked 32x16 (round 1) 0.182 ms; blocked 32x16 0.164,
+#define FGS_LOSS_TILE_H 32   // 32x32 0.150 (default), 64x16 0.160, 64x32 0.175 (206 VGPRs + 79 KB LDS: 2 workgroups per CU)
+#endif
+constexpr int kLossTileW = FGS_LOSS_TILE_W, kLossTileH = FGS_LOSS_TILE_H, kHalo = 5, kTaps = 11;
+constexpr int kRegionW = kLossTileW + 2 * kHalo, kRegionH = kLossTileH + 2 * kHalo;   // 42 x 42: halo re-reads 1.72x (32x16 tiles: 2.13x;
+                                                                                      // rocprofv3 round 2: 239 MB fetched for 50 MB of input)
+constexpr int kRowsPerThread = (kLossTileW * kLossTileH) / 256;                       // 4: thread = one output column x 4 consecutive rows
+constexpr int kHzGroups = kLossTileW / 4;                                             // horizontal pass: 4 adjacent outputs per work item
+static_assert(kLossTileW * (kLossTileH / kRowsPerThread) == 256, "one (column, row strip) per thread");
 
 struct GaussWindow { float w[kTaps]; };
 
@@ -28,52 +36,74 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {   // sum
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// Both filter passes are register-blocked: round 2's profile had 417 lane-instructions per output (one LDS read and an index div/mod per
+// FMA); the horizontal pass now takes 14 staged values for 4 outputs x 11 taps, the vertical pass kRowsPerThread + 10 for kRowsPerThread
+// outputs. Staging keeps a flat index: a row-per-128-threads loop (no div/mod, 42 % idle lanes in the global loads) measured 0.213 ms at 64x32.
+template <int MAPS, typename Load>
+__device__ __forceinline__ void stage_region(float (*dst)[kRegionH][kRegionW], const int x0, const int y0, const int width, const int height, Load load) {
+    for (int idx = threadIdx.x; idx < kRegionH * kRegionW; idx += 256) {            // flat index: every lane loads (division by a constant)
+        const int ry = idx / kRegionW, rx = idx - ry * kRegionW;
+        const int gy = y0 + ry - kHalo, gx = x0 + rx - kHalo;
+        const bool in = gy >= 0 && gy < height && gx >= 0 && gx < width;            // zero padding
+#pragma unroll
+        for (int k = 0; k < MAPS; ++k) dst[k][ry][rx] = in ? load(k, (size_t)gy * width + gx) : 0.0f;
+    }
+}
+
 __global__ void __launch_bounds__(256) ssim_forward_kernel(const LossArgs a, const GaussWindow gw) {
-    __shared__ float sx[kRegionH][kRegionW], sy[kRegionH][kRegionW];
+    __shared__ float sxy[2][kRegionH][kRegionW];
     __shared__ float hz[5][kRegionH][kLossTileW];
     __shared__ float s_red[2][4];
     const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ X = a.image + c * plane; const float* __restrict__ Y = a.target + c * plane;
-    for (int idx = threadIdx.x; idx < kRegionH * kRegionW; idx += 256) {
-        const int ry = idx / kRegionW, rx = idx - ry * kRegionW;
-        const int gy = y0 + ry - kHalo, gx = x0 + rx - kHalo;
-        const bool in = gy >= 0 && gy < a.height && gx >= 0 && gx < a.width;      // zero padding
-        sx[ry][rx] = in ? X[(size_t)gy * a.width + gx] : 0.0f;
-        sy[ry][rx] = in ? Y[(size_t)gy * a.width + gx] : 0.0f;
-    }
+    stage_region<2>(sxy, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? X[e] : Y[e]; });
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kRegionH * kLossTileW; idx += 256) {       // horizontal taps
-        const int ry = idx / kLossTileW, cx = idx - ry * kLossTileW;
-        float m1 = 0.0f, m2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
+    for (int item = threadIdx.x; item < kRegionH * kHzGroups; item += 256) {       // horizontal taps: 4 outputs from 14 inputs
+        const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+        float p[14], q[14];
 #pragma unroll
-        for (int t = 0; t < kTaps; ++t) {
-            const float w = gw.w[t], p = sx[ry][cx + t], q = sy[ry][cx + t];
-            m1 += w * p; m2 += w * q; m11 += w * p * p; m22 += w * q * q; m12 += w * p * q;
+        for (int t = 0; t < 14; ++t) { p[t] = sxy[0][ry][cx + t]; q[t] = sxy[1][ry][cx + t]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float m1 = 0.0f, m2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < kTaps; ++t) {
+                const float w = gw.w[t], pp = p[o + t], qq = q[o + t];
+                m1 += w * pp; m2 += w * qq; m11 += w * pp * pp; m22 += w * qq * qq; m12 += w * pp * qq;
+            }
+            hz[0][ry][cx + o] = m1; hz[1][ry][cx + o] = m2; hz[2][ry][cx + o] = m11; hz[3][ry][cx + o] = m22; hz[4][ry][cx + o] = m12;
         }
-        hz[0][ry][cx] = m1; hz[1][ry][cx] = m2; hz[2][ry][cx] = m11; hz[3][ry][cx] = m22; hz[4][ry][cx] = m12;
     }
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float ssim_sum = 0.0f, l1_sum = 0.0f;
+    const int ox = threadIdx.x % kLossTileW, oy0 = (threadIdx.x / kLossTileW) * kRowsPerThread;   // lanes of a wave: adjacent columns
+    const int gx = x0 + ox;
+    float v[5][kRowsPerThread];
 #pragma unroll
-    for (int o = 0; o < (kLossTileW * kLossTileH) / 256; ++o) {                    // vertical taps, 2 outputs per thread
-        const int idx = threadIdx.x + 256 * o;
-        const int oy = idx / kLossTileW, ox = idx - oy * kLossTileW;
-        const int gy = y0 + oy, gx = x0 + ox;
-        float mu1 = 0.0f, mu2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
+    for (int m = 0; m < 5; ++m) {                                                   // vertical taps: 8 outputs from 18 inputs per map
+        float col[kRowsPerThread + kTaps - 1];
 #pragma unroll
-        for (int t = 0; t < kTaps; ++t) {
-            const float w = gw.w[t];
-            mu1 += w * hz[0][oy + t][ox]; mu2 += w * hz[1][oy + t][ox]; m11 += w * hz[2][oy + t][ox];
-            m22 += w * hz[3][oy + t][ox]; m12 += w * hz[4][oy + t][ox];
+        for (int t = 0; t < kRowsPerThread + kTaps - 1; ++t) col[t] = hz[m][oy0 + t][ox];
+#pragma unroll
+        for (int o = 0; o < kRowsPerThread; ++o) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < kTaps; ++t) acc += gw.w[t] * col[o + t];
+            v[m][o] = acc;
         }
+    }
+#pragma unroll
+    for (int o = 0; o < kRowsPerThread; ++o) {
+        const int oy = oy0 + o, gy = y0 + oy;
         if (gy < a.height && gx < a.width) {
+            const float mu1 = v[0][o], mu2 = v[1][o], m11 = v[2][o], m22 = v[3][o], m12 = v[4][o];
             const float s11 = m11 - mu1 * mu1, s22 = m22 - mu2 * mu2, s12 = m12 - mu1 * mu2;
             const float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
             const float den = B1 * B2;
             ssim_sum += (A1 * A2) / den;
-            l1_sum += fabsf(sx[oy + kHalo][ox + kHalo] - sy[oy + kHalo][ox + kHalo]);
+            l1_sum += fabsf(sxy[0][oy + kHalo][ox + kHalo] - sxy[1][oy + kHalo][ox + kHalo]);
             const size_t e = c * plane + (size_t)gy * a.width + gx;
             a.d_mu[e] = ((2.0f * mu2 * A2 - 2.0f * mu2 * A1) * den - A1 * A2 * (2.0f * mu1 * B2 - 2.0f * mu1 * B1)) / (den * den);
             a.d_m11[e] = -(A1 * A2) / (B1 * B2 * B2);
@@ -82,8 +112,8 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(const LossArgs a, con
     }
     const float bl = block_sum_256(l1_sum, s_red[0]);
     const float bs = block_sum_256(ssim_sum, s_red[1]);
-    // per-workgroup partial sums, reduced by ssim_reduce_kernel: 12 k workgroups adding to two words would serialise on the
-    // same-address atomic rate (~88/us on this chip: measured 0.28 ms at 1080p), and a fixed order makes the loss reproducible
+    // per-workgroup partial sums, reduced by ssim_reduce_kernel: thousands of workgroups adding to two words would serialise on the
+    // same-address atomic rate (measured 0.28 ms at 1080p), and a fixed order makes the loss reproducible
     if (threadIdx.x == 255) {
         const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         a.partials[2 * b] = bl; a.partials[2 * b + 1] = bs;
@@ -92,8 +122,9 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(const LossArgs a, con
 
 __global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, const unsigned n_blocks) {
     __shared__ float s_red[2][4];
+    const float2* __restrict__ part = reinterpret_cast<const float2*>(a.partials);
     float l1 = 0.0f, ss = 0.0f;
-    for (unsigned b = threadIdx.x; b < n_blocks; b += 256u) { l1 += a.partials[2 * b]; ss += a.partials[2 * b + 1]; }
+    for (unsigned b = threadIdx.x; b < n_blocks; b += 256u) { const float2 v = part[b]; l1 += v.x; ss += v.y; }
     const float tl = block_sum_256(l1, s_red[0]);
     const float ts = block_sum_256(ss, s_red[1]);
     if (threadIdx.x == 255) {
@@ -109,39 +140,53 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
     __shared__ float hz[3][kRegionH][kLossTileW];
     const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
     const size_t plane = (size_t)a.width * a.height;
-    const float* const maps[3] = {a.d_mu + c * plane, a.d_m11 + c * plane, a.d_m12 + c * plane};
-    for (int idx = threadIdx.x; idx < kRegionH * kRegionW; idx += 256) {
-        const int ry = idx / kRegionW, rx = idx - ry * kRegionW;
-        const int gy = y0 + ry - kHalo, gx = x0 + rx - kHalo;
-        const bool in = gy >= 0 && gy < a.height && gx >= 0 && gx < a.width;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sd[k][ry][rx] = in ? maps[k][(size_t)gy * a.width + gx] : 0.0f;
-    }
+    const float* __restrict__ m0 = a.d_mu + c * plane; const float* __restrict__ m1 = a.d_m11 + c * plane; const float* __restrict__ m2 = a.d_m12 + c * plane;
+    stage_region<3>(sd, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? m0[e] : (k == 1 ? m1[e] : m2[e]); });
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kRegionH * kLossTileW; idx += 256) {
-        const int ry = idx / kLossTileW, cx = idx - ry * kLossTileW;
-        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+    for (int item = threadIdx.x; item < kRegionH * kHzGroups; item += 256) {
+        const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
 #pragma unroll
-        for (int t = 0; t < kTaps; ++t) { const float w = gw.w[t]; f0 += w * sd[0][ry][cx + t]; f1 += w * sd[1][ry][cx + t]; f2 += w * sd[2][ry][cx + t]; }
-        hz[0][ry][cx] = f0; hz[1][ry][cx] = f1; hz[2][ry][cx] = f2;
+        for (int k = 0; k < 3; ++k) {
+            float p[14];
+#pragma unroll
+            for (int t = 0; t < 14; ++t) p[t] = sd[k][ry][cx + t];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float f = 0.0f;
+#pragma unroll
+                for (int t = 0; t < kTaps; ++t) f += gw.w[t] * p[o + t];
+                hz[k][ry][cx + o] = f;
+            }
+        }
     }
     __syncthreads();
     const float n_total = 3.0f * static_cast<float>(a.width) * static_cast<float>(a.height);
     const float ks = -a.lambda_dssim / n_total, kl = a.lambda_l1 / n_total;
+    const int ox = threadIdx.x % kLossTileW, oy0 = (threadIdx.x / kLossTileW) * kRowsPerThread;
+    const int gx = x0 + ox;
+    float v[3][kRowsPerThread];
 #pragma unroll
-    for (int o = 0; o < (kLossTileW * kLossTileH) / 256; ++o) {
-        const int idx = threadIdx.x + 256 * o;
-        const int oy = idx / kLossTileW, ox = idx - oy * kLossTileW;
-        const int gy = y0 + oy, gx = x0 + ox;
+    for (int m = 0; m < 3; ++m) {
+        float col[kRowsPerThread + kTaps - 1];
+#pragma unroll
+        for (int t = 0; t < kRowsPerThread + kTaps - 1; ++t) col[t] = hz[m][oy0 + t][ox];
+#pragma unroll
+        for (int o = 0; o < kRowsPerThread; ++o) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < kTaps; ++t) acc += gw.w[t] * col[o + t];
+            v[m][o] = acc;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < kRowsPerThread; ++o) {
+        const int gy = y0 + oy0 + o;
         if (gy >= a.height || gx >= a.width) continue;
-        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-#pragma unroll
-        for (int t = 0; t < kTaps; ++t) { const float w = gw.w[t]; f0 += w * hz[0][oy + t][ox]; f1 += w * hz[1][oy + t][ox]; f2 += w * hz[2][oy + t][ox]; }
         const size_t e = c * plane + (size_t)gy * a.width + gx;
         const float p = a.image[e], q = a.target[e];
         const float diff = p - q;
         const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
-        a.grad[e] = ks * (f0 + 2.0f * p * f1 + q * f2) + kl * sgn;
+        a.grad[e] = ks * (v[0][o] + 2.0f * p * v[1][o] + q * v[2][o]) + kl * sgn;
     }
 }
 
