@@ -5,6 +5,8 @@ import sys
 import types
 from pathlib import Path
 
+import os
+
 import numpy as np
 import torch
 
@@ -98,22 +100,43 @@ def tiles_to_image(tile_major: np.ndarray, width: int, height: int, fill=0):
     return full[:height, :width]
 
 
+def _log_tolerance(kind: str, value: float, a: np.ndarray, ref: np.ndarray, **extra) -> None:
+    """FGS_TOL_LOG=<file>: one line per metric evaluation (call site, achieved value, and what the SAME data gives under the
+    1e-4-of-max-abs bar) -- how much slack every tolerance in the suite really has. Off by default; changes no result."""
+    path = os.environ.get('FGS_TOL_LOG')
+    if not path or not ref.size:
+        return
+    import inspect
+    fr = inspect.stack()[2]
+    site = next((f for f in inspect.stack()[2:] if os.path.basename(f.filename).startswith('test_')), fr)
+    err, scale = np.abs(a - ref), np.abs(ref).max() + 1e-30
+    with open(path, 'a') as fh:
+        fh.write(f'{os.path.basename(site.filename)}:{site.lineno} {site.function} {kind}={value:.3e} rel_inf={err.max() / scale:.3e} '
+                 f'frac_above_1e-4_of_max={float((err > 1e-4 * scale).mean()):.3e} n={ref.size} {extra}\n')
+
+
 def rel_inf(a: np.ndarray, ref: np.ndarray) -> float:
     """max |a-ref| normalised by max |ref| -- the tolerance metric of the float parity tests."""
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
-    return float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)) if ref.size else 0.0
+    value = float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)) if ref.size else 0.0
+    _log_tolerance('rel_inf', value, a, ref)
+    return value
 
 
 def outlier_fraction(a: np.ndarray, ref: np.ndarray, rtol: float, atol: float) -> float:
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     bad = np.abs(a - ref) > (atol + rtol * np.abs(ref))
-    return float(bad.mean()) if ref.size else 0.0
+    value = float(bad.mean()) if ref.size else 0.0
+    _log_tolerance('outlier_fraction', value, a, ref, rtol=rtol, atol=atol)
+    return value
 
 
 def check_forward_against_oracle(dec: dict, f: dict, exact_floats: bool, width: int, height: int, image: np.ndarray,
-                                 int_mismatch_budget: int = 0):
+                                 int_mismatch_budget: int = 0, pixel_mask: np.ndarray | None = None):
     """Integer intermediates bit-exact (up to `int_mismatch_budget` primitives whose libm-ULP-sensitive bounds differ);
-    float intermediates within 1e-5 relative (exact when both sides use the same libm, i.e. the simulation)."""
+    float intermediates within 1e-5 relative (exact when both sides use the same libm, i.e. the simulation).
+    On hardware (`exact_floats` False) the per-pixel outputs are held to 1e-4 outside `pixel_mask` -- flip_masks()['pixel'], the pixels
+    that own a (pixel, Gaussian) pair within an ULP-scale margin of the alpha / transmittance thresholds -- whose size is bounded (1e-3)."""
     vis = f['n_touched'] > 0
     assert dec['V'] == f['V'] and dec['I'] == f['I'], (dec['V'], f['V'], dec['I'], f['I'])
     nt_bad = int((dec['n_touched'] != f['n_touched']).sum())
@@ -140,13 +163,20 @@ def check_forward_against_oracle(dec: dict, f: dict, exact_floats: bool, width: 
             assert np.array_equal(npr.reshape(-1), f['n_processed']) and np.array_equal(dec['max_n_processed'], f['max_n_processed'])
             assert np.array_equal(fT.reshape(-1), f['final_T'])
         else:
-            assert (npr.reshape(-1) != f['n_processed']).mean() < 1e-3
-            assert outlier_fraction(fT.reshape(-1), f['final_T'], 1e-4, 1e-6) < 1e-3
+            assert pixel_mask is not None, 'hardware comparison needs the threshold-risk mask of the oracle (flip_masks)'
+            keep = ~pixel_mask.reshape(-1)
+            assert float(pixel_mask.mean()) < 1e-3, ('masked pixels', float(pixel_mask.mean()))
+            assert np.array_equal(npr.reshape(-1)[keep], f['n_processed'][keep]), int((npr.reshape(-1)[keep] != f['n_processed'][keep]).sum())
+            assert np.abs(fT.reshape(-1)[keep] - f['final_T'][keep]).max() < 1e-4, float(np.abs(fT.reshape(-1)[keep] - f['final_T'][keep]).max())
     if exact_floats:
         assert np.array_equal(image, f['image'])
     else:
-        assert outlier_fraction(image, f['image'], 1e-4, 1e-5) < 1e-3, outlier_fraction(image, f['image'], 1e-4, 1e-5)
-        assert np.abs(image - f['image']).max() < 5e-3
+        assert pixel_mask is not None, 'hardware comparison needs the threshold-risk mask of the oracle (flip_masks)'
+        err = np.abs(np.asarray(image, np.float64) - f['image']).max(axis=0)
+        scale = max(1.0, float(np.abs(f['image']).max()))
+        assert float(pixel_mask.mean()) < 1e-3, ('masked pixels', float(pixel_mask.mean()))
+        assert err[~pixel_mask].max() < 1e-4 * scale, ('image outside the mask', float(err[~pixel_mask].max()))
+        assert err.max() < 5e-3, ('image inside the mask', float(err.max()))
 
 
 def poisoned(be):
@@ -196,6 +226,23 @@ def masked_rel_inf(a, ref, keep):
     if not keep.any():
         return 0.0
     return float(np.abs(a[keep] - ref[keep]).max() / (np.abs(ref).max() + 1e-30))
+
+
+def seeded_moments(shape, seed: int):
+    """Non-zero Adam moments (exp_avg ~ 1e-3, exp_avg_sq ~ 1e-6) for tests that compare two paths through several optimizer steps: from
+    zero moments the first steps are lr * g / |g|, and an entry whose tiny gradient changes sign under another summation order moves by
+    2 lr -- the comparison would measure the optimizer's sensitivity, not the agreement of the gradients."""
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=gen) * 1e-3, torch.rand(shape, generator=gen) * 1e-6 + 1e-7
+
+
+def seed_trainer_moments(trainer, names, seed: int = 11) -> None:
+    """Writes seeded_moments() into a harness trainer's exp_avg / exp_avg_sq arenas (trainer.layout[name] = (offset, numel, shape))."""
+    for i, k in enumerate(names):
+        o, n, shape = trainer.layout[k]
+        m0, v0 = seeded_moments(shape, seed + i)
+        trainer.exp_avg[o:o + n].view(shape).copy_(m0)
+        trainer.exp_avg_sq[o:o + n].view(shape).copy_(v0)
 
 
 def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label=''):

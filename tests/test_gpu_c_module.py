@@ -52,7 +52,7 @@ def test_reference_call_pattern_through_c_module(hip_backend, oracle):
     f = oracle.forward(*helpers.np_params(params), S)
     dens_o = np.zeros((2, 1000), np.float32)
     g = oracle.backward(f, S, gi.numpy(), dens_o)
-    assert helpers.outlier_fraction(image.detach().cpu().numpy(), f['image'], 1e-4, 1e-5) < 1e-3
+    assert helpers.rel_inf(image.detach().cpu().numpy(), f['image']) < 1e-4
     for p, k in zip(P, helpers.GRAD_KEYS):
         assert helpers.rel_inf(p.grad.cpu().numpy().reshape(g[k].shape), g[k]) < 1e-4, k
     assert helpers.rel_inf(dens.cpu().numpy(), dens_o) < 1e-4
@@ -81,12 +81,12 @@ def test_c_module_inference_and_pruning_scores(hip_backend, oracle):
     dp = [params[k].to(DEV).contiguous() for k in helpers.NAMES]
     img = _C.inference(*dp, *RS.as_tuple(), False, True)                      # rasterization.py:135-156
     f = oracle.forward(*helpers.np_params(params), S, inference=True, to_chw=False, clamp_output=True)
-    assert img.shape == f['image'].shape and helpers.outlier_fraction(img.cpu().numpy(), f['image'], 1e-4, 1e-5) < 1e-3
+    assert img.shape == f['image'].shape and helpers.rel_inf(img.cpu().numpy(), f['image']) < 1e-4
     scores = torch.zeros(1000, device=DEV)
     assert _C.pruning_scores(scores, *dp, *RS.as_tuple()) is None              # rasterization.py:159-178
     ref = np.zeros(1000, np.float32)
     oracle.pruning_scores(ref, *helpers.np_params(params), S)
-    assert helpers.rel_inf(scores.cpu().numpy(), ref) < 1e-3
+    assert helpers.rel_inf(scores.cpu().numpy(), ref) < 1e-4
 
 
 def test_c_module_aux_entry_points(hip_backend, oracle):

@@ -28,8 +28,9 @@ def test_training_iteration_captures_into_a_graph(hip_backend):
     params, view = make_s0(n=5000)
     _, RS = helpers.settings_pair(view, device=DEV)
     target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(1)).to(DEV)
-    fresh = lambda: ({k: params[k].to(DEV).clone() for k in ORDER}, {k: torch.zeros_like(params[k], device=DEV) for k in ORDER},
-                     {k: torch.zeros_like(params[k], device=DEV) for k in ORDER})
+    seeds = {k: helpers.seeded_moments(params[k].shape, 11 + i) for i, k in enumerate(ORDER)}   # non-zero moments: see helpers.seeded_moments
+    fresh = lambda: ({k: params[k].to(DEV).clone() for k in ORDER}, {k: seeds[k][0].to(DEV) for k in ORDER},
+                     {k: seeds[k][1].to(DEV) for k in ORDER})
     sync = hip_backend.forward(*[params[k].to(DEV) for k in helpers.NAMES], RS)
     capacity = int(1.25 * sync.state[1]) + 4096
 
@@ -62,5 +63,5 @@ def test_training_iteration_captures_into_a_graph(hip_backend):
     assert int(host[2]) == 0 and int(host[1]) > 0
     for k in ORDER:
         moved = (ref[k] - start[k]).abs().max().item()
-        assert moved > 0 and (P[k] - ref[k]).abs().max().item() <= 2e-3 * moved + 1e-9, k      # float atomics in a different order
+        assert moved > 0 and helpers.rel_inf((P[k] - start[k]).cpu().numpy(), (ref[k] - start[k]).cpu().numpy()) < 1e-4, k   # float atomics in a different order
     assert torch.isfinite(res.image).all()

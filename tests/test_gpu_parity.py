@@ -7,8 +7,11 @@ Two facts bound what "bit-exact" can mean on real hardware ('fast-m
    whose floor/ceil/threshold input lies within an ULP of an integer. Tests therefore allow at most max(1, 0.1%) of the
    primitives to differ in integer intermediates and compare the downstream integer arrays exactly when none does.
  * the blend kernels use the hardware exp (v_exp_f32) and FMA contraction; an alpha within ~1e-6 relative of the 1/255
-   threshold can be kept on one side and dropped on the other, changing that pixel by up to ~4e-3. Image tests bound the
-   fraction of such pixels (1e-3) and their magnitude (5e-3) and require 1e-4 everywhere else.
+   threshold can be kept on one side and dropped on the other, changing that pixel by up to ~4e-3. The oracle NAMES the pixels
+   (and Gaussians) that own such a pair (oracle.threshold_risk -> helpers.flip_masks); per-pixel outputs (image, final_T,
+   n_processed) and gradients are held to 1e-4 / exact OUTSIDE that mask, the mask is bounded to 1e-3 of all entries and masked
+   pixels to 5e-3. No test compares against a count of unexplained outliers; achieved errors per assert site on an MI355X are in
+   profiles/r02_gpu_tolerance_slack.txt (FGS_TOL_LOG=<file> regenerates it).
 """
 from pathlib import Path
 
@@ -56,12 +59,16 @@ def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None):
     vis = f['n_touched'] > 0
     bad = int((dec['n_touched'] != f['n_touched']).sum()) + int((dec['screen_bounds'][vis] != f['screen_bounds'][vis]).any(axis=1).sum())
     budget = 0 if bad == 0 else max(1, n // 1000)
+    pixel_mask = helpers.flip_masks(oracle, f, S, dec)['pixel']      # pixels within an ULP-scale margin of the alpha / T thresholds
     if bad == 0:
-        helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy())
-    else:   # an ULP-level flip in a bound: V/I may differ by a few, downstream arrays are compared statistically
-        assert bad <= budget, bad
+        helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy(), pixel_mask=pixel_mask)
+    else:   # an ULP-level flip in a bound: V/I may differ by a few; the image is still held to 1e-4 outside the risk mask, which
+        assert bad <= budget, bad                                    # then also has to cover the pixels of the differing Gaussians
         assert abs(dec['I'] - f['I']) <= 8 * budget
-        assert helpers.outlier_fraction(res.image.cpu().numpy(), f['image'], 1e-4, 1e-5) < 2e-3
+        img = res.image.cpu().numpy()
+        err = np.abs(img.astype(np.float64) - f['image']).max(axis=0)
+        outside = err[~pixel_mask] > 1e-4 * max(1.0, float(np.abs(f['image']).max()))
+        assert float(pixel_mask.mean()) < 1e-3 and float(outside.mean()) < 1e-5 * bad + 1e-6, (float(pixel_mask.mean()), float(outside.mean()), bad)
     return res, f, dp, RS, S
 
 
@@ -85,7 +92,7 @@ def test_s0_against_committed_golden(hip_backend):
     assert np.array_equal(dec['n_touched'], g['n_touched']) and np.array_equal(dec['inst_keys'], g['inst_keys'])
     assert np.array_equal(dec['inst_prims'], g['inst_prims']) and np.array_equal(dec['ranges'], g['ranges'])
     assert np.array_equal(dec['bucket_offsets'], g['b64_bucket_offsets'])
-    assert helpers.outlier_fraction(res.image.cpu().numpy(), g['image'], 1e-4, 1e-5) < 1e-3
+    assert helpers.rel_inf(res.image.cpu().numpy(), g['image']) < 1e-4
     dens = torch.zeros(2, 1000, device=DEV)
     grads = hip_backend.backward(dens, torch.from_numpy(g['grad_image']).to(DEV), res.image, dp['means'], dp['scales'], dp['rotations'],
                                  dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
@@ -273,7 +280,7 @@ def test_inference_variants(hip_backend, oracle, to_chw, clamp):
     img = rasterize(*[dp[k] for k in helpers.NAMES], RS, to_chw, clamp)
     f = oracle.forward(*helpers.np_params(params), S, inference=True, to_chw=to_chw, clamp_output=clamp)
     assert img.shape == f['image'].shape
-    assert helpers.outlier_fraction(img.cpu().numpy(), f['image'], 1e-4, 1e-5) < 1e-3
+    assert helpers.rel_inf(img.cpu().numpy(), f['image']) < 1e-4
 
 
 def test_fused_backward_adam_matches_unfused(hip_backend):
@@ -303,7 +310,7 @@ def test_fused_backward_adam_matches_unfused(hip_backend):
     for k in order:
         delta_ref, delta_fus = (ref_p[k] - start[k]).cpu().numpy(), (fus_p[k] - start[k]).cpu().numpy()
         assert np.abs(delta_ref).max() > 0
-        assert helpers.rel_inf(delta_fus, delta_ref) < 1e-3, k
+        assert helpers.rel_inf(delta_fus, delta_ref) < 1e-4, k          # measured 1.2e-5 (float atomics in another order)
         assert helpers.rel_inf(fus_m[k].cpu().numpy(), ref_m[k].cpu().numpy()) < 1e-4, k
     assert helpers.rel_inf(dens_fus.cpu().numpy(), dens_ref.cpu().numpy()) < 1e-4
 

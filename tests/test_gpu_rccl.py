@@ -40,6 +40,7 @@ def _reference_steps(be, params, RS, target, steps):
     dist.is_initialized = lambda: False           # world-1 trainer without any collective
     try:
         tr = ViewParallelTrainer(be, params, LRS)
+        helpers.seed_trainer_moments(tr, SEGMENTS)           # both sides start from the same non-zero moments (helpers.seeded_moments)
         for _ in range(steps):
             tr.step(RS, target)
     finally:
@@ -58,11 +59,13 @@ def test_trainers_over_rccl_world1_equal_single_gpu_step(hip_backend, rccl_world
     ref, ref_info = _reference_steps(hip_backend, dp, RS, target, 2)
     if mode.startswith('sharded'):
         tr = ShardedTrainer(hip_backend, dp, LRS, fused=(mode == 'sharded'))
+        helpers.seed_trainer_moments(tr, SEGMENTS)
         for _ in range(2):
             tr.step([RS], target)
         got = tr.gather_parameters()
     else:
         tr = ViewParallelTrainer(hip_backend, dp, LRS, mode=mode)
+        helpers.seed_trainer_moments(tr, SEGMENTS)
         for _ in range(2):
             tr.step(RS, target)
         got = {k: tr.params[k] for k in SEGMENTS}
@@ -72,6 +75,6 @@ def test_trainers_over_rccl_world1_equal_single_gpu_step(hip_backend, rccl_world
     for k in SEGMENTS:
         moved = (ref[k] - dp[k]).abs().max().item()
         assert moved > 0
-        # float atomics in a different order + Adam: compare the step taken, relative to the largest step of the tensor
-        assert (got[k] - ref[k]).abs().max().item() < 2e-3 * moved + 1e-9, (mode, k)
+        # float atomics in a different order: compare the step taken, relative to the largest step of the tensor
+        assert helpers.rel_inf((got[k] - dp[k]).cpu().numpy(), (ref[k] - dp[k]).cpu().numpy()) < 1e-4, (mode, k)
     assert helpers.rel_inf(tr.densification_info.cpu().numpy(), ref_info.cpu().numpy()) < 1e-4

@@ -36,15 +36,12 @@ def _cut_vs_whole(be, params, RS, n_shards, grad_scale, strict=True):
     if strict:
         assert (res.image - whole.image).abs().max().item() <= 1e-6
     else:       # at 1 M Gaussians a few thousand pairs share a 32-bit depth key; the rare overlapping pair blends in the other order
-        assert helpers.outlier_fraction(res.image.cpu().numpy(), whole.image.cpu().numpy(), 1e-5, 1e-6) < 1e-4
+        assert helpers.rel_inf(res.image.cpu().numpy(), whole.image.cpu().numpy()) < 1e-4        # measured 2.9e-5
     for s in range(n_shards):
         for g, r, k in zip(grads[s], ref, ORDER):
             assert torch.isfinite(g).all(), k
             a, b = g.cpu().numpy(), r[s::n_shards].cpu().numpy()
-            if strict:
-                assert helpers.rel_inf(a, b) < 1e-4, (k, s, helpers.rel_inf(a, b))
-            else:
-                assert helpers.outlier_fraction(a, b, 1e-3, 1e-4 * np.abs(b).max()) < 1e-4, (k, s)
+            assert helpers.rel_inf(a, b) < 1e-4, (k, s, helpers.rel_inf(a, b))       # full size (1 M, 1080p, 8 shards): measured 3.7e-6
         assert helpers.rel_inf(dens[s].cpu().numpy(), info_ref[:, s::n_shards].cpu().numpy()) < 1e-4
     return table[:, 0]
 
@@ -122,6 +119,18 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
     grp = LocalShardGroup(hip_backend, params, LRS, 4, fused=fused)
     tr = ViewParallelTrainer(hip_backend, params, LRS)
     start = {k: params[k].clone() for k in SEGMENTS}
+    # Both sides start from the same NON-ZERO Adam moments: from zero moments the first steps are lr * g / |g|, and an entry whose tiny
+    # gradient changes sign under another summation order moves by 2 lr -- that would measure the optimizer's sensitivity, not the
+    # agreement of the two gradient paths (the oracle tests of the fused path seed their moments for the same reason).
+    for i, k in enumerate(SEGMENTS):
+        m0, v0 = (t.to(DEV) for t in helpers.seeded_moments(params[k].shape, 11 + i))
+        o, n, shape = tr.layout[k]
+        tr.exp_avg[o:o + n].view(shape).copy_(m0)
+        tr.exp_avg_sq[o:o + n].view(shape).copy_(v0)
+        for s, t in enumerate(grp.ranks):
+            o, n, shape = t.layout[k]
+            t.exp_avg[o:o + n].view(shape).copy_(m0[s::4])
+            t.exp_avg_sq[o:o + n].view(shape).copy_(v0[s::4])
     for _ in range(3):
         grp.step(RS, targets)
         tr.step_count += 1
@@ -135,9 +144,7 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
     for k in SEGMENTS:
         d_ref, d_got = (tr.params[k] - start[k]).cpu().numpy(), (got[k] - start[k]).cpu().numpy()
         assert np.abs(d_ref).max() > 0
-        # Adam's first steps are sign-like (lr * g / |g|): an entry whose tiny gradient changes sign under a different atomic
-        # order moves by 2 lr. Bound the fraction of such entries and require 1e-3 everywhere else.
-        assert helpers.outlier_fraction(d_got, d_ref, 1e-3, 1e-3 * np.abs(d_ref).max()) < 2e-3, k
+        assert helpers.rel_inf(d_got, d_ref) < 1e-4, (k, helpers.rel_inf(d_got, d_ref))
     info = torch.cat([t.densification_info for t in grp.ranks], dim=1)
     full_info = torch.empty_like(tr.densification_info)
     for s, t in enumerate(grp.ranks):
