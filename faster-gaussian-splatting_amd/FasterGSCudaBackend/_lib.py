@@ -87,6 +87,7 @@ _SIGNATURES = {
     'fgs_debug_wave_selftest': (C.c_int32, [_P, _P]),
     'fgs_debug_radix_sort_temp_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_debug_radix_sort': (C.c_int32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_size_t, _P]),
+    'fgs_debug_depth_sort': (C.c_int32, [_P, _P, _P, _P, _I32, C.c_float, C.c_float, _P, C.c_size_t, _P]),
     'fgs_debug_set_backward_variant': (C.c_int32, [_I32]),
     'fgs_debug_set_option': (C.c_int32, [_I32, _I32]),
 }

@@ -291,7 +291,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
         int depth_sel = 0;
         if (n > 0) {
             StageScope t(ST_DEPTH_SORT, stream);
-            FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, stream));
+            FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), stream));
         }
         return forward_tail(mode, pb, tb, geo, n, static_cast<uint32_t>(instance_capacity), depth_sel, settings, image, to_chw, clamp_output, resize, user,
                             state_out, stream, scores, true);
@@ -308,7 +308,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     int depth_sel = -1;
     if (n > 0 && depth_sort_takes_device_count()) {
         StageScope t(ST_DEPTH_SORT, stream);
-        FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, stream));
+        FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), stream));
     }
     FGS_HIP(hipEventSynchronize(ready));
     const uint32_t n_visible = host[0], n_instances = host[1];
@@ -328,7 +328,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     const uint32_t* const visible_ptr = device_counts ? pb.counters : nullptr;
     const uint32_t* const instances_ptr = device_counts ? pb.counters + 5 : nullptr;
     // K2-K4 (fwd:104-127)
-    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, stream)); }
+    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, depth_key_range(settings->near_plane, settings->far_plane), stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
     { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, visible_ptr, stream)); }
 
@@ -996,6 +996,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 7: fgs::g_backward_ablate = value & 15; return FGS_OK;
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
+        case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
@@ -1021,6 +1022,18 @@ int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t
         FGS_HIP(own_sort_pairs_u32(temp, temp_bytes, k, vals, selector, static_cast<uint32_t>(n), end_bit, static_cast<hipStream_t>(stream)));
     }
     return selector;                     // 0 / 1: which buffer pair holds the sorted result
+}
+
+int32_t fgs_debug_depth_sort(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, float near_plane, float far_plane,
+                             void* temp, size_t temp_bytes, void* stream) {
+    if (n < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad sort arguments");
+    if (n > 0 && (!keys0 || !keys1 || !vals0 || !vals1 || !temp)) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL buffer");
+    int selector = 0;
+    uint32_t* k[2] = {keys0, keys1};
+    uint32_t* vals[2] = {vals0, vals1};
+    FGS_HIP(own_depth_sort(temp, temp_bytes, k, vals, selector, static_cast<uint32_t>(n), nullptr, depth_key_range(near_plane, far_plane),
+                           static_cast<hipStream_t>(stream)));
+    return selector;
 }
 
 int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream) {

@@ -36,10 +36,10 @@ size_t depth_sort_temp_bytes(uint32_t n) {
 }
 
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                          uint32_t n_visible, hipStream_t s) {
+                          uint32_t n_visible, DepthKeyRange range, hipStream_t s) {
     selector = 0;
     if (n_visible == 0) return hipSuccess;
-    if (g_sort_implementation & 2) return own_sort_pairs_u32(temp, temp_bytes, keys, vals, selector, n_visible, 32, s);
+    if (g_sort_implementation & 2) return own_depth_sort(temp, temp_bytes, keys, vals, selector, n_visible, nullptr, range, s);
     rocprim::double_buffer<uint32_t> k(keys[0], keys[1]), v(vals[0], vals[1]);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n_visible, 0u, 32u, s);
     if (e != hipSuccess) return e;
@@ -49,8 +49,8 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
 
 bool depth_sort_takes_device_count() { return (g_sort_implementation & 2) != 0; }
 hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                                       uint32_t capacity, const uint32_t* n_visible_ptr, hipStream_t s) {
-    return own_sort_pairs_u32_device_count(temp, temp_bytes, keys, vals, selector, capacity, n_visible_ptr, 32, s);
+                                       uint32_t capacity, const uint32_t* n_visible_ptr, DepthKeyRange range, hipStream_t s) {
+    return own_depth_sort(temp, temp_bytes, keys, vals, selector, capacity, n_visible_ptr, range, s);
 }
 
 // the same input when the host does not know the visible count: entries at and beyond *count contribute nothing

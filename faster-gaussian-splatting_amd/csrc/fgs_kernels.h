@@ -32,13 +32,16 @@ struct PreprocessBatch { int n_views; PreprocessArgs v[kMaxBatchViews]; };
 hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s);
 
 // K2-K4: depth sort of the visible list + exclusive scan of per-primitive tile counts in depth order
+// depth keys lie in [bits(near), bits(far)] (kf:67): the depth sort orders key - base in `bits` bits (radix_sort.hip)
+struct DepthKeyRange { uint32_t base; int bits; };
+DepthKeyRange depth_key_range(float near_plane, float far_plane);
 size_t depth_sort_temp_bytes(uint32_t n);
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                          uint32_t n_visible, hipStream_t s);
+                          uint32_t n_visible, DepthKeyRange range, hipStream_t s);
 // the same with the count still on the device (n_visible_ptr), `capacity` >= *n_visible_ptr; false if this build path needs the host count
 bool depth_sort_takes_device_count();
 hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                                       uint32_t capacity, const uint32_t* n_visible_ptr, hipStream_t s);
+                                       uint32_t capacity, const uint32_t* n_visible_ptr, DepthKeyRange range, hipStream_t s);
 // n_visible_ptr != nullptr: n_visible is a bound (the primitive count) and the exact count is read on the device
 hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
                             uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s);
@@ -59,8 +62,11 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
 // The A/B switches behind fgs_debug_set_option are process-wide; atomics make concurrent set / launch well defined (a launch sees the
 // old or the new value, never a torn one).
+extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
 extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
+hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
+                          DepthKeyRange range, hipStream_t s);
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 // the item count lives on the device (*n_ptr <= capacity): lets the depth sort start before the host has read the counters back

@@ -17,6 +17,8 @@
 // take the digit's running count from the wave's private LDS counters plus their position among the matching lanes, and the
 // lowest matching lane advances the counter. Counts of the four waves are prefix-summed per digit afterwards, the items are
 // reordered through LDS by digit, and leave so that consecutive lanes store to consecutive addresses of a digit's run.
+#include <cstring>
+
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 
@@ -24,13 +26,22 @@ namespace fgs {
 
 namespace sortimpl {
 
-constexpr int kSortThreads = 256, kSortItemsPerThread = 16, kSortWaves = kSortThreads / kWave;
-constexpr int kSortBlockItems = kSortThreads * kSortItemsPerThread;                    // 4096
-constexpr int kSortWaveItems = kSortBlockItems / kSortWaves;                           // 1024 = 16 rounds of 64
-constexpr int kMaxBits = 8, kMaxBins = 1 << kMaxBits;                                  // one thread per digit in the block-wide scans
+constexpr int kSortThreads = 256, kSortWaves = kSortThreads / kWave;
+constexpr int kMaxBits = 9, kMaxBins = 1 << kMaxBits;                                  // up to two digits per thread in the block-wide scans
+constexpr int kScanPerThread = 16;                                                     // row scan: table entries per thread and round
+// Items per thread (IPT) is a template parameter: 16 (4096-item workgroups) for both sorts. The 16 M-item tile sort is throughput-bound
+// (8 / 16 / 24 measured 0.193 / 0.181 / 0.188 ms). The 2 M-item depth sort runs < 2 workgroups per CU and looked latency-bound by a
+// workgroup's chain (load -> IPT ranking rounds -> reorder -> store), but halving the chain (IPT 8) measured 10 % SLOWER (0.119 vs 0.108 ms):
+// twice the workgroups pay their fixed costs twice and the table doubles. The instantiation stays as an A/B switch (g_depth_sort_mode bit 1).
+template <int IPT> struct SortShape {
+    static constexpr int kBlockItems = kSortThreads * IPT;
+    static constexpr int kWaveItems = kBlockItems / kSortWaves;                        // IPT rounds of 64 consecutive items
+};
 
+// `base` is subtracted first (0 for tile keys): depth keys are bit patterns of depths in [near, far], and key - bits(near) keeps their
+// order in fewer bits (DepthKeyRange)
 template <typename KeyT>
-__device__ __forceinline__ uint32_t digit_of(KeyT key, int shift, uint32_t mask) { return (static_cast<uint32_t>(key) >> shift) & mask; }
+__device__ __forceinline__ uint32_t digit_of(KeyT key, uint32_t base, int shift, uint32_t mask) { return ((static_cast<uint32_t>(key) - base) >> shift) & mask; }
 
 // exclusive prefix of one value per thread over the 256-thread workgroup; `total` = sum of all
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_part /*[kSortWaves]*/, uint32_t& total) {
@@ -49,53 +60,56 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 // per-workgroup digit histogram, written digit-major: hist[digit * n_blocks + block]
 // The item count comes by value or -- when the host does not know it yet -- through `n_ptr` (grid sized by a capacity, workgroups
 // beyond the count contribute zero rows and scatter nothing).
-template <typename KeyT>
+template <typename KeyT, int IPT>
 __global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const KeyT* __restrict__ keys, const uint32_t n_value, const uint32_t* __restrict__ n_ptr,
-                                                                       const int shift, const int bits, uint32_t* __restrict__ hist, const uint32_t n_blocks) {
+                                                                       const uint32_t key_base, const int shift, const int bits, uint32_t* __restrict__ hist,
+                                                                       const uint32_t n_blocks) {
+    constexpr int kBlockItems = SortShape<IPT>::kBlockItems;
     __shared__ uint32_t s_hist[kMaxBins];
     const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
-    if (threadIdx.x < bins) s_hist[threadIdx.x] = 0u;
+    for (uint32_t d = threadIdx.x; d < bins; d += kSortThreads) s_hist[d] = 0u;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kSortBlockItems;
+    const uint32_t base = blockIdx.x * kBlockItems;
     constexpr int kPerLoad = 16 / sizeof(KeyT);                                        // keys per 16-byte load
-    if (base + kSortBlockItems <= n) {                                                 // full workgroup: 16-byte loads (order is irrelevant here)
+    static_assert(IPT % kPerLoad == 0, "whole 16-byte loads per thread");
+    if (base + kBlockItems <= n) {                                                     // full workgroup: 16-byte loads (order is irrelevant here)
 #pragma unroll
-        for (int i = 0; i < kSortItemsPerThread / kPerLoad; ++i) {
+        for (int i = 0; i < IPT / kPerLoad; ++i) {
             const uint4 q = reinterpret_cast<const uint4*>(keys + base)[i * kSortThreads + threadIdx.x];
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (sizeof(KeyT) == 4) atomicAdd(&s_hist[(w[j] >> shift) & mask], 1u);
-                else { atomicAdd(&s_hist[((w[j] & 0xffffu) >> shift) & mask], 1u); atomicAdd(&s_hist[((w[j] >> 16) >> shift) & mask], 1u); }
+                if (sizeof(KeyT) == 4) atomicAdd(&s_hist[((w[j] - key_base) >> shift) & mask], 1u);
+                else { atomicAdd(&s_hist[(((w[j] & 0xffffu) - key_base) >> shift) & mask], 1u); atomicAdd(&s_hist[(((w[j] >> 16) - key_base) >> shift) & mask], 1u); }
             }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kSortItemsPerThread; ++i) {
+        for (int i = 0; i < IPT; ++i) {
             const uint32_t idx = base + i * kSortThreads + threadIdx.x;
-            if (idx < n) atomicAdd(&s_hist[digit_of(keys[idx], shift, mask)], 1u);
+            if (idx < n) atomicAdd(&s_hist[digit_of(keys[idx], key_base, shift, mask)], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < bins) hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_hist[threadIdx.x];
+    for (uint32_t d = threadIdx.x; d < bins; d += kSortThreads) hist[(size_t)d * n_blocks + blockIdx.x] = s_hist[d];
 }
 
 // One workgroup per digit: exclusive scan of that digit's row of the table (over the workgroups of the sort), in place, and the
-// row total. The scatter kernel adds the exclusive scan of the <= 256 totals itself.
+// row total. The scatter kernel adds the exclusive scan of the digit totals itself.
 __global__ void __launch_bounds__(kSortThreads) radix_row_scan_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ totals, const uint32_t n_blocks) {
     __shared__ uint32_t s_part[kSortWaves];
     uint32_t* row = table + (size_t)blockIdx.x * n_blocks;
     uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < n_blocks; c0 += kSortBlockItems) {                      // workgroup-uniform trip count
-        uint32_t v[kSortItemsPerThread], sum = 0;
-        const uint32_t first = c0 + threadIdx.x * kSortItemsPerThread;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += kSortThreads * kScanPerThread) {        // workgroup-uniform trip count
+        uint32_t v[kScanPerThread], sum = 0;
+        const uint32_t first = c0 + threadIdx.x * kScanPerThread;
 #pragma unroll
-        for (int i = 0; i < kSortItemsPerThread; ++i) { v[i] = first + i < n_blocks ? row[first + i] : 0u; sum += v[i]; }
+        for (int i = 0; i < kScanPerThread; ++i) { v[i] = first + i < n_blocks ? row[first + i] : 0u; sum += v[i]; }
         uint32_t chunk_total;
         uint32_t run = carry + block_exclusive_scan(sum, s_part, chunk_total);
 #pragma unroll
-        for (int i = 0; i < kSortItemsPerThread; ++i) { if (first + i < n_blocks) row[first + i] = run; run += v[i]; }
+        for (int i = 0; i < kScanPerThread; ++i) { if (first + i < n_blocks) row[first + i] = run; run += v[i]; }
         carry += chunk_total;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
@@ -104,47 +118,55 @@ __global__ void __launch_bounds__(kSortThreads) radix_row_scan_kernel(uint32_t* 
 // table[d * n_blocks + blk] (after the row scan) + exclusive scan of totals[] over d = where this workgroup's first item with
 // digit d goes.
 // BITS (the digit width) is a template parameter so that the match loop is straight-line code: as a run-time loop it cost
-// 8 VALU + 4 SALU + a branch per bit and round.
-template <typename KeyT, int BITS>
+// 8 VALU + 4 SALU + a branch per bit and round. A thread owns DPT = max(1, 2^BITS / 256) ADJACENT digits in the per-digit steps.
+template <typename KeyT, int BITS, int IPT>
 __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                     const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const int shift,
-                                                                     const uint32_t* __restrict__ table,
+                                                                     const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const uint32_t key_base,
+                                                                     const int shift, const uint32_t* __restrict__ table,
                                                                      const uint32_t* __restrict__ totals, const uint32_t n_blocks) {
-    constexpr int bits = BITS;
+    constexpr int kBlockItems = SortShape<IPT>::kBlockItems, kWaveItems = SortShape<IPT>::kWaveItems;
+    constexpr uint32_t kBins = 1u << BITS, mask = kBins - 1u;
+    constexpr int DPT = kBins > static_cast<uint32_t>(kSortThreads) ? static_cast<int>(kBins) / kSortThreads : 1;
     const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
-    if (blockIdx.x * kSortBlockItems >= n) return;                  // workgroup-uniform (capacity-sized grid)
-    __shared__ uint32_t s_cnt[kSortWaves][kMaxBins];              // per wave and digit: running count, later start inside the digit's run
-    __shared__ uint32_t s_first[kMaxBins];                        // first workgroup-local position of each digit
-    __shared__ uint32_t s_dst[kMaxBins];                          // global position of this workgroup's first item of each digit
+    if (blockIdx.x * kBlockItems >= n) return;                      // workgroup-uniform (capacity-sized grid)
+    __shared__ uint32_t s_cnt[kSortWaves][kBins];                 // per wave and digit: running count, later start inside the digit's run
+    __shared__ uint32_t s_first[kBins];                           // first workgroup-local position of each digit
+    __shared__ uint32_t s_dst[kBins];                             // global position of this workgroup's first item of each digit
     __shared__ uint32_t s_part[kSortWaves];
-    __shared__ KeyT s_key[kSortBlockItems];
-    __shared__ uint32_t s_val[kSortBlockItems];
-    const uint32_t bins = 1u << bits, mask = bins - 1u;
+    __shared__ KeyT s_key[kBlockItems];
+    __shared__ uint32_t s_val[kBlockItems];
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-    if (threadIdx.x < bins) {
-#pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) s_cnt[w][threadIdx.x] = 0u;
-    }
+    const uint32_t d0 = threadIdx.x * DPT;                          // this thread's first digit
     // global base of every digit: exclusive scan of the digit totals (requested now, used after the ranking)
-    const uint32_t digit_total = threadIdx.x < bins ? totals[threadIdx.x] : 0u;
-    const uint32_t row_offset = threadIdx.x < bins ? table[(size_t)threadIdx.x * n_blocks + blockIdx.x] : 0u;
+    uint32_t digit_total[DPT], row_offset[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const uint32_t d = d0 + j;
+        const bool own = d < kBins;
+        if (own) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) s_cnt[w][d] = 0u;
+        }
+        digit_total[j] = own ? totals[d] : 0u;
+        row_offset[j] = own ? table[(size_t)d * n_blocks + blockIdx.x] : 0u;
+    }
     __syncthreads();
 
-    const uint32_t seg = blockIdx.x * kSortBlockItems + wv * kSortWaveItems;          // this wave's 1024 consecutive items
-    KeyT key[kSortItemsPerThread];
-    uint32_t val[kSortItemsPerThread], rank[kSortItemsPerThread];
+    const uint32_t seg = blockIdx.x * kBlockItems + wv * kWaveItems;                   // this wave's consecutive items
+    KeyT key[IPT];
+    uint32_t val[IPT], rank[IPT];
 #pragma unroll
-    for (int r = 0; r < kSortItemsPerThread; ++r) {
+    for (int r = 0; r < IPT; ++r) {
         const uint32_t idx = seg + r * kWave + lane;
         const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : static_cast<KeyT>(0);
+        key[r] = valid ? keys_in[idx] : static_cast<KeyT>(key_base);
         val[r] = valid ? vals_in[idx] : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < kSortItemsPerThread; ++r) {                                    // input order: round by round, lane by lane
+    for (int r = 0; r < IPT; ++r) {                                                    // input order: round by round, lane by lane
         const bool valid = seg + r * kWave + lane < n;
-        const uint32_t d = digit_of(key[r], shift, mask);
+        const uint32_t d = digit_of(key[r], key_base, shift, mask);
         uint64_t peers = wave_ballot(valid);                                           // lanes of this round holding the same digit
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -159,33 +181,46 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         wave_lds_fence();
     }
     __syncthreads();
-    // per digit (one thread each): counts of the four waves -> start of each wave's items inside the digit's run; the digit's
-    // count in this workgroup -> its first local position (exclusive scan over the digits); its global destination
-    uint32_t count = 0;
-    if (threadIdx.x < bins) {
+    // per digit: counts of the four waves -> start of each wave's items inside the digit's run; the digit's count in this workgroup ->
+    // its first local position (exclusive scan over the digits); its global destination
+    uint32_t count[DPT], count_sum = 0, total_sum = 0;
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) { const uint32_t c = s_cnt[w][threadIdx.x]; s_cnt[w][threadIdx.x] = count; count += c; }
+    for (int j = 0; j < DPT; ++j) {
+        const uint32_t d = d0 + j;
+        count[j] = 0;
+        if (d < kBins) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = count[j]; count[j] += c; }
+        }
+        count_sum += count[j];
+        total_sum += digit_total[j];
     }
     uint32_t unused;
-    const uint32_t first_local = block_exclusive_scan(count, s_part, unused);
-    const uint32_t digit_base = block_exclusive_scan(digit_total, s_part, unused);
-    if (threadIdx.x < bins) { s_first[threadIdx.x] = first_local; s_dst[threadIdx.x] = digit_base + row_offset; }
+    uint32_t first_local = block_exclusive_scan(count_sum, s_part, unused);
+    uint32_t digit_base = block_exclusive_scan(total_sum, s_part, unused);
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const uint32_t d = d0 + j;
+        if (d < kBins) { s_first[d] = first_local; s_dst[d] = digit_base + row_offset[j]; }
+        first_local += count[j];
+        digit_base += digit_total[j];
+    }
     __syncthreads();
     // items to their workgroup-local sorted position, then out in that order: consecutive lanes -> consecutive addresses per run
 #pragma unroll
-    for (int r = 0; r < kSortItemsPerThread; ++r) {
+    for (int r = 0; r < IPT; ++r) {
         if (seg + r * kWave + lane >= n) continue;
-        const uint32_t d = digit_of(key[r], shift, mask);
+        const uint32_t d = digit_of(key[r], key_base, shift, mask);
         const uint32_t pos = s_first[d] + s_cnt[wv][d] + rank[r];
         s_key[pos] = key[r];
         s_val[pos] = val[r];
     }
     __syncthreads();
-    const uint32_t block_first = blockIdx.x * kSortBlockItems;
-    const uint32_t n_here = n - block_first < static_cast<uint32_t>(kSortBlockItems) ? n - block_first : static_cast<uint32_t>(kSortBlockItems);
+    const uint32_t block_first = blockIdx.x * kBlockItems;
+    const uint32_t n_here = n - block_first < static_cast<uint32_t>(kBlockItems) ? n - block_first : static_cast<uint32_t>(kBlockItems);
     for (uint32_t pos = threadIdx.x; pos < n_here; pos += kSortThreads) {
         const KeyT k = s_key[pos];
-        const uint32_t d = digit_of(k, shift, mask);
+        const uint32_t d = digit_of(k, key_base, shift, mask);
         const uint32_t dst = s_dst[d] + (pos - s_first[d]);
         keys_out[dst] = k;
         vals_out[dst] = s_val[pos];
@@ -194,33 +229,35 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
 
 struct SortPlan { int n_passes; int bits[8]; uint32_t n_blocks; size_t table_bytes, totals_bytes; };
 
-SortPlan plan_sort(uint32_t n, int end_bit) {
+SortPlan plan_sort(uint32_t n, int end_bit, int max_bits, int items_per_thread) {
     SortPlan p{};
-    p.n_passes = (end_bit + kMaxBits - 1) / kMaxBits;
+    p.n_passes = (end_bit + max_bits - 1) / max_bits;
     if (p.n_passes < 1) p.n_passes = 1;
     int left = end_bit;
     for (int i = 0; i < p.n_passes; ++i) { p.bits[i] = (left + (p.n_passes - i) - 1) / (p.n_passes - i); left -= p.bits[i]; }   // even split
-    p.n_blocks = (n + kSortBlockItems - 1) / kSortBlockItems;
+    const uint32_t block_items = static_cast<uint32_t>(kSortThreads * items_per_thread);
+    p.n_blocks = (n + block_items - 1) / block_items;
     p.table_bytes = ((size_t)kMaxBins * p.n_blocks * sizeof(uint32_t) + 255) / 256 * 256;
-    p.totals_bytes = 1024;
+    p.totals_bytes = kMaxBins * sizeof(uint32_t);
     return p;
 }
 
-template <typename KeyT>
+template <typename KeyT, int IPT>
 void launch_scatter(int bits, dim3 grid, dim3 block, hipStream_t s, const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out,
-                    uint32_t n, const uint32_t* n_ptr, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks) {
-#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, shift, table, totals, n_blocks); break;
-    switch (bits) { FGS_SCATTER(1) FGS_SCATTER(2) FGS_SCATTER(3) FGS_SCATTER(4) FGS_SCATTER(5) FGS_SCATTER(6) FGS_SCATTER(7) default: FGS_SCATTER(8) }
+                    uint32_t n, const uint32_t* n_ptr, uint32_t key_base, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks) {
+#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B, IPT>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, key_base, shift, table, totals, n_blocks); break;
+    switch (bits) { FGS_SCATTER(1) FGS_SCATTER(2) FGS_SCATTER(3) FGS_SCATTER(4) FGS_SCATTER(5) FGS_SCATTER(6) FGS_SCATTER(7) FGS_SCATTER(8) default: FGS_SCATTER(9) }
 #undef FGS_SCATTER
 }
 
-// `n` = item count, or with n_ptr != nullptr an upper bound of the count stored at n_ptr on the device
-template <typename KeyT>
+// `n` = item count, or with n_ptr != nullptr an upper bound of the count stored at n_ptr on the device. Keys are sorted by
+// (key - key_base) & (2^end_bit - 1): the caller guarantees key >= key_base.
+template <typename KeyT, int IPT>
 hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
-                      int end_bit, hipStream_t s) {
+                      uint32_t key_base, int end_bit, int max_bits, hipStream_t s) {
     selector = 0;
     if (n == 0) return hipSuccess;
-    const SortPlan p = plan_sort(n, end_bit);
+    const SortPlan p = plan_sort(n, end_bit, max_bits, IPT);
     if (temp_bytes < p.table_bytes + p.totals_bytes) return hipErrorInvalidValue;
     uint32_t* table = static_cast<uint32_t*>(temp);
     uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + p.table_bytes);
@@ -228,10 +265,10 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
     int shift = 0;
     for (int i = 0; i < p.n_passes; ++i) {
         const int bits = p.bits[i];
-        hipLaunchKernelGGL(radix_histogram_kernel<KeyT>, grid, block, 0, s, keys[selector], n, n_ptr, shift, bits, table, p.n_blocks);
+        hipLaunchKernelGGL((radix_histogram_kernel<KeyT, IPT>), grid, block, 0, s, keys[selector], n, n_ptr, key_base, shift, bits, table, p.n_blocks);
         hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), block, 0, s, table, totals, p.n_blocks);
-        launch_scatter<KeyT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, shift, table,
-                             totals, p.n_blocks);
+        launch_scatter<KeyT, IPT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, key_base, shift,
+                                  table, totals, p.n_blocks);
         selector ^= 1;
         shift += bits;
     }
@@ -242,25 +279,54 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
 using namespace sortimpl;
 
 std::atomic<int> g_sort_implementation{3};          // bit 0: tile sort here, bit 1: depth sort here; cleared bit = rocPRIM onesweep (fgs_debug_set_option key 6)
+std::atomic<int> g_depth_sort_mode{1};              // fgs_debug_set_option(9, m) -- bit 0: sort key - bits(near) in ceil(bits / 9) passes (near 0.2, far 1e4: 27 bits
+                                                    // = 3 passes instead of 4); bit 1: 2048-item workgroups (8 items per thread); 0 = round 1 (4 x 8 bits, 4096 items).
+                                                    // tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
 
-size_t own_sort_temp_bytes(uint32_t n, int end_bit) {
-    const SortPlan p = plan_sort(n, end_bit);
+constexpr int kTileSortItems = 16, kDepthSortItems = 8, kGenericMaxBits = 8;
+
+size_t own_sort_temp_bytes(uint32_t n, int end_bit) {                                  // fits every configuration above (smallest workgroups, full table)
+    const SortPlan p = plan_sort(n, end_bit, kGenericMaxBits, kDepthSortItems);
     return p.table_bytes + p.totals_bytes;
 }
 
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, n, nullptr, end_bit, s);
+    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint16_t>(temp, temp_bytes, keys, vals, selector, n, nullptr, end_bit, s);
+    return sort_pairs<uint16_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s) {
-    return sort_pairs<uint32_t>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, end_bit, s);
+    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s) {
-    return sort_pairs<uint16_t>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, end_bit, s);
+    return sort_pairs<uint16_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
+}
+
+// Depth keys are the bit patterns of positive depths that passed the near / far cull (kf:67), i.e. values in [bits(near), bits(far)]:
+// sorting key - bits(near) gives the same order in fewer bits.
+DepthKeyRange depth_key_range(float near_plane, float far_plane) {
+    DepthKeyRange r{0u, 32};
+    if (!(near_plane >= 0.0f) || !(far_plane >= near_plane)) return r;                 // negative / NaN planes: no assumption, all 32 bits
+    uint32_t lo, hi;
+    std::memcpy(&lo, &near_plane, 4); std::memcpy(&hi, &far_plane, 4);
+    const uint32_t span = hi - lo;
+    int bits = 1;
+    while (bits < 32 && (span >> bits) != 0u) ++bits;
+    r.base = lo; r.bits = bits;
+    return r;
+}
+
+// `n` = visible count, or with n_ptr != nullptr a bound of the count stored at n_ptr on the device
+hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
+                          DepthKeyRange range, hipStream_t s) {
+    const int mode = g_depth_sort_mode;
+    const uint32_t base = (mode & 1) ? range.base : 0u;
+    const int end_bit = (mode & 1) ? range.bits : 32, max_bits = (mode & 1) ? kMaxBits : kGenericMaxBits;
+    if (mode & 2) return sort_pairs<uint32_t, kDepthSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
+    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
 }
 
 }  // namespace fgs

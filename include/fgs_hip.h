@@ -279,6 +279,11 @@ int32_t fgs_debug_wave_selftest(uint32_t* out_device_256, void* stream);
 size_t fgs_debug_radix_sort_temp_bytes(int32_t n, int32_t end_bit);
 int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, int32_t key_bytes, int32_t end_bit,
                              void* temp, size_t temp_bytes, void* stream);
+/* The same hook for the depth sort as the forward pass runs it (K2): keys are the bit patterns of float depths in [near_plane, far_plane]
+ * (everything else is culled in preprocess, kernels_forward.cuh:67), sorted as key - bits(near_plane) in as few 9-bit passes as the range
+ * needs (fgs_debug_set_option(9, m) selects the variants). temp as for fgs_debug_radix_sort with end_bit 32. */
+int32_t fgs_debug_depth_sort(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, float near_plane, float far_plane,
+                             void* temp, size_t temp_bytes, void* stream);
 /* Selects the blend-backward formulation: 3 (default) = live-bucket list + compacted pixels + two-value pipeline state, 2 / 0 =
  * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel). A/B switch for tests and bench: process-wide,
  * unsynchronised; all variants must give the same gradients. */
@@ -286,7 +291,9 @@ int32_t fgs_debug_set_backward_variant(int32_t variant);
 /* Tuning switches for A/B measurements inside one process (process-wide, unsynchronised: bench / test processes only):
  * key 0 = blend-backward variant, 1 = Adam float4 pieces per thread (1, 2, 4), 2 = Adam non-temporal accesses, 3 = fused
  * backward+Adam as one kernel (1, default) or round 1's two (0), 5 = K1 tile counting: 0 flattened (default) or n sequential
- * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop).
+ * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop),
+ * 8 = Adam walks the arenas from the end (1, default) or the start (0), 9 = depth sort: bit 0 key - bits(near) in 9-bit passes, bit 1
+ * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower).
  * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
