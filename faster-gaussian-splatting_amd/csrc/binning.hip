@@ -123,12 +123,15 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     const unsigned tbw = tx1 - tx0;
     const uint32_t mask = (active && tbw * (ty1 - ty0) <= 32u) ? __float_as_uint(r2.w) : 0u;   // larger footprints keep a hot-accumulator slot there
     const uint32_t my_off = offsets[i];
-    const uint32_t my_n = active ? n_touched[prim] : 0u;
+    // No read of n_touched[prim]: that second random gather (a 128-byte line per primitive for 4 bytes, like the record's) made this kernel
+    // fetch 528 MB per launch at S2 for ~100 MB of input (rocprofv3 FETCH_SIZE, round 2). A bitmap footprint's count is the number of set
+    // bits (preprocess wrote exactly the overlapped tiles), and every entry of the visible list has at least one tile (preprocess appends
+    // only cnt > 0: visible = active && cnt > 0, kf:190), which is all the other two paths need to know.
 
     // Bitmap primitives of this wave get wave-local output slots: prefix of their counts. Walking these (not the global
     // range) keeps the loop proportional to what is written here -- a wave holding screen-filling Gaussians would otherwise
     // step over tens of thousands of slots that belong to the other two paths.
-    const uint32_t n_small = mask != 0u ? my_n : 0u;
+    const uint32_t n_small = static_cast<uint32_t>(__popc(mask));
     const uint32_t local = wave_exclusive_sum(n_small);
     const uint32_t total_small = wave_sum(n_small);
     s_off[wv][lane] = my_off;
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     // ---- medium footprints (33 .. kHugeFootprint candidate tiles): re-tested by this wave, 64 candidates per step, with
     // ballot-prefix write slots (kf:283-326) ----
     const unsigned count = tbw * (ty1 - ty0);
-    const bool recompute = active && mask == 0u && my_n != 0u;
+    const bool recompute = active && mask == 0u;
     uint64_t pending = wave_ballot(recompute && count <= kHugeFootprint);
     if (pending != 0) {
         const float4* rr = reinterpret_cast<const float4*>(rec + prim);
