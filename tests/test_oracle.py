@@ -104,6 +104,52 @@ def test_culling_rules(oracle):
     assert np.all(g1['sh_rest'] == 0)
 
 
+def _brute_force_scene(case: str):
+    """S0 variants that exercise every cull the pipeline applies before blending."""
+    if case == 'plain':
+        p, v = make_s0(seed=5, n=700)
+        return p, View(v.w2c, v.position, 96, 60, 90.0, 90.0, 48.0, 30.0, 0.2, 1e4, torch.tensor([0.1, 0.3, 0.6])), 16, False
+    if case == 'large_anisotropic':            # screen-filling and needle-shaped footprints: medium / huge tile paths, tile test corners
+        p, v = make_s0(seed=6, n=400)
+        p['scales'][:30] += torch.tensor([2.2, -1.0, 0.3])
+        p['scales'][30:40] += 3.0
+        p['opacities'][:40] -= 2.0
+        return p, View(v.w2c, v.position, 100, 76, 80.0, 80.0, 50.0, 38.0, 0.2, 1e4, torch.zeros(3)), 16, False
+    if case == 'borders_and_near_plane':       # centres outside the image, depths around the near plane, partial tiles (not multiples of 16 x 12)
+        p, v = make_s0(seed=7, n=600)
+        p['means'][:200] *= torch.tensor([2.5, 2.5, 1.0])
+        p['means'][200:260, 2] = -3.9 + 0.3 * torch.rand(60, generator=torch.Generator().manual_seed(1))
+        return p, View(v.w2c, v.position, 75, 53, 70.0, 70.0, 37.5, 26.5, 0.2, 1e4, torch.tensor([0.5, 0.5, 0.5])), 9, False
+    p, v = make_s0(seed=8, n=500)              # 'antialiasing': opacity scaled by the dilation ratio, second opacity cull
+    p['scales'][:250] -= 2.0                   # sub-pixel Gaussians: the factor matters
+    return p, View(v.w2c, v.position, 64, 48, 60.0, 60.0, 32.0, 24.0, 0.2, 1e4, torch.zeros(3)), 4, True
+
+
+@pytest.mark.parametrize('case', ['plain', 'large_anisotropic', 'borders_and_near_plane', 'antialiasing'])
+def test_image_matches_brute_force_definition(oracle, case):
+    """Pins the DISCRETE half of the oracle (which the fp64 autograd check takes as given): screen bounds, exact tile test, 8x4 sub-tile
+    test, both sorts, instance lists, ranges and the culls are all supposed to remove only pairs that fail alpha >= 1/255 and to keep the
+    depth order. oracle.torch_check.brute_force_forward blends every Gaussian at every pixel in fp64 with the per-pair rules alone; image
+    and final transmittance must agree outside the pixels where a blend decision sits on a threshold (counted, from BOTH sides)."""
+    from oracle.torch_check import brute_force_forward
+    p, v, K, aa = _brute_force_scene(case)
+    S, _ = helpers.settings_pair(v, K, aa)
+    a = helpers.np_params(p)
+    f = oracle.forward(*a, S)
+    bf = brute_force_forward(dict(means=a[0], scales=a[1], rotations=a[2], opacities=a[3], sh0=a[4], sh_rest=a[5]), S)
+    mask = bf['risk'] | oracle.threshold_risk(f, S, 2e-5, 1e-3 * 1e-4)['pixel']
+    assert mask.mean() < 5e-3, mask.mean()
+    assert f['V'] > 100 and f['I'] > f['V']
+    err = np.abs(f['image'].astype(np.float64) - bf['image']).max(axis=0)
+    err_T = np.abs(f['final_T'].reshape(v.height, v.width).astype(np.float64) - bf['final_T'])
+    assert err[~mask].max() < 1e-5 and err_T[~mask].max() < 1e-5, (case, float(err[~mask].max()), float(err_T[~mask].max()), int((err > 1e-5).sum()))
+    # a Gaussian that is blended somewhere by definition must be in the pipeline's visible list
+    assert not (bf['contributes'] & (f['n_touched'] == 0)).any()
+    # ... and in the same depth order
+    vis_order = bf['order'][np.isin(bf['order'], np.nonzero(f['n_touched'] > 0)[0])]
+    assert np.array_equal(vis_order, f['prim_idx'][np.isin(f['prim_idx'], vis_order)])
+
+
 @pytest.mark.parametrize('aa,K', [(False, 16), (True, 4)])
 def test_gradients_match_fp64_autograd(oracle, aa, K):
     from oracle.torch_check import autograd_reference
