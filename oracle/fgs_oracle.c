@@ -6,7 +6,9 @@
  * (no nvcc, no NVIDIA device). This file restates the reference arithmetic from its sources; it is
  * pinned only by (a) an independent fp64 torch.autograd compositor (oracle/torch_check.py) and finite
  * differences of it, (b) hand-derived closed-form cases (one / two Gaussians on the optical axis: image
- * and analytic gradients) and the orthonormality of the SH basis, (c) structural invariants
+ * and analytic gradients) and the orthonormality of the SH basis, (c) structural invariants, (d) an fp64 render
+ * BY DEFINITION (torch_check.py: brute_force_forward -- every Gaussian at every pixel under the per-pair alpha / transmittance
+ * rules alone) for the discrete half: bounds, tile test, sub-tile test, sorts, lists, culls
  * (all in tests/test_oracle.py). None of these is an output of the reference itself. See DESIGN.md "Oracle".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.

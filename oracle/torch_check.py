@@ -6,6 +6,9 @@ are checked against autograd of a *forward-only* fp64 re-implementation of the i
 The discrete structure (depth order, instance lists, screen bounds) is taken from the oracle's forward pass;
 everything differentiable is recomputed here from the parameters. Dense [pixels x visible Gaussians] evaluation: use
 small scenes only.
+
+brute_force_forward (below) is the complementary check of that discrete structure: a render by definition that takes NOTHING from the
+oracle's forward pass.
 """
 from __future__ import annotations
 
