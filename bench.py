@@ -313,7 +313,6 @@ def main():
                  'wire_bytes_per_rank_per_step': wire_bytes(other_mode)}
         del vp2
 
-    B_async_stats = FGS.async_forward_stats
     used = [my_views[(args.warmup + PROFILE_STEPS + i) % len(my_views)] for i in range(args.steps)]
     mean = lambda key: float(np.mean([stats[id(v)][key] for v in used]))
     V, I, B = mean('V'), mean('I'), mean('B')
