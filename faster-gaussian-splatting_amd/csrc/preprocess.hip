@@ -17,8 +17,30 @@ namespace fgs {
 __device__ __forceinline__ int float_to_int_floor(float x) { return static_cast<int>(floorf(fminf(fmaxf(x, -1.0e9f), 1.0e9f))); }
 __device__ __forceinline__ int float_to_int_ceil(float x) { return static_cast<int>(ceilf(fminf(fmaxf(x, -1.0e9f), 1.0e9f))); }
 
+// Debug-only phase timer (tools/k1_phase_timer.sh builds a separate library with -DFGS_K1_PHASE_TIMER; the product build has none of it):
+// every wave keeps the cycles it spent between two marks in (scalar) registers and stores them ONCE, to its own slot of g_k1_phase, at the
+// end -- a first version with one atomic per mark onto eight shared words slowed the kernel 9x and measured only itself. A wave's memory
+// waits land in the phase that first uses the data, i.e. where the wave stalls. Result at S2 (profiles/r02_k1_phases.txt): loads +
+// projection 20 %, flattened tile count 26 %, SH colour + record 23 %, and 24 % in the last phase -- waves waiting at the workgroup
+// barrier of the compaction for slower siblings, not the counter's round trip: requesting the counter before the colour phase so that
+// the round trip overlaps with it made the kernel 6.5 % SLOWER (profiles/r02_ab_k1_early_counter.txt) and was reverted.
+#ifdef FGS_K1_PHASE_TIMER
+constexpr unsigned kK1TimerWaves = 1u << 17;
+__device__ unsigned long long g_k1_phase[kK1TimerWaves * 8];
+#define FGS_K1_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_phase_[i] += now_ - t_prev_; t_prev_ = now_; } while (0)
+#define FGS_K1_START unsigned long long t_phase_[8] = {}; unsigned long long t_prev_ = __builtin_readcyclecounter()
+#define FGS_K1_FLUSH do { const unsigned w_ = (blockIdx.x * kPreprocessBlock + threadIdx.x) >> 6; \
+                          if (lane_id() < 8u && w_ < kK1TimerWaves) g_k1_phase[w_ * 8u + lane_id()] += t_phase_[0] * (lane_id() == 0) + t_phase_[1] * (lane_id() == 1) + \
+                              t_phase_[2] * (lane_id() == 2) + t_phase_[3] * (lane_id() == 3) + t_phase_[4] * (lane_id() == 4) + t_phase_[5] * (lane_id() == 5); } while (0)
+#else
+#define FGS_K1_MARK(i) do { } while (0)
+#define FGS_K1_START do { } while (0)
+#define FGS_K1_FLUSH do { } while (0)
+#endif
+
 template <bool INFERENCE>
 __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
+    FGS_K1_START;
     const Camera cam = load_camera(a.cam);
     const unsigned gid = blockIdx.x * kPreprocessBlock + threadIdx.x;
     const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
@@ -31,6 +53,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     m[0] = a.means[3 * (size_t)idx]; m[1] = a.means[3 * (size_t)idx + 1]; m[2] = a.means[3 * (size_t)idx + 2];
     const float depth = view_depth(cam, m[0], m[1], m[2]);
     if (depth < cam.near_plane || depth > cam.far_plane) active = false;              // kf:67
+    FGS_K1_MARK(0);                                                                    // camera + mean loaded, depth cull
 
     bool visible = false;
     unsigned cnt = 0;
@@ -75,6 +98,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         const unsigned tbw = tx1 - tx0;
         const unsigned n_max = tbw * (ty1 - ty0);
         if (n_max == 0) active = false;                                                // kf:178
+        FGS_K1_MARK(1);                                                                // opacity / scale / rotation loads, projection, bounds
 
         if (wave_ballot(active) != 0) {                                                // kf:181
             // ---- exact tile count (kernel_utils.cuh:117-180), wave64 version ----
@@ -144,6 +168,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                     }
                 }
             }
+            FGS_K1_MARK(2);                                                            // flattened exact tile count
             uint64_t pending = wave_ballot(active && n_max > first_shared);
             while (pending != 0) {                              // wave-uniform loop over lanes with large footprints
                 const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
@@ -168,6 +193,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 if (lane == static_cast<unsigned>(src)) cnt += found;
             }
 
+            FGS_K1_MARK(3);                                                            // footprints of > 64 candidates
             visible = active && cnt > 0;                                               // kf:190
             // hot-accumulator slots for K11 (fgs_config.h): one counter atomic per wave that holds such a footprint
             uint32_t slot_word = n_max <= 32u ? hit_mask : 0u;
@@ -203,6 +229,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
             }
         }
     }
+    FGS_K1_MARK(4);                                             // hot slots, SH colour, record write (waves that were not culled whole)
     if (gid < a.n) a.n_touched[idx] = visible ? cnt : 0u;      // kf:59,193; also the scan input of K4 and the skip test of K12
 
     // ---- compaction (kf:204-208): ONE 64-bit atomic per 512-thread workgroup. Both counters share one word
@@ -232,6 +259,8 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         a.depth_keys[off] = __float_as_uint(depth);
         a.prim_idx[off] = idx;
     }
+    FGS_K1_MARK(5);                                             // tile-count store, workgroup barrier + compaction atomic, key / index store
+    FGS_K1_FLUSH;
 }
 
 template <bool INFERENCE>
@@ -296,3 +325,18 @@ hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s) {
 }
 
 }  // namespace fgs
+
+#ifdef FGS_K1_PHASE_TIMER
+// debug build only: sum (and optionally clear) the per-wave, per-phase cycle counts of preprocess_body
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k1_phases(unsigned long long* out8, int reset) {
+    static unsigned long long host[fgs::kK1TimerWaves * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(fgs::g_k1_phase), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (unsigned w = 0; w < fgs::kK1TimerWaves; ++w) for (int i = 0; i < 8; ++i) out8[i] += host[w * 8u + i];
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k1_phase)) != hipSuccess || hipMemset(dev, 0, sizeof(host)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
