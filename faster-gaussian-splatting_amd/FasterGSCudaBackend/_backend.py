@@ -7,7 +7,7 @@ Mirrors what the reference does in C++ in rasterization_api.cu:13-247 and utils/
 from __future__ import annotations
 
 import ctypes as C
-from typing import NamedTuple, Sequence
+from typing import NamedTuple, Optional, Sequence
 
 import torch
 
@@ -242,6 +242,36 @@ class Backend:
         self._check(self.lib.fgs_l1_dssim_loss(image.data_ptr(), target.data_ptr(), w, h, float(lambda_l1), float(lambda_dssim),
                                                sums.data_ptr(), _ptr(grad), scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_loss')
         return sums[2], grad, sums[:2]      # loss and the (l1, ssim) means are formed on the device by the reduce kernel
+
+    def l1_dssim_forward(self, image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2):
+        """The loss value alone: returns (loss 0-dim tensor, (l1, ssim) tensor, scratch). `scratch` holds the derivative maps that
+        l1_dssim_backward turns into dloss/dimage -- the shape of an autograd loss node (forward saves, backward launches one kernel)."""
+        device = self._check_params((image, target), ('image', 'target'))
+        if image.dim() != 3 or image.shape[0] != 3 or image.shape != target.shape:
+            raise RuntimeError('l1_dssim expects two [3,H,W] tensors')
+        _, h, w = image.shape
+        sums = torch.empty(3, dtype=torch.float32, device=device)
+        scratch = torch.empty(int(self.lib.fgs_l1_dssim_scratch_bytes(w, h)), dtype=torch.uint8, device=device)
+        self._check(self.lib.fgs_l1_dssim_loss(image.data_ptr(), target.data_ptr(), w, h, float(lambda_l1), float(lambda_dssim),
+                                               sums.data_ptr(), None, scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_loss')
+        return sums[2], sums[:2], scratch
+
+    def l1_dssim_backward(self, image: torch.Tensor, target: torch.Tensor, scratch: torch.Tensor, upstream: Optional[torch.Tensor] = None,
+                          lambda_l1: float = 0.8, lambda_dssim: float = 0.2) -> torch.Tensor:
+        """dloss/dimage * upstream from the maps of l1_dssim_forward (same image / target). `upstream`: a float32 scalar tensor on the
+        device (dL/dloss), folded into the kernel -- no `grad * upstream` pass over the image -- or None for 1."""
+        device = self._check_params((image, target), ('image', 'target'))
+        _, h, w = image.shape
+        if scratch.device != device or scratch.numel() < int(self.lib.fgs_l1_dssim_scratch_bytes(w, h)):
+            raise RuntimeError('l1_dssim_backward: scratch is not the buffer l1_dssim_forward returned for this image size')
+        if upstream is not None:
+            if upstream.device != device or upstream.dtype != torch.float32 or upstream.numel() != 1:
+                raise RuntimeError('l1_dssim_backward: upstream must be one float32 on the device of the image')
+            upstream = upstream.reshape(1).contiguous()
+        grad = torch.empty_like(image)
+        self._check(self.lib.fgs_l1_dssim_backward(image.data_ptr(), target.data_ptr(), w, h, float(lambda_l1), float(lambda_dssim),
+                                                   _ptr(upstream), grad.data_ptr(), scratch.data_ptr(), _stream_of(device)), 'fgs_l1_dssim_backward')
+        return grad
 
     # -- Gaussian-sharded multi-GPU path (include/fgs_hip.h, "Gaussian-sharded multi-GPU path") --------------------------------
     def _settings_array(self, views: Sequence[RasterizerSettings], total_sh_rest: int, device: torch.device, keep: list):

@@ -82,6 +82,7 @@ _SIGNATURES = {
     'fgs_morton_order': (C.c_int32, [_P, _P, _P, _P, _I32, _P, C.c_size_t, _P]),
     'fgs_l1_dssim_scratch_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_l1_dssim_loss': (C.c_int32, [_P, _P, _I32, _I32, C.c_float, C.c_float, _P, _P, _P, _P]),
+    'fgs_l1_dssim_backward': (C.c_int32, [_P, _P, _I32, _I32, C.c_float, C.c_float, _P, _P, _P, _P]),
     'fgs_profile_enable': (C.c_int32, [_I32]),
     'fgs_profile_read': (C.c_int32, [C.POINTER(StageTime), _I32]),
     'fgs_debug_wave_selftest': (C.c_int32, [_P, _P]),

@@ -959,6 +959,19 @@ int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width
     return FGS_OK;
 }
 
+int32_t fgs_l1_dssim_backward(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
+                              const float* upstream, float* grad_image, const void* scratch, void* stream_) {
+    if (!image || !target || !grad_image || !scratch || width <= 0 || height <= 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t plane3 = 3 * static_cast<size_t>(width) * static_cast<size_t>(height);
+    LossArgs a{};
+    a.image = image; a.target = target; a.grad = grad_image; a.upstream = upstream;
+    a.d_mu = static_cast<float*>(const_cast<void*>(scratch)); a.d_m11 = a.d_mu + plane3; a.d_m12 = a.d_m11 + plane3;
+    a.width = width; a.height = height; a.lambda_l1 = lambda_l1; a.lambda_dssim = lambda_dssim;
+    { StageScope t(ST_LOSS, stream); FGS_HIP(launch_l1_dssim_backward(a, stream)); }
+    return FGS_OK;
+}
+
 int32_t fgs_profile_enable(int32_t enable) {
     g_prof.enabled = enable != 0;
     g_prof.only = enable >= 2 ? enable - 2 : -1;          // 1: every stage; 2 + k: stage k only (index into fgs_profile_read's table)

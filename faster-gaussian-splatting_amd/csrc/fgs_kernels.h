@@ -156,9 +156,11 @@ struct LossArgs {                       // fused L1 + DSSIM loss and its image g
     float* partials;                             // scratch: 2 floats per workgroup of the forward kernel
     int width, height;
     float lambda_l1, lambda_dssim;
+    const float* upstream;                       // device scalar dL/dloss the gradient is multiplied with, or nullptr (= 1)
 };
 size_t l1_dssim_partials(int width, int height);   // number of floats in LossArgs::partials
 hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s);
+hipError_t launch_l1_dssim_backward(const LossArgs& a, hipStream_t s);   // gradient only, from the maps a forward launch left in d_mu / d_m11 / d_m12
 
 // shard_exchange.hip: record (un)packing either side of the two exchanges of the Gaussian-sharded multi-GPU path
 struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const uint32_t* depth_keys; const uint32_t* prim_idx;

@@ -259,6 +259,12 @@ int32_t fgs_morton_order(const float* means, const float* lo, const float* hi, i
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height);
 int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
                           float* out3, float* grad_image, void* scratch, void* stream);
+/* The gradient alone, later: dloss/dimage * upstream from the derivative maps that fgs_l1_dssim_loss (with grad_image == NULL or not) left in
+ * `scratch` for the same image / target. `upstream` is a DEVICE float (the dL/dloss an autograd engine hands to the loss node) or NULL for 1:
+ * the scalar is folded into the kernel, so a framework does not spend a pass over the image on `grad * upstream`. This is the shape of the
+ * reference's loss node (fused_dssim: forward saves maps, backward launches one kernel). */
+int32_t fgs_l1_dssim_backward(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
+                              const float* upstream, float* grad_image, const void* scratch, void* stream);
 
 /* Optional per-stage timing. While enabled (1), every pipeline stage is bracketed by hipEvents recorded on the caller's stream
  * (each event costs a few microseconds of GPU idle time: ~0.2 ms per training iteration with all stages on); enable = 2 + k brackets

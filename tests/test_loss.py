@@ -51,6 +51,15 @@ def test_sim_loss_kernels_match_oracle(sim_backend, oracle, h, w):
     assert helpers.rel_inf(grad.numpy(), og) < 1e-5
     loss2, none, _ = sim_backend.l1_dssim(torch.from_numpy(x), torch.from_numpy(y), with_grad=False)
     assert none is None and abs(float(loss2) - ol) < 1e-6
+    # the autograd shape: forward keeps the derivative maps, backward alone produces dloss/dimage * upstream (a device scalar)
+    loss3, means3, scratch = sim_backend.l1_dssim_forward(torch.from_numpy(x), torch.from_numpy(y))
+    assert float(loss3) == float(loss) and torch.equal(means3, means)
+    g1 = sim_backend.l1_dssim_backward(torch.from_numpy(x), torch.from_numpy(y), scratch)
+    assert torch.equal(g1, grad)                                                   # upstream None = 1: the same kernel, bit for bit
+    g2 = sim_backend.l1_dssim_backward(torch.from_numpy(x), torch.from_numpy(y), scratch, torch.tensor(-0.37))
+    assert helpers.rel_inf(g2.numpy(), -0.37 * og) < 1e-5
+    with pytest.raises(RuntimeError):
+        sim_backend.l1_dssim_backward(torch.from_numpy(x), torch.from_numpy(y), scratch[:16])
 
 
 @pytest.mark.gpu
