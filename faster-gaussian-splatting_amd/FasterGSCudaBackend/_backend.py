@@ -166,8 +166,10 @@ class Backend:
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
 
     def backward(self, densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest, buffers, settings,
-                 state, out: tuple | None = None) -> tuple:
-        """`out`: optional six preallocated gradient tensors (e.g. views into one contiguous arena for a single RCCL call)."""
+                 state, out: tuple | None = None, live_blocks: Optional[torch.Tensor] = None) -> tuple:
+        """`out`: optional six preallocated gradient tensors (e.g. views into one contiguous arena for a single RCCL call).
+        `live_blocks`: optional uint8 [ceil(N / 64)] on the device, filled with 1 / 0 per block of 64 Gaussians: 0 = every gradient of the block
+        is zero (still written) -- what adam_step_multi(live_blocks=...) needs to skip reading those zeros."""
         device = self._check_params((means, scales, rotations, opacities, sh_rest), ('means', 'scales', 'rotations', 'opacities', 'sh_coefficients_rest'))
         keep: list = []
         n = means.shape[0]
@@ -187,10 +189,14 @@ class Backend:
             raise RuntimeError('densification_info must be a contiguous float32 [2, N] tensor on the parameters\' device')
         scratch = self._scratch(n, settings, device)
         st = _lib.ForwardState(*state)
-        self._check(self.lib.fgs_backward(_ptr(grad_image), _ptr(image), _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities),
-                                          _ptr(sh_rest), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]), _ptr(buffers[3]),
-                                          _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), _ptr(grads[3]), _ptr(grads[4]), _ptr(grads[5]),
-                                          _ptr(dens), scratch.data_ptr(), n, C.byref(S), C.byref(st), _stream_of(device)), 'fgs_backward')
+        if live_blocks is not None and (live_blocks.dtype != torch.uint8 or live_blocks.device != device or not live_blocks.is_contiguous()
+                                        or live_blocks.numel() != (n + 63) // 64):
+            raise RuntimeError('live_blocks must be a contiguous uint8 tensor of ceil(N / 64) elements on the parameters\' device')
+        self._check(self.lib.fgs_backward_live(_ptr(grad_image), _ptr(image), _ptr(means), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                               _ptr(sh_rest), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]), _ptr(buffers[3]),
+                                               _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), _ptr(grads[3]), _ptr(grads[4]), _ptr(grads[5]),
+                                               _ptr(dens), scratch.data_ptr(), n, C.byref(S), C.byref(st), _ptr(live_blocks), _stream_of(device)),
+                    'fgs_backward')
         return grads
 
     def backward_adam_fused(self, densification_info, grad_image, image, params: Sequence[torch.Tensor], exp_avgs, exp_avg_sqs,
@@ -218,16 +224,27 @@ class Backend:
         self._check(self.lib.fgs_adam_step(_ptr(grad), _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), int(step),
                                            float(lr), float(beta1), float(beta2), float(eps), _stream_of(device)), 'fgs_adam_step')
 
-    def adam_step_multi(self, grads, params, exp_avgs, exp_avg_sqs, steps, lrs, beta1: float, beta2: float, eps: float) -> None:
+    def adam_step_multi(self, grads, params, exp_avgs, exp_avg_sqs, steps, lrs, beta1: float, beta2: float, eps: float,
+                        live_blocks: Optional[torch.Tensor] = None) -> None:
+        """`live_blocks` (as filled by backward(live_blocks=...) for EXACTLY these gradient tensors, all of them [N, ...]): a promise that the
+        gradient rows of blocks flagged 0 are zero; they are not read. The result is bit-identical either way."""
         k = len(params)
         if k == 0:
             return
         device = self._check_params(tuple(grads) + tuple(params) + tuple(exp_avgs) + tuple(exp_avg_sqs), ['adam tensor'] * (4 * k))
         arr = lambda ts: (C.c_void_p * k)(*[_ptr(t) for t in ts])
-        self._check(self.lib.fgs_adam_step_multi(k, arr(grads), arr(params), arr(exp_avgs), arr(exp_avg_sqs),
-                                                 (C.c_int64 * k)(*[p.numel() for p in params]), (C.c_int32 * k)(*[int(s) for s in steps]),
-                                                 (C.c_double * k)(*[float(x) for x in lrs]), float(beta1), float(beta2), float(eps),
-                                                 _stream_of(device)), 'fgs_adam_step_multi')
+        rows = None
+        if live_blocks is not None:
+            n = params[0].shape[0]
+            if any(p.dim() < 1 or p.shape[0] != n for p in params) or n == 0:
+                raise RuntimeError('live_blocks needs parameter tensors that all have one row per Gaussian')
+            if live_blocks.dtype != torch.uint8 or live_blocks.device != device or not live_blocks.is_contiguous() or live_blocks.numel() != (n + 63) // 64:
+                raise RuntimeError('live_blocks must be a contiguous uint8 tensor of ceil(N / 64) elements on the parameters\' device')
+            rows = (C.c_int32 * k)(*[p.numel() // n for p in params])
+        self._check(self.lib.fgs_adam_step_multi_live(k, arr(grads), arr(params), arr(exp_avgs), arr(exp_avg_sqs),
+                                                      (C.c_int64 * k)(*[p.numel() for p in params]), (C.c_int32 * k)(*[int(s) for s in steps]),
+                                                      (C.c_double * k)(*[float(x) for x in lrs]), float(beta1), float(beta2), float(eps),
+                                                      _ptr(live_blocks), rows, _stream_of(device)), 'fgs_adam_step_multi')
 
     def l1_dssim(self, image: torch.Tensor, target: torch.Tensor, lambda_l1: float = 0.8, lambda_dssim: float = 0.2,
                  with_grad: bool = True):

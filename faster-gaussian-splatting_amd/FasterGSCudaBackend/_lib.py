@@ -56,10 +56,13 @@ _SIGNATURES = {
     'fgs_forward_counts': (C.c_int32, [_P, _I32, _P, _P]),
     'fgs_backward_scratch_bytes': (C.c_size_t, [_I32, _I32, _I32]),
     'fgs_backward': (C.c_int32, [_P] * 2 + [_P] * 5 + [_P] * 4 + [_P] * 6 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
+    'fgs_backward_live': (C.c_int32, [_P] * 2 + [_P] * 5 + [_P] * 4 + [_P] * 6 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P, _P]),
     'fgs_inference': (C.c_int32, [_P] * 6 + [_I32, C.POINTER(Settings), _P, _I32, _I32, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
     'fgs_pruning_scores': (C.c_int32, [_P] * 7 + [_I32, C.POINTER(Settings), RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
     'fgs_adam_step': (C.c_int32, [_P] * 4 + [_I64, _I32, _F64, _F64, _F64, _F64, _P]),
     'fgs_adam_step_multi': (C.c_int32, [_I32] + [C.POINTER(_P)] * 4 + [C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _F64, _F64, _F64, _P]),
+    'fgs_adam_step_multi_live': (C.c_int32, [_I32] + [C.POINTER(_P)] * 4 + [C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_F64), _F64, _F64, _F64, _P,
+                                             C.POINTER(_I32), _P]),
     'fgs_backward_adam_fused': (C.c_int32, [_P] * 2 + [C.POINTER(_P)] * 3 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState),
                                             _I32, C.POINTER(_F64), _F64, _F64, _F64, _P]),
     'fgs_shard_preprocess': (C.c_int32, [_P] * 6 + [_I32, _I32, C.POINTER(Settings), _P, _P, RESIZE_FN, _P, _P]),

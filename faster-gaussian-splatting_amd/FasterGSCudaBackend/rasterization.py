@@ -31,6 +31,70 @@ def set_gradient_buffers(provider) -> None:
 # instance count between two consecutive iterations that training does not produce (densification grows N, and the bound scales with N).
 _ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0}
 
+# ---- live-block hand-over from this backward pass to FusedAdam.step ------------------------------------------------------------------
+# One third of the Gaussians is invisible in a view; their gradients are zeros that the backward pass writes (the gradient tensors are dense and
+# valid for any reader) and the optimizer reads back. The backward pass also leaves one byte per block of 64 Gaussians ("any visible"), and
+# FusedAdam.step skips READING the gradients of dead blocks -- if, and only if, the gradients it is handed are still exactly what this
+# backward pass wrote. That is established without trusting anybody: the six gradients are views into ONE arena that this registry keeps alive
+# (their addresses cannot be re-used by another tensor while registered). The registry holds the ARENA and the views' addresses / shapes, never
+# the view tensors themselves: autograd adopts an incoming gradient as `.grad` only if nobody else references that tensor (it looks at the
+# reference count of the view, not of its storage) and clones it otherwise -- 708 MB per iteration at 3 M Gaussians. A match needs the same address, the same shape and an unchanged version counter (views share the arena's: any
+# in-place edit -- accumulation of a second backward, clipping, scaling -- shows). Anything else takes the ordinary path; results are
+# bit-identical either way.
+_LIVE = {'enabled': True, 'arena': None, 'version': -1, 'flags': None, 'views': (), 'matched': 0, 'missed': 0}
+_ALIGN_FLOATS = 64          # every gradient starts on a 256-byte boundary (16-byte loads in the optimizer kernel)
+
+
+def set_live_block_handover(enabled: bool) -> None:
+    _LIVE['enabled'] = bool(enabled)
+    clear_live_blocks()
+
+
+def live_block_stats() -> dict:
+    return {'matched': _LIVE['matched'], 'missed': _LIVE['missed']}
+
+
+def clear_live_blocks() -> None:
+    _LIVE.update(arena=None, version=-1, flags=None, views=())
+
+
+def _gradient_arena(shapes, device):
+    offsets, total = [], 0
+    for sh in shapes:
+        offsets.append(total)
+        numel = 1
+        for d in sh:
+            numel *= d
+        total += (numel + _ALIGN_FLOATS - 1) // _ALIGN_FLOATS * _ALIGN_FLOATS
+    arena = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    views = []
+    for sh, off in zip(shapes, offsets):
+        numel = 1
+        for d in sh:
+            numel *= d
+        views.append(arena[off:off + numel].view(sh))
+    return arena, tuple(views)
+
+
+def match_live_blocks(gradients) -> 'torch.Tensor | None':
+    """The flags of the registered backward pass if `gradients` (the tensors an optimizer is about to consume, one per parameter group) are
+    exactly the tensors it wrote -- same addresses, shapes, untouched since -- else None. The registration is consumed either way."""
+    arena, flags, views, version = _LIVE['arena'], _LIVE['flags'], _LIVE['views'], _LIVE['version']
+    clear_live_blocks()
+    if arena is None or flags is None or len(gradients) == 0:
+        return None
+    by_address = {address: shape for address, shape in views if address != 0}
+    seen = set()
+    for g in gradients:
+        shape = by_address.get(g.data_ptr())
+        if (shape is None or g.data_ptr() in seen or tuple(g.shape) != shape or g.dtype != torch.float32 or not g.is_contiguous()
+                or g.device != arena.device or g._version != version):
+            _LIVE['missed'] += 1
+            return None
+        seen.add(g.data_ptr())
+    _LIVE['matched'] += 1
+    return flags
+
 
 def set_async_forward(enabled: bool, headroom: float = 1.25) -> None:
     _ASYNC.update(enabled=bool(enabled), headroom=float(headroom))
@@ -91,9 +155,20 @@ class _Rasterize(torch.autograd.Function):
                               RuntimeWarning)
                 res = default_backend().forward(means, scales, rotations, opacities, sh0, sh_rest, ctx.rasterizer_settings)
                 image, buffers, state = res.image, list(res.buffers), res.state
-        grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
-                                           buffers, ctx.rasterizer_settings, state,
-                                           out=_GRAD_OUT() if _GRAD_OUT is not None else None)
+        n = means.shape[0]
+        if _LIVE['enabled'] and _GRAD_OUT is None and n > 0:
+            total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
+            arena, views = _gradient_arena(((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3)), means.device)
+            flags = torch.empty((n + 63) // 64, dtype=torch.uint8, device=means.device)
+            grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
+                                               buffers, ctx.rasterizer_settings, state, out=views, live_blocks=flags)
+            _LIVE.update(arena=arena, version=arena._version, flags=flags, views=tuple((v.data_ptr() if v.numel() else 0, tuple(v.shape)) for v in views))
+            del views
+        else:
+            clear_live_blocks()
+            grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
+                                               buffers, ctx.rasterizer_settings, state,
+                                               out=_GRAD_OUT() if _GRAD_OUT is not None else None)
         return (*grads, None, None)   # densification_info, rasterizer_settings
 
 

@@ -473,14 +473,14 @@ size_t fgs_backward_scratch_bytes(int32_t n_primitives, int32_t width, int32_t h
     return c.total();
 }
 
-int32_t fgs_backward(const float* grad_image, const float* image,
-                     const float* means, const float* scales, const float* rotations, const float* opacities,
-                     const float* sh_coefficients_rest,
-                     void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
-                     float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
-                     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
-                     float* densification_info, void* scratch,
-                     int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
+int32_t fgs_backward_live(const float* grad_image, const float* image,
+                          const float* means, const float* scales, const float* rotations, const float* opacities,
+                          const float* sh_coefficients_rest,
+                          void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                          float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                          float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                          float* densification_info, void* scratch,
+                          int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, uint8_t* live_blocks, void* stream_) {
     BackwardPlan P;
     if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_primitives, settings, state)) return rc;
     if (!grad_image || !image) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL image / grad_image");
@@ -503,12 +503,27 @@ int32_t fgs_backward(const float* grad_image, const float* image,
     sh.n = a.n; sh.total_sh_rest = settings->total_sh_bases_rest; sh.active_sh_bases = settings->active_sh_bases;
     if (g_fused_single_kernel) {           // K12 (bwd:94) as one kernel
         StageScope t(ST_PREPROCESS_BACKWARD, stream);
+        a.live_blocks = live_blocks;
         FGS_HIP(launch_backward_gradients(a, sh, stream));
         return FGS_OK;
     }
+    if (live_blocks != nullptr) FGS_HIP(hipMemsetAsync(live_blocks, 1, (static_cast<size_t>(n_primitives) + 63) / 64, stream));   // A/B form: no flags, every block "live"
     { StageScope t(ST_PREPROCESS_BACKWARD, stream); FGS_HIP(launch_preprocess_backward(false, a, stream)); }   // round-1 form: geometry kernel + SH-rest kernel
     if (settings->total_sh_bases_rest > 0) { StageScope t(ST_SH_REST_BACKWARD, stream); FGS_HIP(launch_sh_rest_backward(false, sh, stream)); }
     return FGS_OK;
+}
+
+int32_t fgs_backward(const float* grad_image, const float* image,
+                     const float* means, const float* scales, const float* rotations, const float* opacities,
+                     const float* sh_coefficients_rest,
+                     void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                     float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                     float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                     float* densification_info, void* scratch,
+                     int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream) {
+    return fgs_backward_live(grad_image, image, means, scales, rotations, opacities, sh_coefficients_rest, primitive_buffers, tile_buffers,
+                             instance_buffers, bucket_buffers, grad_means, grad_scales, grad_rotations, grad_opacities, grad_sh_coefficients_0,
+                             grad_sh_coefficients_rest, densification_info, scratch, n_primitives, settings, state, nullptr, stream);
 }
 
 int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
@@ -752,11 +767,14 @@ int32_t fgs_shard_backward_adam_fused(const float* acc_records, const int32_t* n
                               nullptr, nullptr, nullptr, nullptr, densification_info, scratch, n_primitives, n_views, settings, &adam, stream);
 }
 
-int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
-                            float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
-                            double beta1, double beta2, double eps, void* stream) {
+int32_t fgs_adam_step_multi_live(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
+                                 float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
+                                 double beta1, double beta2, double eps, const uint8_t* live_blocks, const int32_t* floats_per_gaussian,
+                                 void* stream) {
     if (n_groups < 0 || n_groups > 8) return fail(FGS_ERR_INVALID_ARGUMENT, "n_groups %d (max 8)", n_groups);
+    if (live_blocks != nullptr && floats_per_gaussian == nullptr) return fail(FGS_ERR_INVALID_ARGUMENT, "live_blocks without floats_per_gaussian");
     AdamArgs a{};
+    a.live_blocks = live_blocks;
     uint32_t blocks = 0;
     for (int k = 0; k < n_groups; ++k) {
         if (n_elements[k] < 0 || steps[k] < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "group %d: n_elements / step", k);
@@ -765,12 +783,23 @@ int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* 
         AdamGroup& g = a.g[a.n_groups++];
         g.grad = grads[k]; g.param = params[k]; g.exp_avg = exp_avgs[k]; g.exp_avg_sq = exp_avg_sqs[k]; g.n = n_elements[k];
         g.h = adam_hyper(steps[k], lrs[k], beta1, beta2, eps);
+        g.row_len = 0;
+        if (live_blocks != nullptr) {
+            if (floats_per_gaussian[k] < 1 || n_elements[k] % floats_per_gaussian[k] != 0) return fail(FGS_ERR_INVALID_ARGUMENT, "group %d: floats_per_gaussian", k);
+            if (n_elements[k] < (int64_t{1} << 32)) g.row_len = static_cast<uint32_t>(floats_per_gaussian[k]);   // 32-bit index arithmetic in the kernel
+        }
         g.first_block = blocks;
         blocks += static_cast<uint32_t>((n_elements[k] + 1023) / 1024);
     }
     a.total_blocks = blocks;
     { StageScope t(ST_ADAM, static_cast<hipStream_t>(stream)); FGS_HIP(launch_adam(a, static_cast<hipStream_t>(stream))); }
     return FGS_OK;
+}
+
+int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
+                            double beta1, double beta2, double eps, void* stream) {
+    return fgs_adam_step_multi_live(n_groups, grads, params, exp_avgs, exp_avg_sqs, n_elements, steps, lrs, beta1, beta2, eps, nullptr, nullptr, stream);
 }
 
 int32_t fgs_adam_step(const float* grad, float* param, float* exp_avg, float* exp_avg_sq, int64_t n_elements,

@@ -127,6 +127,9 @@ struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for th
     int n_views; BackwardView view[kMaxBatchViews];   // gradients are summed over the views in registers
     // fused mode (grad_* unused, one view): parameters and moments updated in place, order means, sh0, opacities, scales, rotations
     float* p[5]; float* m[5]; float* v[5]; AdamHyper h[5];
+    // single-kernel unfused form only: [ceil(n / 64)] bytes or nullptr -- 1 if any Gaussian of the block 64 b .. 64 b + 63 is visible, 0 if the
+    // block's gradients are all zero (they are still written); lets the optimizer skip the read of those zeros (launch_adam)
+    uint8_t* live_blocks;
 };
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s);
 
@@ -144,8 +147,11 @@ hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShR
 // single-view unfused K12 in one kernel: all six gradients written once (sh: grad_sh_rest + SH layout)
 hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s);
 
-struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block; };
-struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; int reverse; };
+struct AdamGroup { const float* grad; float* param; float* exp_avg; float* exp_avg_sq; int64_t n; AdamHyper h; uint32_t first_block;
+                   uint32_t row_len; };      // floats per Gaussian in this tensor (live_blocks only; 0: read every gradient)
+// live_blocks: [ceil(N / 64)] bytes or nullptr; 0 = the caller guarantees that the gradient rows of Gaussians 64 b .. 64 b + 63 are zero:
+// they are not read (one third of the Gaussians is invisible per view, 85 % of them in such blocks: tools/dead_blocks.py)
+struct AdamArgs { AdamGroup g[8]; int n_groups; uint32_t total_blocks; int reverse; const uint8_t* live_blocks; };
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);   // K13, all groups in one launch
 
 struct LossArgs {                       // fused L1 + DSSIM loss and its image gradient (loss.hip)

@@ -355,8 +355,9 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
 #pragma unroll
             for (int k = 0; k < kGroupWidth[grp]; ++k) outs[grp][(size_t)i * kGroupWidth[grp] + k] = grad[kGroupOffset[grp] + k];
     }
-    if (R == 0) return;
     const bool any_visible = wave_ballot(visible) != 0;
+    if (a.live_blocks != nullptr && lane == 0) a.live_blocks[first >> 6] = any_visible ? 1 : 0;   // first is a multiple of 64
+    if (R == 0) return;
     float* const slice = s_grad[wv];
     if (any_visible) {
         float B[15];
@@ -651,7 +652,15 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
         const int64_t base = block_base + ((int64_t)u * 256 + threadIdx.x) * 4;
         full[u] = base + 4 <= G.n;
         if (full[u]) {
-            g4[u] = load4<NT>(G.grad + base);
+            // the float4 covers the rows base / L .. (base + 3) / L of the [N, L] gradient; they lie in at most two consecutive blocks of 64
+            // Gaussians. Both dead: every element is a zero the backward pass wrote -- skip the read (the kernel is HBM-bound; the index
+            // arithmetic is free)
+            bool need = true;
+            if (a.live_blocks != nullptr && G.row_len != 0u) {
+                const uint32_t r0 = static_cast<uint32_t>(base) / G.row_len, r1 = static_cast<uint32_t>(base + 3) / G.row_len;
+                need = (a.live_blocks[r0 >> 6] | a.live_blocks[r1 >> 6]) != 0;
+            }
+            g4[u] = need ? load4<NT>(G.grad + base) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p4[u] = load4<NT>(G.param + base);
             m4[u] = load4<NT>(G.exp_avg + base);
             v4[u] = load4<NT>(G.exp_avg_sq + base);

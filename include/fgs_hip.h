@@ -87,6 +87,18 @@ int32_t fgs_backward(const float* grad_image, const float* image,
                      float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
                      float* densification_info, void* scratch,
                      int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, void* stream);
+/* fgs_backward plus one byte per block of 64 consecutive Gaussians: live_blocks[b] = 1 if any Gaussian 64 b .. 64 b + 63 was visible, 0 if
+ * all gradients of the block are zero (they are written all the same: the gradient tensors are dense and valid). [ceil(n_primitives / 64)]
+ * bytes, or NULL (= fgs_backward). One third of the Gaussians is invisible in a view and 85 % of them sit in such blocks (Morton order):
+ * fgs_adam_step_multi_live does not read the zeros back. */
+int32_t fgs_backward_live(const float* grad_image, const float* image,
+                          const float* means, const float* scales, const float* rotations, const float* opacities,
+                          const float* sh_coefficients_rest,
+                          void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                          float* grad_means, float* grad_scales, float* grad_rotations, float* grad_opacities,
+                          float* grad_sh_coefficients_0, float* grad_sh_coefficients_rest,
+                          float* densification_info, void* scratch,
+                          int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state, uint8_t* live_blocks, void* stream);
 
 /* fgs_forward WITHOUT its host synchronisation (the reference blocks three times per forward pass, forward.cu:100,102,234; fgs_forward
  * once): nothing is read back. The instance-stage buffers and launches are sized by `instance_capacity` -- the caller's bound, e.g. 1.25 x
@@ -124,6 +136,13 @@ int32_t fgs_adam_step(const float* grad, float* param, float* exp_avg, float* ex
 int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
                             float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
                             double beta1, double beta2, double eps, void* stream);
+/* The same with the caller's PROMISE that gradient rows of dead blocks are zero: live_blocks as written by fgs_backward_live for exactly these
+ * gradient tensors (device, [ceil(N / 64)] bytes), floats_per_gaussian[k] = row length of group k ([host]). Gradients of dead blocks are not
+ * read; parameters and moments of every Gaussian are updated as always (the result is bit-identical to fgs_adam_step_multi). NULL = no promise. */
+int32_t fgs_adam_step_multi_live(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
+                                 float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
+                                 double beta1, double beta2, double eps, const uint8_t* live_blocks, const int32_t* floats_per_gaussian,
+                                 void* stream);
 
 /* Fused backward + Adam (the reference's FasterGSFused branch, README.md:37; not in /root/reference -- defined here as
  * "equal to fgs_backward followed by FusedAdam.step() on all six groups"). Gradients are never

@@ -1,0 +1,163 @@
+"""Live-block hand-over (include/fgs_hip.h: fgs_backward_live / fgs_adam_step_multi_live; FasterGSCudaBackend/rasterization.py): the backward
+pass flags the blocks of 64 Gaussians without a visible one, the optimizer does not read their (zero) gradients back. Results must be
+bit-identical to the plain path, the flags must only ever be used for the very tensors they describe, and every other situation must fall
+back. CPU: the simulation build of the same sources; GPU: hardware."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from harness.scenes import make_s0
+
+ORDER = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')     # optimizer-group order (Model.py:238-245)
+LRS = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
+
+
+def _scene(dev, n=1000):
+    """S0 with two contiguous runs of Gaussians behind the camera: several blocks of 64 are entirely invisible, others partly."""
+    p, v = make_s0(seed=21, n=n)
+    p['means'][130:450, 2] = -30.0
+    p['means'][700:733, 2] = -30.0
+    return {k: t.to(dev).contiguous() for k, t in p.items()}, v
+
+
+def _backward(be, dp, RS, dev, live: bool):
+    res = be.forward(*[dp[k] for k in helpers.NAMES], RS)
+    gi = (torch.randn(3, RS.height, RS.width, generator=torch.Generator().manual_seed(3)) / (3 * RS.height * RS.width)).to(dev)
+    n = dp['means'].shape[0]
+    flags = torch.full(((n + 63) // 64,), 7, dtype=torch.uint8, device=dev) if live else None
+    grads = be.backward(None, gi, res.image, dp['means'], dp['scales'], dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'],
+                        res.buffers, RS, res.state, live_blocks=flags)
+    return res, dict(zip(helpers.NAMES, grads)), flags
+
+
+def _check_kernels(be, dev):
+    dp, view = _scene(dev)
+    _, RS = helpers.settings_pair(view, device=dev)
+    n = dp['means'].shape[0]
+    res, g_plain, _ = _backward(be, dp, RS, dev, False)
+    res, g_live, flags = _backward(be, dp, RS, dev, True)
+    dec = helpers.decode_forward(be, res, n, view.width, view.height)
+    vis = np.concatenate([dec['n_touched'] > 0, np.zeros((-n) % 64, bool)]).reshape(-1, 64).any(axis=1)
+    assert np.array_equal(flags.cpu().numpy(), vis.astype(np.uint8)) and 0 < vis.sum() < vis.size          # exactly "any visible", both kinds present
+    for k in helpers.NAMES:                                      # the gradients themselves: unchanged, dense (two passes: on hardware the float
+        if dev == 'cpu':                                         # atomics of the blend-backward kernel add in another order every time)
+            assert torch.equal(g_live[k], g_plain[k]), k
+        else:
+            assert helpers.rel_inf(g_live[k].cpu().numpy(), g_plain[k].cpu().numpy()) < 1e-5, k
+    dead_rows = torch.from_numpy(np.repeat(~vis, 64)[:n]).to(dev)
+    assert dead_rows.any() and all(bool((g_live[k][dead_rows] == 0).all()) for k in helpers.NAMES)
+
+    def adam(grads, live):
+        gen = torch.Generator().manual_seed(5)
+        P = {k: dp[k].clone() for k in ORDER}
+        M = {k: (torch.randn(dp[k].shape, generator=gen) * 1e-3).to(dev) for k in ORDER}
+        V = {k: (torch.rand(dp[k].shape, generator=gen) * 1e-6 + 1e-7).to(dev) for k in ORDER}
+        for step in (1, 2):
+            be.adam_step_multi([grads[k] for k in ORDER], [P[k] for k in ORDER], [M[k] for k in ORDER], [V[k] for k in ORDER], [step] * 6, LRS,
+                               0.9, 0.999, 1e-15, live_blocks=live)
+        return P, M, V
+    ref = adam(g_live, None)                                      # the SAME gradient tensors with and without the promise: the optimizer kernel has no
+    got = adam(g_live, flags)                                     # atomics, so this is bit-exact on hardware as well
+    poisoned = {k: g_live[k].clone() for k in ORDER}
+    for k in ORDER:
+        poisoned[k][dead_rows] = float('nan')                      # rows of dead blocks must not be READ: garbage there changes nothing
+    got_poisoned = adam(poisoned, flags)
+    for a, b, c in zip(ref, got, got_poisoned):
+        for k in ORDER:
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    # ragged N (last block partial) and a promise that does not fit the tensors
+    with pytest.raises(RuntimeError):
+        be.adam_step_multi([g_live[k] for k in ORDER], [dp[k].clone() for k in ORDER], [torch.zeros_like(dp[k]) for k in ORDER],
+                           [torch.zeros_like(dp[k]) for k in ORDER], [1] * 6, LRS, 0.9, 0.999, 1e-15, live_blocks=flags[:-1])
+
+
+def test_sim_live_block_kernels():
+    _check_kernels(helpers.sim_backend(), 'cpu')
+
+
+@pytest.mark.gpu
+def test_gpu_live_block_kernels(hip_backend):
+    _check_kernels(hip_backend, 'cuda')
+
+
+def _train(dev, be, steps, handover: bool, tamper=None):
+    """The reference's loop (Trainer.py:180-199) through the public operators: render -> loss -> backward -> FusedAdam.step -> zero_grad."""
+    import FasterGSCudaBackend as FGS
+    from FasterGSCudaBackend import rasterization as R
+    FGS.set_live_block_handover(handover)
+    dp, view = _scene(dev, n=700)
+    _, RS = helpers.settings_pair(view, device=dev)
+    P = {k: dp[k].clone().requires_grad_(True) for k in ORDER}
+    opt = FGS.FusedAdam([{'params': [P[k]], 'lr': lr, 'name': k} for k, lr in zip(ORDER, LRS)], lr=0.0, eps=1e-15)
+    for i, k in enumerate(ORDER):                       # non-zero moments (helpers.seeded_moments): two hardware runs differ in the last bits of the
+        m0, v0 = helpers.seeded_moments(dp[k].shape, 31 + i)     # gradients, and from zero moments Adam turns a sign change of a tiny gradient into 2 lr
+        opt.state[P[k]] = {'step': 0, 'exp_avg': m0.to(dev), 'exp_avg_sq': v0.to(dev)}
+    target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(9)).to(dev)
+    stolen = True
+    for _ in range(steps):
+        image = FGS.diff_rasterize(P['means'], P['scales'], P['rotations'], P['opacities'], P['sh_coefficients_0'], P['sh_coefficients_rest'],
+                                   torch.empty(0, device=dev), RS)
+        ((image - target) ** 2).mean().backward()
+        if handover:
+            stolen &= {P[k].grad.data_ptr() for k in ORDER} == {address for address, _ in R._LIVE['views']}
+        if tamper is not None:
+            tamper(P, FGS, RS, target)
+        opt.step()
+        opt.zero_grad()
+    FGS.set_live_block_handover(True)
+    return {k: P[k].detach().clone() for k in ORDER}, stolen
+
+
+def _check_handover(dev, be, monkeypatch):
+    import FasterGSCudaBackend as FGS
+    from FasterGSCudaBackend import adam as A, rasterization as R
+    if dev == 'cpu':                                   # the public operators refuse CPU tensors (no CPU implementation): point them at the simulation
+        monkeypatch.setattr(R, '_require_gpu', lambda t: None)
+        monkeypatch.setattr(R, 'default_backend', lambda: be)
+        monkeypatch.setattr(A, 'default_backend', lambda: be)
+    base = FGS.live_block_stats()
+    dense, _ = _train(dev, be, 3, False)
+    assert FGS.live_block_stats() == base
+    fast, stolen = _train(dev, be, 3, True)
+    assert stolen, 'autograd did not adopt the arena views as .grad'
+    s1 = FGS.live_block_stats()
+    assert s1['matched'] == base['matched'] + 3 and s1['missed'] == base['missed']
+    start, _ = _train(dev, be, 0, False)
+
+    def same(a, b, what):
+        for k in ORDER:
+            if dev == 'cpu':
+                assert torch.equal(a[k], b[k]), (what, k)                      # bit-identical training
+            else:                                                              # two hardware runs: the step taken agrees to the float bar
+                assert helpers.rel_inf((a[k] - start[k]).cpu().numpy(), (b[k] - start[k]).cpu().numpy()) < 1e-4, (what, k)
+    same(fast, dense, 'hand-over')
+
+    def scale_in_place(P, *_):                         # e.g. gradient clipping: the rows of dead blocks stay zero, but nothing proves it
+        for k in ORDER:
+            P[k].grad.mul_(0.5)
+
+    def replace(P, *_):
+        P['means'].grad = P['means'].grad.clone()
+
+    def second_backward(P, FGS_, RS, target):          # accumulation: .grad += gradients of another registered backward pass
+        image = FGS_.diff_rasterize(P['means'], P['scales'], P['rotations'], P['opacities'], P['sh_coefficients_0'], P['sh_coefficients_rest'],
+                                    torch.empty(0, device=dev), RS)
+        ((image - target) ** 2).mean().backward()
+
+    for tamper in (scale_in_place, replace, second_backward):
+        before = FGS.live_block_stats()
+        a, _ = _train(dev, be, 2, True, tamper)
+        after = FGS.live_block_stats()
+        assert after['matched'] == before['matched'] and after['missed'] == before['missed'] + 2, tamper.__name__
+        b, _ = _train(dev, be, 2, False, tamper)
+        same(a, b, tamper.__name__)
+
+
+def test_sim_handover_through_autograd(monkeypatch):
+    _check_handover('cpu', helpers.sim_backend(), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_gpu_handover_through_autograd(hip_backend, monkeypatch):
+    _check_handover('cuda', hip_backend, monkeypatch)
