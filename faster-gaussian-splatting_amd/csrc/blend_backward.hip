@@ -357,7 +357,15 @@ __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBa
 
 __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const BlendBackwardArgs a) {
     const unsigned lane = threadIdx.x;
-    __shared__ float4 s_pix[kTilePixels + 1];          // dL/dC rgb + packed (x | y << 8 | rel_last << 16); slot n_px = dead sentinel
+    // Per live pixel: (dL/dC rgb, rel_last as a float) in s_pix and the pixel centre (x, y) in s_xy; slot n_px = dead sentinel (rel 0).
+    // Until here x | y << 8 | rel << 16 were packed in the fourth float: three v_cvt_f32_ubyte (4.3 cycles each, tools/valu_rate.hip) and two
+    // adds of the tile origin per (pixel, Gaussian) step -- 14 % of the loop's instructions. The centre is x0 + small integer either way
+    // (exact), so dx, dy and every result are bit-identical. TWO dense arrays, not one 32-byte slot: lane l reads slot (step - l), and with a
+    // 32-byte lane stride the 16-byte read conflicts every 8 lanes and the 8-byte read four-fold -- SQ_LDS_BANK_CONFLICT 2.3 M -> 42.6 M
+    // cycles per launch at S2, LDS busy 34 M -> 86 M, which ate the whole gain (profiles/r02_pmc_k11_lds.txt). 6.7 KB of LDS per wave
+    // instead of 5.1: no effect on this kernel up to 8.2 KB (profiles/r02_k11_occupancy.txt).
+    __shared__ float4 s_pix[kTilePixels + 1];
+    __shared__ float2 s_xy[kTilePixels + 1];
     // T_ckpt, S - g_w: enters the pipeline at lane 0. Slots n_px .. n_px + 63 are zero: lane 0 reads slot (step + 1) without a clamp
     // until the last step, and lanes 1..63 read slot n_px (zero) in every step, which makes "shift up by one lane, inject at lane 0"
     // ONE DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
@@ -373,6 +381,8 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         const unsigned bucket = (tile == 0 ? 0u : a.bucket_offsets[tile - 1]) + tb;
         const unsigned first_gaussian = tb * kBucket;
 
+        const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f;
+        const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
         // ---- stage the live pixels, compacted (kb:349-380) ----
         unsigned n_px = 0;
         {
@@ -394,14 +404,14 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
                 if (live) {
                     const unsigned slot = n_px + lanes_below(m);
                     const unsigned rel = min(last - first_gaussian, static_cast<unsigned>(kBucket));
-                    const unsigned packed = (p & (kTileW - 1)) | ((p / kTileW) << 8) | (rel << 16);
-                    s_pix[slot] = make_float4(g[c].x, g[c].y, g[c].z, __uint_as_float(packed));
+                    s_pix[slot] = make_float4(g[c].x, g[c].y, g[c].z, static_cast<float>(rel));
+                    s_xy[slot] = make_float2(x0 + static_cast<float>(p & (kTileW - 1)), y0 + static_cast<float>(p / kTileW));
                     const float S = (cst[c].x - k[c].x) * g[c].x + (cst[c].y - k[c].y) * g[c].y + (cst[c].z - k[c].z) * g[c].z;   // kb:371-374
                     s_inj[slot] = make_float2(k[c].w, S - g[c].w);
                 }
                 n_px += static_cast<unsigned>(__popcll(m));
             }
-            if (lane0) s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));   // rel_last 0: never contributes
+            if (lane0) { s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[n_px] = make_float2(0.0f, 0.0f); }   // rel_last 0: never contributes
             s_inj[n_px + lane] = make_float2(0.0f, 0.0f);
         }
 
@@ -426,8 +436,6 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
             footprint = (tx1 - tx0) * (ty1 - ty0);
             hot_slot_word = __float_as_uint(r2.w);
         }
-        const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f;
-        const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
         wave_lds_fence();
 
         float a_c0 = 0.0f, a_c1 = 0.0f, a_c2 = 0.0f;                 // sum w g_c               (kb:426-427 without the clamp gate)
@@ -440,17 +448,25 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         // several times an FMA on this chip (tools/valu_rate.hip), and the empty-mask branch of the `if` is the wave-uniform skip.
         unsigned inj_slot = lane0 ? 0u : n_px;                        // lane 0: slot of the step; other lanes: the zero slot
         const unsigned inj_step = lane0 ? 1u : 0u;
-        int pix_idx = -static_cast<int>(lane);                        // pixel slot of this lane in the step whose reads are issued next
+        // pixel slot of this lane in the step whose reads are issued next; negative (as unsigned: huge) or past the list -> the sentinel, with
+        // ONE unsigned min
+        unsigned pix_idx = static_cast<unsigned>(-static_cast<int>(lane));
+        struct PixRead { float4 g; float2 xy; };
         auto read_inj = [&]() { const float2 v = s_inj[inj_slot]; inj_slot += inj_step; return v; };
-        auto read_pix = [&]() { const float4 v = s_pix[min(static_cast<unsigned>(pix_idx), n_px)]; ++pix_idx; return v; };   // negative / past the list -> sentinel
-        auto step = [&](const float2 inj, const float4 px) {
+        auto read_pix = [&]() {
+            const unsigned at = min(pix_idx, n_px);
+            ++pix_idx;
+            PixRead r;
+            r.g = s_pix[at];
+            r.xy = s_xy[at];
+            return r;
+        };
+        auto step = [&](const float2 inj, const PixRead pr) {
             sT = wave_shift_up1_zero(sT) + inj.x;                                               // kb:383-410
             sS = wave_shift_up1_zero(sS) + inj.y;
-            const unsigned packed = __float_as_uint(px.w);
-            const float pxf = x0 + static_cast<float>(packed & 0xffu);
-            const float pyf = y0 + static_cast<float>((packed >> 8) & 0xffu);
-            const float rel = static_cast<float>((packed >> 16) & 0xffu);
-            const float dx = mx - pxf, dy = my - pyf;
+            const float4 px = pr.g;
+            const float rel = px.w;
+            const float dx = mx - pr.xy.x, dy = my - pr.xy.y;
             const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
             const float alpha = op * __expf(fminf(power, 0.0f));
             if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
@@ -472,7 +488,7 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
         // two steps per trip with the read registers ping-ponged (no copies); an odd step count runs one extra step in which every
         // lane sees the sentinel
         float2 inj_a = read_inj(), inj_b;
-        float4 pix_a = read_pix(), pix_b;
+        PixRead pix_a = read_pix(), pix_b;
         const int n_steps = (a.ablate & 2) ? 0 : static_cast<int>(n_px) + kWave - 1;
         for (int i = 0; i < n_steps; i += 2) {
             inj_b = read_inj(); pix_b = read_pix();
