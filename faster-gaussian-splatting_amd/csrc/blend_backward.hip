@@ -355,8 +355,12 @@ __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBa
     if (tid == 0) *a.live_count = base;
 }
 
-__global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const BlendBackwardArgs a) {
-    const unsigned lane = threadIdx.x;
+#ifndef FGS_K11_WAVES_PER_GROUP
+#define FGS_K11_WAVES_PER_GROUP 1
+#endif
+constexpr unsigned kCompactWaves = FGS_K11_WAVES_PER_GROUP;      // independent waves (one work item each, no barrier) per workgroup
+__global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_kernel(const BlendBackwardArgs a) {
+    const unsigned lane = threadIdx.x & 63u, wave_in_group = threadIdx.x >> 6;
     // Per live pixel: (dL/dC rgb, rel_last as a float) in s_pix and the pixel centre (x, y) in s_xy; slot n_px = dead sentinel (rel 0).
     // Until here x | y << 8 | rel << 16 were packed in the fourth float: three v_cvt_f32_ubyte (4.3 cycles each, tools/valu_rate.hip) and two
     // adds of the tile origin per (pixel, Gaussian) step -- 14 % of the loop's instructions. The centre is x0 + small integer either way
@@ -364,16 +368,19 @@ __global__ void __launch_bounds__(kWave) blend_backward_compact_kernel(const Ble
     // 32-byte lane stride the 16-byte read conflicts every 8 lanes and the 8-byte read four-fold -- SQ_LDS_BANK_CONFLICT 2.3 M -> 42.6 M
     // cycles per launch at S2, LDS busy 34 M -> 86 M, which ate the whole gain (profiles/r02_pmc_k11_lds.txt). 6.7 KB of LDS per wave
     // instead of 5.1: no effect on this kernel up to 8.2 KB (profiles/r02_k11_occupancy.txt).
-    __shared__ float4 s_pix[kTilePixels + 1];
-    __shared__ float2 s_xy[kTilePixels + 1];
+    __shared__ float4 s_pix_all[kCompactWaves][kTilePixels + 1];
+    __shared__ float2 s_xy_all[kCompactWaves][kTilePixels + 1];
+    float4* const s_pix = s_pix_all[wave_in_group];
+    float2* const s_xy = s_xy_all[wave_in_group];
     // T_ckpt, S - g_w: enters the pipeline at lane 0. Slots n_px .. n_px + 63 are zero: lane 0 reads slot (step + 1) without a clamp
     // until the last step, and lanes 1..63 read slot n_px (zero) in every step, which makes "shift up by one lane, inject at lane 0"
     // ONE DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
-    __shared__ float2 s_inj[kTilePixels + kWave];
+    __shared__ float2 s_inj_all[kCompactWaves][kTilePixels + kWave];
+    float2* const s_inj = s_inj_all[wave_in_group];
     const unsigned n_live = *a.live_count;
     const float lane_f = static_cast<float>(lane);
     const bool lane0 = lane == 0;
-    for (unsigned item = blockIdx.x; item < n_live; item += gridDim.x) {            // wave-uniform
+    for (unsigned item = blockIdx.x * kCompactWaves + wave_in_group; item < n_live; item += gridDim.x * kCompactWaves) {            // wave-uniform
         const uint2 work = a.work_list[item];
         const unsigned tile = work.x, tb = work.y;
         const uint2 range = a.ranges[tile];
@@ -555,7 +562,7 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
         // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
         // for the launch of a quarter of a million empty ones
         const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;
-        hipLaunchKernelGGL(blend_backward_compact_kernel, dim3(blocks), dim3(kWave), 0, s, a);
+        hipLaunchKernelGGL(blend_backward_compact_kernel, dim3((blocks + kCompactWaves - 1) / kCompactWaves), dim3(kWave * kCompactWaves), 0, s, a);
         hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
         return hipGetLastError();
     }
