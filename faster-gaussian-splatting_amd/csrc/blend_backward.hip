@@ -355,6 +355,13 @@ __global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBa
     if (tid == 0) *a.live_count = base;
 }
 
+// Debug-only timeline (tools/k11_timeline.sh builds a separate library with -DFGS_K11_TIMELINE; the product build has none of it): per work
+// item its start / end timestamp, the number of pipeline steps and the hardware id of the wave -- concurrency over time, per-item durations,
+// load per XCD / CU.
+#ifdef FGS_K11_TIMELINE
+constexpr unsigned kK11TimelineItems = 1u << 18;
+__device__ unsigned long long g_k11_timeline[kK11TimelineItems * 4];
+#endif
 #ifndef FGS_K11_WAVES_PER_GROUP
 #define FGS_K11_WAVES_PER_GROUP 1
 #endif
@@ -381,6 +388,10 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
     const float lane_f = static_cast<float>(lane);
     const bool lane0 = lane == 0;
     for (unsigned item = blockIdx.x * kCompactWaves + wave_in_group; item < n_live; item += gridDim.x * kCompactWaves) {            // wave-uniform
+#ifdef FGS_K11_TIMELINE
+        const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();       // 100 MHz, the same clock on every CU (the cycle counter is not)
+        const unsigned long long c_start_ = __builtin_readcyclecounter();
+#endif
         const uint2 work = a.work_list[item];
         const unsigned tile = work.x, tb = work.y;
         const uint2 range = a.ranges[tile];
@@ -524,9 +535,33 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             unsafeAtomicAdd(dst + 7 * plane, a_c1 * f1);
             unsafeAtomicAdd(dst + 8 * plane, a_c2 * f2);
         }
+#ifdef FGS_K11_TIMELINE
+        if (lane == 0 && item < kK11TimelineItems) {
+            g_k11_timeline[item * 4u] = t_start_;
+            g_k11_timeline[item * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+            g_k11_timeline[item * 4u + 2u] = static_cast<unsigned long long>(n_steps) | ((__builtin_readcyclecounter() - c_start_) << 16);
+            g_k11_timeline[item * 4u + 3u] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))) << 32)   // HW_ID, all 32 bits
+                                            | static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));            // XCC_ID (gfx94x+)
+        }
+#endif
         wave_lds_fence();                                  // the next item restages the LDS slices
     }
 }
+
+#ifdef FGS_K11_TIMELINE
+}  // namespace fgs
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_timeline(unsigned long long* out, unsigned n_items, int reset) {
+    if (n_items > fgs::kK11TimelineItems) n_items = fgs::kK11TimelineItems;
+    if (out != nullptr && hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k11_timeline), sizeof(unsigned long long) * 4 * n_items) != hipSuccess) return -1;
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k11_timeline)) != hipSuccess
+            || hipMemset(dev, 0, sizeof(unsigned long long) * 4 * fgs::kK11TimelineItems) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace fgs {
+#endif
 
 // after K11: the hot Gaussians' replicas are summed and added to their entries of the nine planes (one thread per (slot, plane))
 __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendBackwardArgs a) {
