@@ -258,16 +258,43 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
     if (first >= a.n) return;                                         // wave-uniform
     const uint32_t i = first + lane;
     const bool in_range = i < a.n;
-    const uint32_t ic = in_range ? i : a.n - 1u;                      // out-of-range lanes shadow the last Gaussian (loads only)
+    float* const slice = s_grad[wv];                                  // the wave's LDS slice: phase A staging now, the SH-rest gradient block later
+    const uint32_t n_here = a.n - first < kWave ? a.n - first : kWave;   // Gaussians of this wave
+    const bool whole = n_here == kWave;
 
+    // ---- phase A: the 14 small floats of parameters and both moments. A wave's 64 x w floats of a group are contiguous: they come in (and
+    // go out) as ONE coalesced 16-byte access per lane and pass through LDS, instead of w scalar accesses per lane at a stride of 4 w bytes --
+    // 42 loads + 42 stores per lane before, more memory instructions than phase B issues for three times the data. ----
     float st_p[14], st_m[14], st_v[14];
+    if (whole) {
 #pragma unroll
-    for (int grp = 0; grp < 5; ++grp)
+        for (int arr = 0; arr < 3; ++arr)
 #pragma unroll
-        for (int k = 0; k < kGroupWidth[grp]; ++k) {
-            const size_t e = (size_t)ic * kGroupWidth[grp] + k;
-            st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
-        }
+            for (int grp = 0; grp < 5; ++grp) {
+                constexpr int kLanes[5] = {48, 48, 16, 48, 64};       // 64 w / 4 float4 pieces
+                const float* const src = (arr == 0 ? a.p[grp] : arr == 1 ? a.m[grp] : a.v[grp]) + (size_t)first * kGroupWidth[grp];
+                if (lane < static_cast<uint32_t>(kLanes[grp]))
+                    *reinterpret_cast<float4*>(slice + (arr * 14 + kGroupOffset[grp]) * kWave + 4u * lane) = load_float4_nt(src + 4u * lane);
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                const int o = kGroupOffset[grp] + k;
+                const uint32_t at = kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k;
+                st_p[o] = slice[at]; st_m[o] = slice[14 * kWave + at]; st_v[o] = slice[28 * kWave + at];
+            }
+    } else {                                                         // the last, partial wave: scalar accesses
+        const uint32_t ic = in_range ? i : a.n - 1u;                  // out-of-range lanes shadow the last Gaussian (loads only)
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                const size_t e = (size_t)ic * kGroupWidth[grp] + k;
+                st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
+            }
+    }
     float grad[14], dir[3] = {0.0f, 0.0f, 0.0f}, gcol[3] = {0.0f, 0.0f, 0.0f};
     bool visible = false;
     if (in_range) {
@@ -276,17 +303,34 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
             for (int k = 0; k < kGroupWidth[grp]; ++k) {
-                const size_t e = (size_t)i * kGroupWidth[grp] + k;
                 const int o = kGroupOffset[grp] + k;
                 adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
-                a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
+                if (whole) {
+                    const uint32_t at = kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k;
+                    slice[at] = st_p[o]; slice[14 * kWave + at] = st_m[o]; slice[28 * kWave + at] = st_v[o];
+                } else {
+                    const size_t e = (size_t)i * kGroupWidth[grp] + k;
+                    a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
+                }
             }
+    }
+    if (whole) {
+        wave_lds_fence();
+#pragma unroll
+        for (int arr = 0; arr < 3; ++arr)
+#pragma unroll
+            for (int grp = 0; grp < 5; ++grp) {
+                constexpr int kLanes[5] = {48, 48, 16, 48, 64};
+                float* const dst = (arr == 0 ? a.p[grp] : arr == 1 ? a.m[grp] : a.v[grp]) + (size_t)first * kGroupWidth[grp];
+                if (lane < static_cast<uint32_t>(kLanes[grp]))
+                    store_float4_nt(dst + 4u * lane, *reinterpret_cast<const float4*>(slice + (arr * 14 + kGroupOffset[grp]) * kWave + 4u * lane));
+            }
+        wave_lds_fence();                                             // the slice is about to be rewritten with the SH-rest gradient block
     }
     if (R == 0) return;
 
     // ---- the wave's SH-rest gradient block -> LDS (skipped when no lane of the wave is visible: the block is zero) ----
     const bool any_visible = wave_ballot(visible) != 0;
-    float* const slice = s_grad[wv];
     if (any_visible) {
         float B[15];
 #pragma unroll
