@@ -130,6 +130,7 @@ struct PreprocessBackwardArgs {         // K12, optionally fused with K13 for th
     // single-kernel unfused form only: [ceil(n / 64)] bytes or nullptr -- 1 if any Gaussian of the block 64 b .. 64 b + 63 is visible, 0 if the
     // block's gradients are all zero (they are still written); lets the optimizer skip the read of those zeros (launch_adam)
     uint8_t* live_blocks;
+    int vector_ok;                        // set by the launchers: every per-Gaussian tensor of the call is 16-byte aligned (coalesced 16-byte phase A)
 };
 hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardArgs& a, hipStream_t s);
 

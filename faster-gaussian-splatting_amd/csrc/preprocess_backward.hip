@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
     const bool in_range = i < a.n;
     float* const slice = s_grad[wv];                                  // the wave's LDS slice: phase A staging now, the SH-rest gradient block later
     const uint32_t n_here = a.n - first < kWave ? a.n - first : kWave;   // Gaussians of this wave
-    const bool whole = n_here == kWave;
+    const bool whole = a.vector_ok != 0 && n_here == kWave;           // 16-byte accesses need 16-byte aligned tensors (checked at launch)
 
     // ---- phase A: the 14 small floats of parameters and both moments. A wave's 64 x w floats of a group are contiguous: they come in (and
     // go out) as ONE coalesced 16-byte access per lane and pass through LDS, instead of w scalar accesses per lane at a stride of 4 w bytes --
@@ -393,16 +393,19 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
     bool visible = false;
     if (in_range) {
         visible = gaussian_backward<false, false, true>(a, i, unused, grad, dir, gcol);
+        // scalar stores at a stride of 4 w bytes: the write path combines them. Staging the wave's 64 x w block in LDS and storing it as one
+        // coalesced 16-byte access per lane -- what pays in the fused kernel, where the same floats are also LOADED three times -- measured
+        // 0.261 vs 0.252 ms here (profiles/r02_ab_k12_coalesced_stores.txt)
         float* const outs[5] = {a.grad_means, a.grad_sh0, a.grad_opacities, a.grad_scales, a.grad_rotations};
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
             for (int k = 0; k < kGroupWidth[grp]; ++k) outs[grp][(size_t)i * kGroupWidth[grp] + k] = grad[kGroupOffset[grp] + k];
     }
+    float* const slice = s_grad[wv];
     const bool any_visible = wave_ballot(visible) != 0;
     if (a.live_blocks != nullptr && lane == 0) a.live_blocks[first >> 6] = any_visible ? 1 : 0;   // first is a multiple of 64
     if (R == 0) return;
-    float* const slice = s_grad[wv];
     if (any_visible) {
         float B[15];
 #pragma unroll
@@ -426,18 +429,24 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
     }
 }
 
-hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a_in, const ShRestArgs& sh, hipStream_t s) {
+    if (a_in.n == 0) return hipSuccess;
     if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
+    const PreprocessBackwardArgs& a = a_in;
     const dim3 grid((a.n + 255u) / 256u), block(256);
     if (sh.total_sh_rest == 15) hipLaunchKernelGGL(backward_gradients_kernel<15>, grid, block, 0, s, a, sh);
     else hipLaunchKernelGGL(backward_gradients_kernel<0>, grid, block, 0, s, a, sh);
     return hipGetLastError();
 }
 
-hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a, const ShRestArgs& sh, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
+hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a_in, const ShRestArgs& sh, hipStream_t s) {
+    if (a_in.n == 0) return hipSuccess;
     if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
+    PreprocessBackwardArgs a = a_in;
+    a.vector_ok = 1;
+    for (int g = 0; g < 5; ++g) a.vector_ok = a.vector_ok && aligned16(a.p[g]) && aligned16(a.m[g]) && aligned16(a.v[g]);
     const dim3 grid((a.n + 255u) / 256u), block(256);
     if (sh.total_sh_rest == 15) hipLaunchKernelGGL(fused_backward_adam_kernel<15>, grid, block, 0, s, a, sh);
     else hipLaunchKernelGGL(fused_backward_adam_kernel<0>, grid, block, 0, s, a, sh);

@@ -48,6 +48,19 @@ def _check_kernels(be, dev):
             assert torch.equal(g_live[k], g_plain[k]), k
         else:
             assert helpers.rel_inf(g_live[k].cpu().numpy(), g_plain[k].cpu().numpy()) < 1e-5, k
+    # gradient tensors that are NOT 16-byte aligned (views one float into a buffer): the coalesced 16-byte stores of the gradient kernel must
+    # give way to the scalar path, same values
+    shapes = [tuple(g_plain[k].shape) for k in helpers.NAMES]
+    odd = [torch.empty(int(np.prod(sh)) + 1, dtype=torch.float32, device=dev)[1:].view(sh) for sh in shapes]
+    assert all(t.data_ptr() % 16 == 4 for t in odd if t.numel())
+    gi = (torch.randn(3, RS.height, RS.width, generator=torch.Generator().manual_seed(3)) / (3 * RS.height * RS.width)).to(dev)
+    g_odd = be.backward(None, gi, res.image, dp['means'], dp['scales'], dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'],
+                        res.buffers, RS, res.state, out=tuple(odd))
+    for k, t in zip(helpers.NAMES, g_odd):
+        if dev == 'cpu':
+            assert torch.equal(t, g_live[k]), k
+        else:
+            assert helpers.rel_inf(t.cpu().numpy(), g_live[k].cpu().numpy()) < 1e-5, k
     dead_rows = torch.from_numpy(np.repeat(~vis, 64)[:n]).to(dev)
     assert dead_rows.any() and all(bool((g_live[k][dead_rows] == 0).all()) for k in helpers.NAMES)
 
