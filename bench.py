@@ -381,6 +381,9 @@ def main():
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_,
                    'forward': 'one host read per pass (fgs_forward)' if not args.async_forward else 'no host synchronisation (fgs_forward_async, capacity = 1.25 x largest instances/Gaussian seen)',
                    'async_forward_overflows': FGS.async_forward_stats()['overflows'],
+                   # dense gradients; FusedAdam.step does not read back the zeros of 64-Gaussian blocks without a visible Gaussian when it can prove
+                   # the gradient tensors untouched (bit-identical): how often that held / did not in this process
+                   'live_block_handover': FGS.live_block_stats(),
                    'world': world, 'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
                    'device': f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
                    'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0},
