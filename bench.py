@@ -209,7 +209,9 @@ def main():
             lay = be.blob_layout(1, n, v.width, v.height, res.state[1], res.state[2])
             n_tiles = ((v.width + 15) // 16) * ((v.height + 11) // 12)
             b_real = int(be.view(res.buffers[1], lay, 'bucket_offsets', torch.int32)[n_tiles - 1].item())
-            stats[id(v)] = {'V': res.state[0], 'I': res.state[1], 'B': b_real}
+            # what the blend kernels actually walk: every tile list ends at its last processed Gaussian (early termination, kf:424,477)
+            mx = be.view(res.buffers[1], lay, 'max_n_processed', torch.int32)[:n_tiles].long()
+            stats[id(v)] = {'V': res.state[0], 'I': res.state[1], 'B': b_real, 'Ip': int(mx.sum().item()), 'Bp': int(((mx + 63) // 64).sum().item())}
             del res
         del pert
 
@@ -316,6 +318,7 @@ def main():
     used = [my_views[(args.warmup + PROFILE_STEPS + i) % len(my_views)] for i in range(args.steps)]
     mean = lambda key: float(np.mean([stats[id(v)][key] for v in used]))
     V, I, B = mean('V'), mean('I'), mean('B')
+    Ip, Bp = mean('Ip'), mean('Bp')      # instances / 64-Gaussian buckets in front of each tile's last processed Gaussian
     W_, H_ = views[0].width, views[0].height
     P_, T_ = W_ * H_, ((W_ + 15) // 16) * ((H_ + 11) // 12)
     K_ = g.active_sh_bases
@@ -329,9 +332,14 @@ def main():
         'tile_sort': 26.0 * I,
         'extract_ranges': 2.0 * I + 8.0 * T_,
         'bucket_scan': 12.0 * T_,
-        'blend_forward': 48.0 * I + 8.0 * T_ + 20.0 * P_ + 3076.0 * B,
+        # K10 / K11 stop at each tile's last processed Gaussian: SURVEY.md 8d's 48 I + 3076 B (and 76 I + 3076 B) count every instance and every
+        # bucket, which at S2 is 10x what the kernels touch (2.1 of 21 buckets per tile are processed) and put the forward blend at 9.7 TB/s
+        # "algorithmic". Counted here: the instances / buckets in front of that point. K10: record + index per walked instance, a checkpoint
+        # per walked bucket, image + final T + count per pixel. K11: per live bucket 64 records + indices, the 192 staged pixel records
+        # (32 B) and checkpoints (16 B); 9 accumulator floats per visible Gaussian at least once.
+        'blend_forward': 52.0 * Ip + 8.0 * T_ + 20.0 * P_ + 3072.0 * Bp,
         'stage_pixels': 32.0 * P_,
-        'blend_backward': 76.0 * I + 3076.0 * B,
+        'blend_backward': (52.0 * 64 + 192 * 32.0 + 192 * 16.0) * Bp + 36.0 * V,
         # K12 as this build splits it (SURVEY.md 8d total 4 N + (24 K + 128) V, plus the 236 N of gradients that are written exactly once
         # instead of the reference's zero-fill + accumulate): the geometry kernel reads the tile count, the Gaussian (44 B), its 9
         # accumulators and its sh_rest coefficients (view-direction term), writes the 14 small gradients and the view direction;
@@ -348,12 +356,15 @@ def main():
                  'blend_forward': 'blend_kernel<true>', 'create_instances': 'create_instances_kernel<u16>',
                  'tile_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u16, 7> x 2 passes', 'sh_rest_backward': 'sh_rest_gradient_kernel<15, false>',
                  'preprocess_backward': 'backward_gradients_kernel<15>',
-                 'depth_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u32, 8> x 4 passes', 'fused_backward_adam': 'fused_backward_adam_kernel<15>'}
+                 'depth_sort': 'sortimpl::radix_{histogram,row_scan,scatter}_kernel<u32, 9> x 3 passes of key - bits(near)', 'fused_backward_adam': 'fused_backward_adam_kernel<15>'}
     per_launch = {k: v_[0] / n_prof for k, v_ in prof.items() if v_[1] > 0}   # ms per step, from the untimed stage-profile pass
     dom = dom_stage
     dom_s = prof_dom[dom][0] / max(prof_dom[dom][1], 1) * 1e-3            # average launch duration over the TIMED steps (HIP events on the launch stream)
     achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
-    bytes_iter = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
+    # bytes of one iteration: the stages that ran, with THIS build's counts (walked instances / buckets for the blend kernels); SURVEY.md 8d's
+    # closed form for the reference's data flow (every instance and bucket) is reported beside it
+    bytes_iter = float(sum(stage_bytes[k] for k, v_ in prof.items() if v_[1] > 0 and k in stage_bytes))
+    bytes_iter_survey = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
     # live counters (rank 0, one GPU): HBM traffic of the dominant kernel; VALU instruction counts for the secondary ceiling
     pmc = live_pmc(args) if (rank == 0 and world == 1 and not args.no_pmc) else {'error': 'not collected (--no-pmc or N > 1)'}
     traffic, traffic_note = None, pmc.get('error', 'no counters for this kernel')
@@ -378,7 +389,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload + '; full training iteration fwd+loss+bwd+Adam (BASELINE.json configs[2]), loss 0.8*L1+0.2*DSSIM, '
                                'densification_info updated', 'parallelism': f'view-parallel dp{world} ({args.dp_mode})' if vp is not None else 'single GPU',
-                   'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'active_sh_bases': K_,
+                   'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'instances_walked': Ip, 'buckets64_walked': Bp, 'active_sh_bases': K_,
                    'forward': 'one host read per pass (fgs_forward)' if not args.async_forward else 'no host synchronisation (fgs_forward_async, capacity = 1.25 x largest instances/Gaussian seen)',
                    'async_forward_overflows': FGS.async_forward_stats()['overflows'],
                    # dense gradients; FusedAdam.step does not read back the zeros of 64-Gaussian blocks without a visible Gaussian when it can prove
@@ -392,7 +403,7 @@ def main():
                      'algorithmic_bytes_per_launch': stage_bytes[dom],
                      'note': 'dominant = longest kernel of the timed region (HIP events on the launch stream)',
                      'secondary': secondary,
-                     'iteration_algorithmic_GB': bytes_iter / 1e9,
+                     'iteration_algorithmic_GB': bytes_iter / 1e9, 'iteration_survey_formula_GB': bytes_iter_survey / 1e9,
                      'iteration_frac_of_hbm_peak': bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         'stage_ms_per_step': {k: v[0] / n_prof for k, v in prof.items() if v[1] > 0},
         'stage_profile_steps': n_prof,
