@@ -1039,6 +1039,8 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
+        case 10: if (value < 0 || (value > 64 && value != 255)) return fail(FGS_ERR_INVALID_ARGUMENT, "row group must be 0 (bands), 255 (bands, bottom first) or 1..64");
+                 fgs::g_tile_row_group = value; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

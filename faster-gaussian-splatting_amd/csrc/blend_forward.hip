@@ -11,16 +11,64 @@
 //    traffic -- 1 KiB contiguous per wave; T_final / n_processed are tile-major so backward reads them coalesced.
 //  * workgroup -> tile mapping keeps contiguous image bands on one XCD (workgroup b runs on XCD b % 8), so the
 //    records gathered by neighbouring tiles stay in that XCD's 4 MiB L2.
+#include <atomic>
+
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 
 namespace fgs {
 
+// Which tile does workgroup `block` blend? The hardware deals workgroups to the 8 XCDs round-robin (XCD = block % 8), and a Gaussian's
+// records are re-read by every tile it overlaps -- from the XCD's own L2 if the neighbouring tiles run there. Round 1 gave every XCD one
+// contiguous band of tile rows. A per-tile timeline (tools/k10_timeline.sh, profiles/r02_k10_timeline_before.txt) showed what that costs: the
+// top band of the image is nearly empty (XCD 0 had 30 ms of summed tile time against 44-47 ms for the others at S2, 47 against 210-220 ms on the
+// layered scene, and idled for a third / two thirds of the kernel), and the heaviest rows -- the bottom of the image, nearest to the camera --
+// came LAST in every band. Alternative mapping (row_group >= 1): groups of `row_group` consecutive tile rows are dealt to the XCDs in turn over
+// the whole image and every XCD walks its rows from the bottom of the image upwards (heaviest first). Measured (tools/ab_tile_rows.py,
+// profiles/r02_ab_tile_rows.txt; training / inference blend): S2 bands 0.163 / 0.157 ms, g = 1 0.177 / 0.171, g = 2 0.189 / 0.182 -- at two
+// blended buckets per tile the kernel lives on the L2 locality of vertical neighbours; layered scene (11 buckets per tile) bands 0.725 / 0.700,
+// g = 1 0.663 / 0.646, g = 2 0.654 / 0.633 -- there balance wins 10 %. Bands walked bottom-up (255): no difference. Which of the two a scene
+// wants depends on how deep its tiles blend, which the host does not know at launch: the DEFAULT stays the bands (the benchmark workload),
+// fgs_debug_set_option(10, g) selects the other. Returns n_tiles for padding workgroups.
+constexpr unsigned kBandsBottomFirst = 255u;     // row_group value: the round-1 bands, each walked from its last tile to its first
+std::atomic<int> g_tile_row_group{0};
+__device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, const unsigned grid_w, const unsigned n_tiles, const unsigned row_group) {
+    if (row_group == 0u || row_group == kBandsBottomFirst) {                                // one contiguous band per XCD, top-down or bottom-up
+        const unsigned per_xcd = (n_tiles + kXcds - 1) / kXcds;
+        const unsigned idx = block / kXcds;
+        const unsigned tile = (block % kXcds) * per_xcd + (row_group == 0u ? idx : per_xcd - 1u - idx);
+        return tile < n_tiles ? tile : n_tiles;
+    }
+    const unsigned grid_h = n_tiles / grid_w;
+    const unsigned xcd = block % kXcds, j = block / kXcds;
+    const unsigned k = j / grid_w, col = j - k * grid_w;                                   // k-th row this XCD walks
+    const unsigned cycles = (grid_h + kXcds * row_group - 1) / (kXcds * row_group);        // groups per XCD
+    if (k >= cycles * row_group) return n_tiles;
+    const unsigned kk = cycles * row_group - 1u - k;                                       // bottom of the image first
+    const unsigned row = (kk / row_group) * (kXcds * row_group) + xcd * row_group + kk % row_group;
+    return row < grid_h ? row * grid_w + col : n_tiles;
+}
+static unsigned blend_grid(const BlendArgs& a) {
+    if (a.row_group == 0u || a.row_group == kBandsBottomFirst) return ((a.n_tiles + kXcds - 1) / kXcds) * kXcds;
+    const unsigned grid_h = a.n_tiles / a.grid_w;
+    const unsigned cycles = (grid_h + kXcds * a.row_group - 1) / (kXcds * a.row_group);
+    return kXcds * cycles * a.row_group * a.grid_w;
+}
+
+// Debug-only timeline (tools/k10_timeline.sh builds a separate library with -DFGS_K10_TIMELINE; the product build has none of it): per tile
+// its start / end on the chip-wide 100 MHz counter, the length of its list and how far it was walked.
+#ifdef FGS_K10_TIMELINE
+constexpr unsigned kK10TimelineTiles = 1u << 17;
+__device__ unsigned long long g_k10_timeline[kK10TimelineTiles * 4];
+#endif
+
 template <bool TRAINING>
 __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
-    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
-    const unsigned tile = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group);
     if (tile >= a.n_tiles) return;
+#ifdef FGS_K10_TIMELINE
+    const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
     const unsigned lx = half * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
@@ -133,7 +181,30 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
         __syncthreads();
         if (tid == 0) a.max_n_processed[tile] = max(s_max[0], max(s_max[1], s_max[2]));   // kf:493-497
     }
+#ifdef FGS_K10_TIMELINE
+    if (tid == 0 && tile < kK10TimelineTiles) {
+        g_k10_timeline[tile * 4u] = t_start_;
+        g_k10_timeline[tile * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+        g_k10_timeline[tile * 4u + 2u] = (static_cast<unsigned long long>(n_total) << 32) | blockIdx.x;
+        g_k10_timeline[tile * 4u + 3u] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));   // XCC_ID
+    }
+#endif
 }
+
+#ifdef FGS_K10_TIMELINE
+}  // namespace fgs
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k10_timeline(unsigned long long* out, unsigned n_tiles, int reset) {
+    if (n_tiles > fgs::kK10TimelineTiles) n_tiles = fgs::kK10TimelineTiles;
+    if (out != nullptr && hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k10_timeline), sizeof(unsigned long long) * 4 * n_tiles) != hipSuccess) return -1;
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k10_timeline)) != hipSuccess
+            || hipMemset(dev, 0, sizeof(unsigned long long) * 4 * fgs::kK10TimelineTiles) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace fgs {
+#endif
 
 // Speedy-Splat pruning scores (kernels_pruning_scores.cuh:348-505): the tile list is blended twice -- pass 1
 // for the final colour / transmittance, pass 2 re-walks it with dL/dC = 1 and adds (opacity * dL/dalpha)^2 of every blended
@@ -141,8 +212,7 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
 // one atomicAdd per (pixel, Gaussian) pair (kp:490); here the 64 lanes of a wave evaluate the SAME Gaussian, so their
 // scores are summed with 6 DPP adds and leave through one atomic per (Gaussian, wave).
 __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const BlendArgs a) {
-    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
-    const unsigned tile = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds;
+    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group);
     if (tile >= a.n_tiles) return;
     const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
@@ -220,15 +290,17 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
 #undef FGS_PIXEL_DONE
 }
 
-hipError_t launch_pruning_scores(const BlendArgs& a, hipStream_t s) {
-    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
-    hipLaunchKernelGGL(pruning_scores_kernel, dim3(per_xcd * kXcds), dim3(kBlendBlock), 0, s, a);
+hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
+    BlendArgs a = a_in;
+    a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    hipLaunchKernelGGL(pruning_scores_kernel, dim3(blend_grid(a)), dim3(kBlendBlock), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_blend(bool training, const BlendArgs& a, hipStream_t s) {
-    const unsigned per_xcd = (a.n_tiles + kXcds - 1) / kXcds;
-    const dim3 grid(per_xcd * kXcds), block(kBlendBlock);
+hipError_t launch_blend(bool training, const BlendArgs& a_in, hipStream_t s) {
+    BlendArgs a = a_in;
+    a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    const dim3 grid(blend_grid(a)), block(kBlendBlock);
     if (training) hipLaunchKernelGGL(blend_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(blend_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();

@@ -62,6 +62,7 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
 // The A/B switches behind fgs_debug_set_option are process-wide; atomics make concurrent set / launch well defined (a launch sees the
 // old or the new value, never a torn one).
+extern std::atomic<int> g_tile_row_group;            // blend_forward.hip: tile rows per XCD group of the tile -> workgroup mapping (0: round-1 bands)
 extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
 extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
@@ -85,6 +86,7 @@ struct BlendArgs {                      // K10 / inference blend
     float* final_T; uint32_t* n_processed; uint32_t* max_n_processed;     // tile-major [T][192]
     uint32_t* bucket_tile; float4* ckpt;                                   // [B], [B][192]
     uint32_t width, height, grid_w, n_tiles;
+    uint32_t row_group;                      // tile -> workgroup mapping (blend_forward.hip: tile_of_workgroup); set by the launchers
     int to_chw, clamp_output;
     float* scores;                        // pruning-score mode: accumulated per primitive [N]
 };

@@ -318,7 +318,9 @@ int32_t fgs_debug_set_backward_variant(int32_t variant);
  * backward+Adam as one kernel (1, default) or round 1's two (0), 5 = K1 tile counting: 0 flattened (default) or n sequential
  * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop),
  * 8 = Adam walks the arenas from the end (1, default) or the start (0), 9 = depth sort: bit 0 key - bits(near) in 9-bit passes, bit 1
- * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower).
+ * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower), 10 = forward-blend tile -> workgroup
+ * mapping: 0 (default) = one contiguous band of tile rows per XCD, g = 1..64 = groups of g rows dealt to the XCDs in turn, bottom of the image
+ * first (10 % faster on deeply layered scenes, 9-16 % slower at two blended buckets per tile), 255 = the bands walked bottom-up.
  * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
