@@ -324,11 +324,11 @@ def test_empty_scene(hip_backend):
     assert torch.allclose(res.image.cpu(), torch.tensor([0.1, 0.2, 0.3])[:, None, None].expand(3, 128, 128))
 
 
-def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0):
+def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, K=16, aa=False, max_masked=1e-3):
     """Forward + backward (+ FusedAdam-style steps with the same gradients) against the oracle; entries on a hard threshold are
     counted and excluded (helpers.check_flip_aware), everything else is held to 1e-4 -- image, six gradients, densification_info,
     and after `adam_steps` Adam steps the parameters and both moments."""
-    S, RS = helpers.settings_pair(view, device=DEV)
+    S, RS = helpers.settings_pair(view, K, aa, device=DEV)
     dp = _to(params)
     n = dp['means'].shape[0]
     res = hip_backend.forward(*[dp[k] for k in helpers.NAMES], RS)
@@ -346,7 +346,7 @@ def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_
     got['densification_info'] = dens.cpu().numpy().T
     ref = {k: g[k] for k in helpers.GRAD_KEYS}
     ref['densification_info'] = dens_o.T
-    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, label=label)
+    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, max_masked=max_masked, label=label)
     # integer intermediates away from the thresholds: the pixel's last contributor
     npr = helpers.tiles_to_image(dec['n_processed_tiles'], view.width, view.height)
     if dec['I'] == f['I']:
