@@ -45,3 +45,12 @@ def test_random_configuration_against_oracle(hip_backend, oracle, seed):
     # threshold: the oracle's risk masks are allowed 1 % here (0.1 % in the fixed-size tests); outside them the bar is the same 1e-4
     budget = max(1e-2, 6.0 / min(n, pixels))
     _flip_aware_forward_backward(hip_backend, oracle, p, view, label, adam_steps=2, K=K, aa=aa, max_masked=budget)
+
+
+@pytest.mark.parametrize('seed', range(0, 32, 3))
+def test_random_configuration_fused_backward_adam(hip_backend, oracle, seed):
+    """The same configurations through fgs_backward_adam_fused (two steps): parameters and both moments against oracle backward -> oracle Adam."""
+    from test_gpu_fused import _run
+    p, view, K, aa, label = _configuration(seed)
+    n = p['means'].shape[0]
+    _run(hip_backend, oracle, p, view, K=K, aa=aa, steps=2, label=label, masked_budget=max(2e-2, 6.0 / n))
