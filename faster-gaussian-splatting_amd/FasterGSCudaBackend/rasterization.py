@@ -40,7 +40,8 @@ _ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0}
 # the view tensors themselves: autograd adopts an incoming gradient as `.grad` only if nobody else references that tensor (it looks at the
 # reference count of the view, not of its storage) and clones it otherwise -- 708 MB per iteration at 3 M Gaussians. A match needs the same address, the same shape and an unchanged version counter (views share the arena's: any
 # in-place edit -- accumulation of a second backward, clipping, scaling -- shows). Anything else takes the ordinary path; results are
-# bit-identical either way.
+# bit-identical either way. Writes the version counter does not see (`.grad.data.add_(...)`, raw pointers) are the kernel's business: it reads
+# one sentinel float per dead block and tensor and, unless that is +-0, the block's gradients after all (csrc/preprocess_backward.hip).
 _LIVE = {'enabled': True, 'arena': None, 'version': -1, 'flags': None, 'views': (), 'matched': 0, 'missed': 0}
 _ALIGN_FLOATS = 64          # every gradient starts on a 256-byte boundary (16-byte loads in the optimizer kernel)
 

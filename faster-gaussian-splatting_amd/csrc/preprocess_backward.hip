@@ -711,7 +711,17 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
             bool need = true;
             if (a.live_blocks != nullptr && G.row_len != 0u) {
                 const uint32_t r0 = static_cast<uint32_t>(base) / G.row_len, r1 = static_cast<uint32_t>(base + 3) / G.row_len;
-                need = (a.live_blocks[r0 >> 6] | a.live_blocks[r1 >> 6]) != 0;
+                const uint32_t b0 = r0 >> 6, b1 = r1 >> 6;
+                need = (a.live_blocks[b0] | a.live_blocks[b1]) != 0;
+                if (!need) {
+                    // Belt and braces: the promise rests on the caller's proof that nobody touched the gradients since the backward pass,
+                    // and a write that bypasses the framework's bookkeeping (`.grad.data.add_(...)`, a raw-pointer kernel) cannot be seen by
+                    // it. One SENTINEL float per dead block and tensor (the first element of the block: the same cached 4 bytes for every
+                    // float4 of the block) is read anyway; anything but +-0 there -- a whole-tensor edit such as hand-written weight decay,
+                    // NaN / Inf -- and the block's gradients are read after all.
+                    const float s0 = G.grad[(size_t)b0 * 64u * G.row_len], s1 = G.grad[(size_t)b1 * 64u * G.row_len];
+                    need = !(s0 == 0.0f) || !(s1 == 0.0f);
+                }
             }
             g4[u] = need ? load4<NT>(G.grad + base) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             p4[u] = load4<NT>(G.param + base);

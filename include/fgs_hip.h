@@ -138,7 +138,9 @@ int32_t fgs_adam_step_multi(int32_t n_groups, const float* const* grads, float* 
                             double beta1, double beta2, double eps, void* stream);
 /* The same with the caller's PROMISE that gradient rows of dead blocks are zero: live_blocks as written by fgs_backward_live for exactly these
  * gradient tensors (device, [ceil(N / 64)] bytes), floats_per_gaussian[k] = row length of group k ([host]). Gradients of dead blocks are not
- * read; parameters and moments of every Gaussian are updated as always (the result is bit-identical to fgs_adam_step_multi). NULL = no promise. */
+ * read -- except one sentinel float per dead block and tensor (the block's first element): if it is not +-0 the block is read after all, so a
+ * whole-tensor edit behind the caller's back does not go unnoticed; parameters and moments of every Gaussian are updated as always (the result
+ * is bit-identical to fgs_adam_step_multi). NULL = no promise. */
 int32_t fgs_adam_step_multi_live(int32_t n_groups, const float* const* grads, float* const* params, float* const* exp_avgs,
                                  float* const* exp_avg_sqs, const int64_t* n_elements, const int32_t* steps, const double* lrs,
                                  double beta1, double beta2, double eps, const uint8_t* live_blocks, const int32_t* floats_per_gaussian,

@@ -75,13 +75,26 @@ def _check_kernels(be, dev):
         return P, M, V
     ref = adam(g_live, None)                                      # the SAME gradient tensors with and without the promise: the optimizer kernel has no
     got = adam(g_live, flags)                                     # atomics, so this is bit-exact on hardware as well
+    # rows of dead blocks are not READ -- except one sentinel float per dead block and tensor (the block's first element): garbage everywhere
+    # else in them changes nothing
+    first_rows = torch.from_numpy((np.arange(n) % 64 == 0)).to(dev)
     poisoned = {k: g_live[k].clone() for k in ORDER}
     for k in ORDER:
-        poisoned[k][dead_rows] = float('nan')                      # rows of dead blocks must not be READ: garbage there changes nothing
+        flat = poisoned[k].reshape(n, -1)
+        flat[dead_rows & ~first_rows] = float('nan')
+        flat[dead_rows & first_rows, 1:] = float('nan')            # everything but element 0 of the block's first row
     got_poisoned = adam(poisoned, flags)
     for a, b, c in zip(ref, got, got_poisoned):
         for k in ORDER:
             assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    # a write that no framework bookkeeping sees (p.grad.data.add_(...): hand-written weight decay) makes the sentinels non-zero: those
+    # blocks are read after all, and the result is the one of the plain path on the edited gradients
+    edited = {k: g_live[k].clone() for k in ORDER}
+    for k in ORDER:
+        edited[k].data.add_(0.01 * dp[k])
+    for a, b in zip(adam(edited, None), adam(edited, flags)):
+        for k in ORDER:
+            assert torch.equal(a[k], b[k]), ('edited behind the version counter', k)
     # ragged N (last block partial) and a promise that does not fit the tensors
     with pytest.raises(RuntimeError):
         be.adam_step_multi([g_live[k] for k in ORDER], [dp[k].clone() for k in ORDER], [torch.zeros_like(dp[k]) for k in ORDER],
@@ -156,6 +169,10 @@ def _check_handover(dev, be, monkeypatch):
     def replace(P, *_):
         P['means'].grad = P['means'].grad.clone()
 
+    def decay_behind_the_counter(P, *_):               # old-style weight decay on .data: the version counter does not move, the flags still MATCH,
+        for k in ORDER:                                # and the optimizer kernel's sentinel check has to notice
+            P[k].grad.data.add_(1e-3 * P[k].data)
+
     def second_backward(P, FGS_, RS, target):          # accumulation: .grad += gradients of another registered backward pass
         image = FGS_.diff_rasterize(P['means'], P['scales'], P['rotations'], P['opacities'], P['sh_coefficients_0'], P['sh_coefficients_rest'],
                                     torch.empty(0, device=dev), RS)
@@ -168,6 +185,11 @@ def _check_handover(dev, be, monkeypatch):
         assert after['matched'] == before['matched'] and after['missed'] == before['missed'] + 1, tamper.__name__
         b, _ = _train(dev, be, 1, False, tamper)
         same(a, b, tamper.__name__)
+    before = FGS.live_block_stats()
+    a, _ = _train(dev, be, 1, True, decay_behind_the_counter)
+    assert FGS.live_block_stats()['matched'] == before['matched'] + 1          # the registry cannot see it ...
+    b, _ = _train(dev, be, 1, False, decay_behind_the_counter)
+    same(a, b, 'decay_behind_the_counter')                                       # ... the kernel does
 
 
 def test_sim_handover_through_autograd(monkeypatch):
