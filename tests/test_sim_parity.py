@@ -116,7 +116,7 @@ def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
     p['opacities'] -= 2.5
     p['means'][:50, 2] = -10.0                      # invisible primitives: their records stay poisoned
     be = helpers.poisoned(sim_backend)
-    for variant in (0, 1, 2, 3):
+    for variant in (2, 3):                          # the default and round 1's main form (0 / 1: on hardware, test_gpu_parity.py)
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             _run(be, oracle, p, v)
