@@ -115,11 +115,54 @@ def _log_tolerance(kind: str, value: float, a: np.ndarray, ref: np.ndarray, **ex
                  f'frac_above_1e-4_of_max={float((err > 1e-4 * scale).mean()):.3e} n={ref.size} {extra}\n')
 
 
+def log_note(kind: str, value, **extra) -> None:
+    """FGS_TOL_LOG: a counted event that is not a tensor comparison (e.g. how often the integer-mismatch budget of a forward check is used)."""
+    path = os.environ.get('FGS_TOL_LOG')
+    if not path:
+        return
+    import inspect
+    site = next((f for f in inspect.stack()[1:] if os.path.basename(f.filename).startswith('test_')), inspect.stack()[1])
+    with open(path, 'a') as fh:
+        fh.write(f'{os.path.basename(site.filename)}:{site.lineno} {site.function} {kind}={value} {extra}\n')
+
+
 def rel_inf(a: np.ndarray, ref: np.ndarray) -> float:
     """max |a-ref| normalised by max |ref| -- the tolerance metric of the float parity tests."""
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     value = float(np.abs(a - ref).max() / (np.abs(ref).max() + 1e-30)) if ref.size else 0.0
     _log_tolerance('rel_inf', value, a, ref)
+    return value
+
+
+ELEM_RTOL = 1e-4            # north_star: "within 1e-4 relative float" -- per ELEMENT, not per tensor
+ELEM_FRACTION = 1e-4        # entries allowed beyond it (fp32 sums that cancel to << their terms carry the error of the terms)
+
+
+def elementwise_fraction(a: np.ndarray, ref: np.ndarray, keep: np.ndarray | None = None, rtol: float = ELEM_RTOL, kind: str = 'elementwise',
+                         free_rows: int = 0) -> float:
+    """Second criterion beside rel_inf (missing #3): the fraction of entries with |a - ref| > rtol * |ref| + atol, where
+    atol = rtol * MEDIAN |ref| over the non-zero reference entries -- not the tensor's maximum, so an entry a thousand times smaller
+    than the largest one is still held to its own magnitude (down to the median's scale; below that fp32 accumulation order decides).
+    `keep`: boolean mask over the first axis (rows outside the oracle's threshold-risk masks). `free_rows`: rows (Gaussians) that may
+    fail without being counted -- for the small scenes compared WITHOUT a risk mask, where one alpha-threshold flip moves one or two
+    Gaussians' gradients and 1e-4 of a few hundred entries is less than one entry. Logged like rel_inf under FGS_TOL_LOG."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    if keep is not None:
+        a, ref = a[keep], ref[keep]
+    if not ref.size:
+        return 0.0
+    mag = np.abs(ref)
+    nz = mag[mag > 0]
+    atol = rtol * float(np.median(nz)) if nz.size else 0.0
+    excess = np.abs(a - ref) / (rtol * mag + atol + 1e-300)
+    bad = excess > 1.0
+    n_bad = int(bad.sum())
+    if free_rows and n_bad:
+        rows = bad.reshape(bad.shape[0], -1).any(axis=1)
+        if int(rows.sum()) <= free_rows:
+            n_bad = 0
+    value = n_bad / ref.size
+    _log_tolerance(kind, value, a, ref, rtol=rtol, atol=atol, worst_excess=float(excess.max()), bad_entries=int(bad.sum()))
     return value
 
 
@@ -245,9 +288,11 @@ def seed_trainer_moments(trainer, names, seed: int = 11) -> None:
         trainer.exp_avg_sq[o:o + n].view(shape).copy_(v0)
 
 
-def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label=''):
+def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label='', elem_fraction=ELEM_FRACTION):
     """image [3,H,W]; grads / g_ref: {name: array with the Gaussian index first}. Entries outside the masks must agree to `tol`
-    (max-abs error relative to the tensor's max-abs value); the masked fraction is bounded; masked entries stay within `loose`."""
+    (max-abs error relative to the tensor's max-abs value) AND element by element (elementwise_fraction: fewer than `elem_fraction` of the
+    entries beyond 1e-4 of their own magnitude + 1e-4 of the tensor's median magnitude); the masked fraction is bounded; masked entries
+    stay within `loose`."""
     report = {}
     pm = masks['pixel']
     frac_p, frac_g = float(pm.mean()), float(masks['prim'].mean()) if masks['prim'].size else 0.0
@@ -258,7 +303,10 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         scale = max(1.0, float(np.abs(f_image).max()))
         report['image'] = float(err[~pm].max() / scale) if (~pm).any() else 0.0
         report['image_masked'] = float(err[pm].max() / scale) if pm.any() else 0.0
+        report['image_elem'] = elementwise_fraction(np.moveaxis(np.asarray(image), 0, -1)[~pm], np.moveaxis(np.asarray(f_image), 0, -1)[~pm],
+                                                    kind='elementwise_image')
         assert report['image'] < tol, (label, 'image', report)
+        assert report['image_elem'] < elem_fraction, (label, 'image (element-wise 1e-4)', report)
         assert report['image_masked'] < loose, (label, 'image (masked pixels)', report)
     keep = ~masks['prim']
     for k, a in grads.items():
@@ -266,6 +314,8 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         a = np.asarray(a).reshape(ref.shape)
         report[k] = masked_rel_inf(a, ref, keep)
         report[k + '_masked'] = masked_rel_inf(a, ref, masks['prim'])
+        report[k + '_elem'] = elementwise_fraction(a, ref, keep, kind='elementwise_' + k)
         assert report[k] < tol, (label, k, report)
         assert report[k + '_masked'] < loose, (label, k + ' (masked Gaussians)', report)
+        assert report[k + '_elem'] < elem_fraction, (label, k + ' (element-wise 1e-4)', report)
     return report

@@ -64,6 +64,12 @@ def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, l
         report[k] = (helpers.masked_rel_inf(moved, moved_ref, keep), helpers.masked_rel_inf(dM[k].cpu().numpy(), oM[k], keep),
                      helpers.masked_rel_inf(dV[k].cpu().numpy(), oV[k], keep))
         assert max(report[k]) < tol, (label, k, report)
+        # element by element (helpers.elementwise_fraction): the step each parameter took and both moments
+        elem = (helpers.elementwise_fraction(moved, moved_ref, keep, kind='elementwise_step_' + k),
+                helpers.elementwise_fraction(dM[k].cpu().numpy(), oM[k], keep, kind='elementwise_exp_avg_' + k),
+                helpers.elementwise_fraction(dV[k].cpu().numpy(), oV[k], keep, kind='elementwise_exp_avg_sq_' + k))
+        report[k + '_elem'] = elem
+        assert max(elem) < max(helpers.ELEM_FRACTION, 2.0 * oP[k][0].size / oP[k].size), (label, k, 'element-wise 1e-4', report)
         assert helpers.rel_inf(dM[k].cpu().numpy(), oM[k]) < 5e-2, (label, k, 'masked')
     report['dens'] = helpers.masked_rel_inf(dens_dev.cpu().numpy().T, dens_o.T, keep)
     assert report['dens'] < tol, (label, report)
@@ -113,3 +119,10 @@ def test_fused_full_size_1m_1080p(hip_backend, oracle):
     params = make_garden_like(1_000_003)
     v = orbit_views(8)[2]
     _run(hip_backend, oracle, params, v, steps=2, label='1M')
+
+
+def test_fused_full_size_s2_3m_1080p(hip_backend, oracle):
+    """BASELINE.json configs[3] at the size bench.py times it (`fused_train_iters_per_sec`: S2, 3 M Gaussians, 1920x1080; VERDICT r2
+    missing #2): two fused backward+Adam steps against oracle backward -> oracle Adam on all 59 x 3 M floats and both moments."""
+    params = make_garden_like(3_000_000)
+    _run(hip_backend, oracle, params, orbit_views(8)[0], steps=2, label='S2 fused')

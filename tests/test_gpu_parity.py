@@ -31,10 +31,15 @@ def _to(params, dev=None):
     return {k: v.to(dev or DEV).contiguous() for k, v in params.items()}
 
 
-def _grads_close(grads, g, tol=1e-4):
+def _grads_close(grads, g, tol=1e-4, free_rows=2):
+    """Max-norm 1e-4 per tensor AND the element-wise 1e-4 bar (helpers.elementwise_fraction). These scenes are compared without the
+    oracle's threshold-risk mask, so up to `free_rows` Gaussians (one alpha-test flip) may exceed the element-wise bar."""
     for k, t in zip(helpers.GRAD_KEYS, grads):
-        e = helpers.rel_inf(t.detach().cpu().numpy().reshape(g[k].shape), g[k])
+        a = t.detach().cpu().numpy().reshape(g[k].shape)
+        e = helpers.rel_inf(a, g[k])
         assert e < tol, (k, e)
+        frac = helpers.elementwise_fraction(a, g[k], kind='elementwise_' + k, free_rows=free_rows)
+        assert frac < helpers.ELEM_FRACTION, (k, 'element-wise 1e-4', frac)
 
 
 def test_wave_primitives_selftest(hip_backend):
@@ -59,6 +64,7 @@ def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None):
     vis = f['n_touched'] > 0
     bad = int((dec['n_touched'] != f['n_touched']).sum()) + int((dec['screen_bounds'][vis] != f['screen_bounds'][vis]).any(axis=1).sum())
     budget = 0 if bad == 0 else max(1, n // 1000)
+    helpers.log_note('int_mismatch_primitives', bad, n=n)          # how often the budget branch below is taken at all
     pixel_mask = helpers.flip_masks(oracle, f, S, dec)['pixel']      # pixels within an ULP-scale margin of the alpha / T thresholds
     if bad == 0:
         helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy(), pixel_mask=pixel_mask)
@@ -385,6 +391,23 @@ def test_full_size_against_oracle(hip_backend, oracle, scene, n, view):
     image, six gradients, densification_info to 1e-4 outside the counted threshold mask, then 3 Adam steps on all 59 N floats."""
     params = make_garden_like(n)
     _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[view], scene, adam_steps=3)
+
+
+def test_layered_scene_full_size_against_oracle(hip_backend, oracle):
+    """bench.py's `layered_scene` at the size it is timed (missing #2): S2 with every opacity logit lowered by 3 -- ~11 of the
+    ~13 buckets of a tile are blended instead of 2 of 21, the regime of a trained scene, where K10 / K11 are more than half of the step.
+    Forward, backward, densification_info and 3 Adam steps against the oracle (kernels_backward.cuh:286-471, adam.cu:10-34). The
+    threshold-risk masks grow with the number of (pixel, Gaussian) pairs per pixel: bounded at 3e-3 here (1e-3 for S2)."""
+    params = make_garden_like(3_000_000)
+    params['opacities'] = params['opacities'] - 3.0
+    _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[3], 'S2 layered', adam_steps=3, max_masked=3e-3)
+
+
+def test_s3_six_million_against_oracle(hip_backend, oracle):
+    """S3 (6 M Gaussians, the top of north_star's '~1-6 M' range; profiles/r0x_s3_bench_line.json times it): forward + backward +
+    densification_info against the oracle, flip-aware, max-norm and element-wise 1e-4."""
+    params = make_garden_like(6_000_000)
+    _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[5], 'S3', adam_steps=0)
 
 
 def test_full_size_properties(hip_backend):
