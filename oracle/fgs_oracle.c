@@ -42,6 +42,30 @@
 
 typedef unsigned int uint;
 
+/*
+ * ORC_F64 (libfgs_oracle64.so, built from this same file): every `float` below becomes `double` -- the same formulas in the same order
+ * with the reference's fp32 CONSTANTS (literals keep their f suffix: 0.3f, 1.0f / 255.0f, the SH constants are the float values)
+ * evaluated in double precision. It is the tests' estimate of the TRUE value of every float the fp32 pipelines produce, used to
+ * separate implementation error from the rounding noise any fp32 evaluation of an ill-conditioned sum carries (tests/helpers.py:
+ * three-way element-wise check; measured: the fp32 restatement itself misses an element-wise 1e-4 bar against this build on
+ * 1-4 % of the gradient entries of a deep scene). Only the continuous half is meaningful in this build: the discrete structure
+ * (visible set, bounds, instance lists, ranges) is taken from the fp32 run (orc_preprocess_follow), bit-punning helpers
+ * (depth keys) are not called.
+ */
+#ifdef ORC_F64
+#define float double
+#define expf exp
+#define logf log
+#define sqrtf sqrt
+#define floorf floor
+#define ceilf ceil
+#define fmaxf fmax
+#define fminf fmin
+#define fabsf fabs
+#define fmaf fma
+#define copysignf copysign
+#endif
+
 /* ---- cfg:8-60 --------------------------------------------------------------------------------------- */
 #define DILATION 0.3f
 #define DILATION_PROPER_AA 0.1f
@@ -344,6 +368,35 @@ int orc_preprocess(int N, const float* means, const float* scales, const float* 
     }
     *n_instances_out = I;
     return V;
+}
+
+/*
+ * TEST SUPPORT (ORC_F64 build): the float outputs of K1 for exactly the primitives another run (the fp32 one) found visible --
+ * no cull is re-decided here, so both precisions work on the same visible set, bounds and instance lists.
+ */
+void orc_preprocess_follow(int N, const float* means, const float* scales, const float* rotations, const float* opacities,
+                           const float* sh0, const float* sh_rest, const orc_settings* S, const uint* n_touched,
+                           float* mean2d, float* conic_opacity, float* color) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; i++) {
+        if (n_touched[i] == 0) continue;
+        const float* m = means + 3 * (size_t)i;
+        float opacity = sigmoidf(opacities[i]);
+        proj_t P;
+        project(m, scales + 3 * (size_t)i, rotations + 4 * (size_t)i, S, &P);
+        float cov_x = P.a_raw, cov_y = P.b, cov_z = P.c_raw;
+        const float det_raw = cov_x * cov_z - cov_y * cov_y;
+        const float ks = S->proper_aa ? DILATION_PROPER_AA : DILATION;
+        cov_x += ks; cov_z += ks;
+        const float det = cov_x * cov_z - cov_y * cov_y;
+        if (S->proper_aa) opacity *= sqrtf(fmaxf(det_raw / det, 0.0f));
+        mean2d[2 * (size_t)i] = P.x * S->fx + S->cx; mean2d[2 * (size_t)i + 1] = P.y * S->fy + S->cy;
+        conic_opacity[4 * (size_t)i] = cov_z / det; conic_opacity[4 * (size_t)i + 1] = -cov_y / det;
+        conic_opacity[4 * (size_t)i + 2] = cov_x / det; conic_opacity[4 * (size_t)i + 3] = opacity;
+        float col[3];
+        sh_to_color(sh0, sh_rest, m, S->cam_pos, (uint)i, (uint)S->active_sh_bases, (uint)S->total_sh_rest, col);
+        for (int c = 0; c < 3; c++) color[3 * (size_t)i + c] = col[c];
+    }
 }
 
 /* stable LSD radix sort of (key,value) pairs on bits [0,end_bit) -- semantics of cub::DeviceRadixSort::SortPairs

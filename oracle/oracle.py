@@ -68,9 +68,10 @@ class Settings:
 
 def build(force: bool = False) -> Path:
     so = _HERE / 'libfgs_oracle.so'
+    so64 = _HERE / 'libfgs_oracle64.so'
     src = _HERE / 'fgs_oracle.c'
-    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(['make', '-C', str(_HERE), '-B', 'libfgs_oracle.so'], check=True, capture_output=True)
+    if force or not so.exists() or not so64.exists() or min(so.stat().st_mtime, so64.stat().st_mtime) < src.stat().st_mtime:
+        subprocess.run(['make', '-C', str(_HERE), '-B', 'all'], check=True, capture_output=True)
     return so
 
 
@@ -211,6 +212,73 @@ def backward(fwd: dict, settings: Settings, grad_image, densification_info: np.n
     L.orc_preprocess_backward(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh_rest), C.byref(S),
                               _p(fwd['n_touched']), _p(grad_mean2d), _p(grad_conic), _p(g['means']), _p(g['scales']),
                               _p(g['rotations']), _p(g['opacities']), _p(g['sh0']), _p(g['sh_rest']), dens)
+    return g
+
+
+# ---- double-precision evaluation of the same formulas (libfgs_oracle64.so = fgs_oracle.c built with -DORC_F64) ---------------------
+_LIB64 = None
+
+
+class _Settings64(C.Structure):
+    _fields_ = [
+        ('w2c', C.c_double * 12), ('cam_pos', C.c_double * 3), ('bg', C.c_double * 3),
+        ('active_sh_bases', C.c_int), ('total_sh_rest', C.c_int), ('width', C.c_int), ('height', C.c_int),
+        ('fx', C.c_double), ('fy', C.c_double), ('cx', C.c_double), ('cy', C.c_double),
+        ('near_plane', C.c_double), ('far_plane', C.c_double), ('proper_aa', C.c_int),
+    ]
+
+
+def lib64() -> C.CDLL:
+    global _LIB64
+    if _LIB64 is None:
+        build()
+        _LIB64 = C.CDLL(str(_HERE / 'libfgs_oracle64.so'))
+    return _LIB64
+
+
+def forward_backward_f64(fwd: dict, settings: Settings, grad_image) -> dict:
+    """The image and the six gradients of `fwd`'s scene evaluated in DOUBLE precision: the same formulas in the same order
+    (fgs_oracle.c built with -DORC_F64), on the fp32 inputs and the fp32 constants, over the discrete structure of the fp32 run `fwd`
+    (visible set, bounds, instance lists, ranges, buckets). The per-pair decisions (alpha >= 1/255, T < 1e-4) are re-taken in double;
+    the few that land on the other side are the pairs oracle.threshold_risk names. Returns {'image', 'final_T', 'means', 'scales',
+    'rotations', 'opacities', 'sh0', 'sh_rest'} as float64 arrays -- the tests' estimate of the true values."""
+    L = lib64()
+    f64 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+    means, scales, rotations, opacities, sh0, sh_rest = (f64(a) for a in fwd['_inputs'])
+    N, B, T, bs = fwd['N'], fwd['B'], fwd['T'], fwd['bucket_size']
+    total_rest = sh_rest.shape[1] if sh_rest.ndim == 3 else 0
+    S32 = fwd['_S']
+    S = _Settings64()
+    for name, _ in _Settings64._fields_:
+        v = getattr(S32, name)
+        if hasattr(v, '__len__'):
+            getattr(S, name)[:] = [float(x) for x in v]
+        else:
+            setattr(S, name, v)
+    S.total_sh_rest = int(total_rest)
+    W, H = settings.width, settings.height
+    P = W * H
+    mean2d, conic, color = np.zeros((N, 2)), np.zeros((N, 4)), np.zeros((N, 3))
+    L.orc_preprocess_follow(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh0), _p(sh_rest), C.byref(S),
+                            _p(fwd['n_touched']), _p(mean2d), _p(conic), _p(color))
+    inst_prims = np.ascontiguousarray(fwd['inst_prims']) if fwd['I'] > 0 else np.zeros(1, np.uint32)
+    image, final_T = np.zeros((3, H, W)), np.ones(P)
+    n_processed, max_n_processed = np.zeros(P, np.uint32), np.zeros(T, np.uint32)
+    bti = np.zeros(max(B, 1), np.uint32)
+    ckpt = np.zeros((max(B, 1), BLOCK_BLEND, 4))
+    L.orc_blend_forward(0, 1, 0, bs, _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims), _p(fwd['screen_bounds']), _p(mean2d),
+                        _p(conic), _p(color), C.byref(S), _p(image), _p(final_T), _p(n_processed), _p(max_n_processed), _p(bti), _p(ckpt))
+    gi = f64(grad_image).reshape(3, H, W)
+    g = {'means': np.zeros((N, 3)), 'scales': np.zeros((N, 3)), 'rotations': np.zeros((N, 4)), 'opacities': np.zeros((N, 1)),
+         'sh0': np.zeros((N, 1, 3)), 'sh_rest': np.zeros(sh_rest.shape)}
+    grad_mean2d, grad_conic = np.zeros((N, 2)), np.zeros((3, N))
+    L.orc_blend_backward(N, B, bs, _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims), _p(mean2d), _p(conic), _p(color),
+                         C.byref(S), _p(gi), _p(image), _p(final_T), _p(max_n_processed), _p(n_processed), _p(bti), _p(ckpt),
+                         _p(grad_mean2d), _p(grad_conic), _p(g['opacities']), _p(g['sh0']))
+    L.orc_preprocess_backward(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh_rest), C.byref(S), _p(fwd['n_touched']),
+                              _p(grad_mean2d), _p(grad_conic), _p(g['means']), _p(g['scales']), _p(g['rotations']), _p(g['opacities']),
+                              _p(g['sh0']), _p(g['sh_rest']), None)
+    g.update(image=image, final_T=final_T, n_processed=n_processed)
     return g
 
 

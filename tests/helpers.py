@@ -166,6 +166,28 @@ def elementwise_fraction(a: np.ndarray, ref: np.ndarray, keep: np.ndarray | None
     return value
 
 
+THREE_WAY_FACTOR = 1.25     # the HIP path may miss the element-wise bar (against the fp64 evaluation) at most this often relative to the fp32 oracle; measured on MI355X: 0.98-1.03 at every site (profiles/r03_gpu_tolerance_slack.txt)
+
+
+def elementwise_three_way(a, ref32, truth, keep: np.ndarray | None = None, kind: str = '', free_rows: int = 0):
+    """The element-wise 1e-4 bar cannot be held by ANY fp32 evaluation of these gradients against another one: they are sums of
+    hundreds of signed per-pixel terms, and an entry that cancels to 1 % of its terms carries 100x the relative rounding error.
+    Measured (tests/test_oracle.py::test_fp32_oracle_misses_elementwise_bar_by_conditioning): on a deep 1500-Gaussian scene the fp32
+    ORACLE misses the bar against the same formulas evaluated in double (oracle.forward_backward_f64, itself within 6e-8 of the
+    independent fp64 autograd model) on 1.3-3.9 % of the entries of four of the six gradient tensors. So the bar is applied three-way:
+    both fp32 results are measured against the fp64 values, and the HIP path may miss it at most THREE_WAY_FACTOR times as often as the
+    reference-arithmetic oracle does, plus the ELEM_FRACTION budget. Returns (fraction HIP vs fp64, fraction oracle32 vs fp64); the
+    direct HIP-vs-oracle32 fraction (the two fp32 noises added) is logged beside them."""
+    fh = elementwise_fraction(a, truth, keep, kind='elem_hip_vs_f64_' + kind, free_rows=free_rows)
+    fo = elementwise_fraction(ref32, truth, keep, kind='elem_oracle32_vs_f64_' + kind)
+    elementwise_fraction(a, ref32, keep, kind='elem_hip_vs_oracle32_' + kind)          # logged only
+    return fh, fo
+
+
+def three_way_ok(frac_hip: float, frac_oracle: float) -> bool:
+    return frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION
+
+
 def outlier_fraction(a: np.ndarray, ref: np.ndarray, rtol: float, atol: float) -> float:
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     bad = np.abs(a - ref) > (atol + rtol * np.abs(ref))
@@ -288,11 +310,13 @@ def seed_trainer_moments(trainer, names, seed: int = 11) -> None:
         trainer.exp_avg_sq[o:o + n].view(shape).copy_(v0)
 
 
-def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label='', elem_fraction=ELEM_FRACTION):
+def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label='', elem_fraction=ELEM_FRACTION,
+                     truth: dict | None = None):
     """image [3,H,W]; grads / g_ref: {name: array with the Gaussian index first}. Entries outside the masks must agree to `tol`
-    (max-abs error relative to the tensor's max-abs value) AND element by element (elementwise_fraction: fewer than `elem_fraction` of the
-    entries beyond 1e-4 of their own magnitude + 1e-4 of the tensor's median magnitude); the masked fraction is bounded; masked entries
-    stay within `loose`."""
+    (max-abs error relative to the tensor's max-abs value) AND element by element: with `truth` (oracle.forward_backward_f64: the fp64
+    values of 'image' and the six gradients) three-way (elementwise_three_way), without it directly against the oracle (fewer than
+    `elem_fraction` of the entries beyond 1e-4 of their own magnitude + 1e-4 of the tensor's median magnitude); the masked fraction is
+    bounded; masked entries stay within `loose`."""
     report = {}
     pm = masks['pixel']
     frac_p, frac_g = float(pm.mean()), float(masks['prim'].mean()) if masks['prim'].size else 0.0
@@ -303,10 +327,14 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         scale = max(1.0, float(np.abs(f_image).max()))
         report['image'] = float(err[~pm].max() / scale) if (~pm).any() else 0.0
         report['image_masked'] = float(err[pm].max() / scale) if pm.any() else 0.0
-        report['image_elem'] = elementwise_fraction(np.moveaxis(np.asarray(image), 0, -1)[~pm], np.moveaxis(np.asarray(f_image), 0, -1)[~pm],
-                                                    kind='elementwise_image')
+        hwc = lambda x: np.moveaxis(np.asarray(x), 0, -1)[~pm]
         assert report['image'] < tol, (label, 'image', report)
-        assert report['image_elem'] < elem_fraction, (label, 'image (element-wise 1e-4)', report)
+        if truth is not None and 'image' in truth:
+            report['image_elem'] = elementwise_three_way(hwc(image), hwc(f_image), hwc(truth['image']), kind='image')
+            assert three_way_ok(*report['image_elem']), (label, 'image (element-wise 1e-4, three-way)', report)
+        else:
+            report['image_elem'] = elementwise_fraction(hwc(image), hwc(f_image), kind='elementwise_image')
+            assert report['image_elem'] < elem_fraction, (label, 'image (element-wise 1e-4)', report)
         assert report['image_masked'] < loose, (label, 'image (masked pixels)', report)
     keep = ~masks['prim']
     for k, a in grads.items():
@@ -314,8 +342,12 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         a = np.asarray(a).reshape(ref.shape)
         report[k] = masked_rel_inf(a, ref, keep)
         report[k + '_masked'] = masked_rel_inf(a, ref, masks['prim'])
-        report[k + '_elem'] = elementwise_fraction(a, ref, keep, kind='elementwise_' + k)
         assert report[k] < tol, (label, k, report)
         assert report[k + '_masked'] < loose, (label, k + ' (masked Gaussians)', report)
-        assert report[k + '_elem'] < elem_fraction, (label, k + ' (element-wise 1e-4)', report)
+        if truth is not None and k in truth:
+            report[k + '_elem'] = elementwise_three_way(a, ref, np.asarray(truth[k]).reshape(ref.shape), keep, kind=k)
+            assert three_way_ok(*report[k + '_elem']), (label, k + ' (element-wise 1e-4, three-way)', report)
+        else:
+            report[k + '_elem'] = elementwise_fraction(a, ref, keep, kind='elementwise_' + k)
+            assert report[k + '_elem'] < elem_fraction, (label, k + ' (element-wise 1e-4)', report)
     return report
