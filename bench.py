@@ -43,6 +43,10 @@ def parse():
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
     ap.add_argument('--async-forward', action='store_true', help='training forward without the host read of the visible / instance counts (fgs_forward_async)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the live rocprofv3 counter passes (HBM traffic, VALU instructions)')
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps iterations: the first is the contract\'s timed region (value), '
+                                                         'the others show its repeatability (median / min / max in `repeatability`)')
+    ap.add_argument('--watchdog', type=int, default=900, help='seconds after which a hung rank dumps its stacks and exits (0 = off)')
+    ap.add_argument('--pmc-child', action='store_true', help='internal: the short child run of the rocprofv3 counter passes (training + fused steps only)')
     ap.add_argument('--force-dp', action='store_true', help='world size 1: run the multi-GPU step (exchange = local copy) instead of the single-GPU iteration (profiling)')
     ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'zero1', 'allreduce'],
                     help="N > 1: 'sharded' = every rank owns N/G Gaussians, 56-B records / 36-B accumulators cross xGMI (harness/sharded.py); "
@@ -79,8 +83,8 @@ def live_pmc(args) -> dict:
         return {'error': 'rocprofv3 not on PATH'}
     out: dict = {}
     tmp = tempfile.mkdtemp(prefix='fgs_pmc_', dir='/tmp')
-    child = [sys.executable, str(Path(__file__).resolve()), '--scene', args.scene, '--steps', '3', '--warmup', '1', '--no-extras',
-             '--no-cpu-baseline', '--no-pmc'] + (['--n-gaussians', str(args.n_gaussians)] if args.n_gaussians else [])
+    child = [sys.executable, str(Path(__file__).resolve()), '--scene', args.scene, '--steps', '3', '--warmup', '1', '--no-extras', '--blocks', '1',
+             '--no-cpu-baseline', '--no-pmc', '--pmc-child'] + (['--n-gaussians', str(args.n_gaussians)] if args.n_gaussians else [])
     try:
         for tag, counters in (('fetch', ['FETCH_SIZE', 'SQ_INSTS_VALU']), ('write', ['WRITE_SIZE', 'SQ_WAVES'])):
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', *counters, '-d', f'{tmp}/{tag}', '-o', 'b', '--'] + child
@@ -157,12 +161,30 @@ def main():
         with socket.socket() as sock:
             sock.bind(('127.0.0.1', 0))
             port = sock.getsockname()[1]
+        import tempfile
+        log_dir = tempfile.mkdtemp(prefix='fgs_bench_ranks_', dir='/tmp')
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+               '--master-port', str(port), '--log-dir', log_dir, '--redirects', '2', '--tee', '1', str(Path(__file__).resolve())] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+        # own process group: on a timeout exactly this launcher and its ranks are killed (never by pattern)
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=(args.watchdog + 120) if args.watchdog else None)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(proc.pid, signal.SIGKILL)
+            rc = 124
+            print(f'bench.py: the {args.gpus}-rank run exceeded {args.watchdog + 120} s and was killed', file=sys.stderr)
+        if rc != 0:                                     # relay what every rank wrote to stderr (torchrun keeps it in --log-dir)
+            for f in sorted(Path(log_dir).rglob('stderr.log')):
+                tail = f.read_text(errors='replace')[-3000:]
+                print(f'---- {f.relative_to(log_dir)} (tail) ----\n{tail}', file=sys.stderr)
+        raise SystemExit(rc)
     if world != args.gpus and not args.cpu_baseline_only:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}')
+    if args.watchdog and not args.cpu_baseline_only:
+        import faulthandler                              # a rank stuck in a collective dumps every thread's stack to stderr and exits, instead
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)      # of hanging the whole job until the driver's own limit
     params, views, workload = build_scene(args)
 
     if args.cpu_baseline_only:
@@ -179,7 +201,9 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
-        dist.init_process_group('nccl', device_id=device)
+        import datetime
+        dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=max(args.watchdog, 120) if args.watchdog else 1800))
+        assert dist.get_world_size() == world and dist.get_rank() == rank, (dist.get_world_size(), world, dist.get_rank(), rank)
     be = default_backend()
     import FasterGSCudaBackend as FGS
     # Default: fgs_forward with its ONE host read of the counts -- the depth sort is enqueued behind the copy, so the wait costs nothing at
@@ -256,6 +280,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def peak_vram(reset: bool = False) -> dict:
+        """Peak device memory of this process since the last reset: everything the path allocates goes through torch (parameters, moments,
+        gradients, images, and the four scratch blobs the library sizes through the resize callback), so torch's allocator statistics cover it."""
+        out_ = {'peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 1e9, 'peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 1e9}
+        if reset:
+            torch.cuda.reset_peak_memory_stats(device)
+        return out_
+
+    def blob_capacities(gaussians, view) -> dict:
+        """Sizes of the backend's private scratch for one view: the four forward blobs (bucket / instance blobs are sized by capacity
+        bounds, api.hip bucket_capacity) and the backward scratch."""
+        S_ = T.extract_settings(view, gaussians.active_sh_bases, view.background_color)
+        r_ = be.forward(*gaussians.tensors(), S_)
+        names_ = ('primitive', 'tile', 'instance', 'bucket')
+        caps = {f'{k}_blob_GB': b.numel() / 1e9 for k, b in zip(names_, r_.buffers)}
+        caps['backward_scratch_GB'] = int(be.lib.fgs_backward_scratch_bytes(n, view.width, view.height)) / 1e9
+        caps['total_GB'] = sum(caps.values())
+        del r_
+        return caps
+
+    torch.cuda.reset_peak_memory_stats(device)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -286,6 +331,40 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # Repeatability: the contract's timed region above is ONE block of --steps iterations (49 ms at 20 steps); --blocks - 1 further blocks,
+    # each bracketed the same way (barrier + synchronize, maximum over the ranks), say how far one such sample can be trusted.
+    block_ms = [elapsed / args.steps * 1e3]
+    for b in range(1, max(args.blocks, 1)):
+        fence()
+        tb0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + PROFILE_STEPS + b * args.steps + i)
+        fence()
+        tb = time.perf_counter() - tb0
+        if world > 1:
+            tmax = torch.tensor([tb], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tb = float(tmax.item())
+        block_ms.append(tb / args.steps * 1e3)
+    headline_vram = peak_vram(reset=True)
+    # who took part: every rank reports its device and the Gaussians it saw (proves N ranks ran)
+    roster = None
+    if dist.is_initialized():
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(device), 'n_gaussians_on_rank': int(vp.n_local) if hasattr(vp, 'n_local') else n,
+                'n_visible_view0': int(stats[id(my_views[0])]['V']), 'visible_devices': torch.cuda.device_count()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        roster = gathered
+
+    if args.pmc_child:
+        # child of live_pmc(): the counter passes also want the fused kernel in the trace; nothing is printed
+        v = my_views[0]
+        fo = FusedRasterizerOptimizer([getattr(g, k).detach() for k in T.PARAM_ORDER], [1.6e-4 * 5.0, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3])
+        S = T.extract_settings(v, g.active_sh_bases, v.background_color)
+        for _ in range(3):
+            fo.render_and_step(S, lambda img: be.l1_dssim(img, targets[id(v)], 0.8, 0.2)[1], g.densification_info)
+        torch.cuda.synchronize(device)
+        return
 
     def wire_bytes(mode: str) -> float:
         """Bytes this rank puts on xGMI per step. sharded: 56-B records out + 36-B accumulators back for the (G-1)/G of its visible
@@ -382,6 +461,7 @@ def main():
         if st in pmc and 'SQ_INSTS_VALU' in pmc[st] and st in per_launch:
             insts = pmc[st]['SQ_INSTS_VALU']
             secondary.append({'bound': 'valu', 'stage': st, 'kernel': kernel_of[st], 'insts': insts, 'avg_kernel_ms': per_launch[st],
+                              'avg_kernel_ms_source': f'untimed {n_prof}-step stage-profile pass (HIP events around every stage), not the timed region',
                               'cycles_per_inst': 2.9, 'frac': insts * 2.9 / (1024 * 2.4e9 * per_launch[st] * 1e-3)})
     out = {
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
@@ -395,7 +475,9 @@ def main():
                    # dense gradients; FusedAdam.step does not read back the zeros of 64-Gaussian blocks without a visible Gaussian when it can prove
                    # the gradient tensors untouched (bit-identical): how often that held / did not in this process
                    'live_block_handover': FGS.live_block_stats(),
-                   'world': world, 'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
+                   'world': dist.get_world_size() if dist.is_initialized() else 1, 'ranks': roster,
+                   'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if dist.is_initialized() else None,
+                   'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
                    'device': f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
                    'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0},
         'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -405,6 +487,12 @@ def main():
                      'secondary': secondary,
                      'iteration_algorithmic_GB': bytes_iter / 1e9, 'iteration_survey_formula_GB': bytes_iter_survey / 1e9,
                      'iteration_frac_of_hbm_peak': bytes_iter / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        'repeatability': {'blocks': len(block_ms), 'steps_per_block': args.steps, 'ms_per_step': block_ms, 'median_ms': float(np.median(block_ms)),
+                          'min_ms': float(min(block_ms)), 'max_ms': float(max(block_ms)),
+                          'median_iters_per_sec': world * 1e3 / float(np.median(block_ms)),
+                          'note': 'block 0 is the timed region `value` / `ms_per_step` come from; every block is bracketed by barrier + synchronize'},
+        'peak_vram_GB': {**headline_vram, 'scratch_blobs': blob_capacities(g, my_views[0]) if vp is None else None,
+                         'note': 'torch allocator peaks over warm-up + stage profile + all timed blocks of the headline run'},
         'stage_ms_per_step': {k: v[0] / n_prof for k, v in prof.items() if v[1] > 0},
         'stage_profile_steps': n_prof,
         'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes},
@@ -435,19 +523,43 @@ def main():
         for _ in range(2):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            fo.render_and_step(S, grad_fn, g.densification_info)
-        torch.cuda.synchronize(device)
-        out['fused_train_iters_per_sec'] = reps / (time.perf_counter() - t0)
+        peak_vram(reset=True)
+        be.profile_enable(True, only='fused_backward_adam')      # HIP events around the fused kernel only, inside the timed repetitions
+        be.profile_read()
+        fused_blocks = []
+        reps = args.steps
+        for _b in range(max(args.blocks, 1)):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fo.render_and_step(S, grad_fn, g.densification_info)
+            torch.cuda.synchronize(device)
+            fused_blocks.append((time.perf_counter() - t0) / reps * 1e3)
+        prof_f = be.profile_read()
+        be.profile_enable(False)
+        fused_ms = float(np.median(fused_blocks))
+        out['fused_train_iters_per_sec'] = 1e3 / fused_ms
+        fk_ms = prof_f['fused_backward_adam'][0] / max(prof_f['fused_backward_adam'][1], 1)
+        f_traffic = None
+        if 'fused_backward_adam' in pmc and 'FETCH_SIZE' in pmc['fused_backward_adam'] and 'WRITE_SIZE' in pmc['fused_backward_adam']:
+            f_traffic = (2.0 * pmc['fused_backward_adam']['FETCH_SIZE'] + pmc['fused_backward_adam']['WRITE_SIZE']) * 1024.0
+        f_bytes = stage_bytes['fused_backward_adam'] if stats[id(v)]['V'] == V else 1416.0 * n + 4.0 * n + 52.0 * stats[id(v)]['V']
+        out['fused'] = {'what': 'BASELINE.json configs[3]: forward + loss + fused backward+Adam (gradients never materialised), view 0',
+                        'train_iters_per_sec': 1e3 / fused_ms, 'ms_per_step': fused_ms,
+                        'repeatability': {'blocks': len(fused_blocks), 'steps_per_block': reps, 'ms_per_step': fused_blocks,
+                                          'min_ms': float(min(fused_blocks)), 'max_ms': float(max(fused_blocks))},
+                        'roofline': {'bound': 'hbm', 'kernel': kernel_of['fused_backward_adam'], 'achieved': f_bytes / (fk_ms * 1e-3) / 1e9 if fk_ms > 0 else 0.0,
+                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (f_bytes / (fk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fk_ms > 0 else 0.0,
+                                     'traffic': f_traffic, 'avg_kernel_ms': fk_ms, 'algorithmic_bytes_per_launch': f_bytes,
+                                     'note': 'HIP events around the fused kernel over the timed repetitions; traffic from the same rocprofv3 --pmc child passes'},
+                        'peak_vram_GB': peak_vram(reset=True)}
         be.profile_enable(True)
         be.profile_read()
         for _ in range(PROFILE_STEPS):
             fo.render_and_step(S, grad_fn, g.densification_info)
         torch.cuda.synchronize(device)
         out['fused_stage_ms_per_step'] = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
-        out['fused_vs_unfused'] = out['fused_train_iters_per_sec'] / out['value']
+        out['fused_vs_unfused'] = out['fused_train_iters_per_sec'] / out['repeatability']['median_iters_per_sec']
         be.profile_enable(False)
         del fo
         # A "trained-like" regime beside S2: S2's random opacities saturate a pixel after ~2 buckets; lowering every
@@ -462,13 +574,18 @@ def main():
         for i in range(2):
             T.training_iteration(g2, my_views[i % len(my_views)], tg2[id(my_views[i % len(my_views)])], i)
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
+        peak_vram(reset=True)
         reps = 8
-        for i in range(reps):
-            vv = my_views[(2 + i) % len(my_views)]
-            T.training_iteration(g2, vv, tg2[id(vv)], 2 + i)
-        torch.cuda.synchronize(device)
-        dt = (time.perf_counter() - t0) / reps
+        layered_blocks = []
+        for _b in range(max(min(args.blocks, 3), 1)):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                vv = my_views[(2 + i) % len(my_views)]
+                T.training_iteration(g2, vv, tg2[id(vv)], 2 + i)
+            torch.cuda.synchronize(device)
+            layered_blocks.append((time.perf_counter() - t0) / reps * 1e3)
+        dt = float(np.median(layered_blocks)) * 1e-3
         be.profile_enable(True)
         be.profile_read()
         for i in range(PROFILE_STEPS):
@@ -481,7 +598,8 @@ def main():
         lay = be.blob_layout(1, n, W_, H_, res.state[1], res.state[2])
         mx = be.view(res.buffers[1], lay, 'max_n_processed', torch.int32)[:T_].long()
         out['layered_scene'] = {'what': 'S2 with every opacity logit lowered by 3.0 (deep semi-transparent layering, as in a trained scene)',
-                                'train_iters_per_sec': 1.0 / dt, 'ms_per_step': dt * 1e3, 'instances': res.state[1],
+                                'train_iters_per_sec': 1.0 / dt, 'ms_per_step': dt * 1e3, 'ms_per_step_blocks': layered_blocks, 'instances': res.state[1],
+                                'peak_vram_GB': peak_vram(reset=True), 'scratch_blobs_GB': blob_capacities(g2, my_views[0]),
                                 'blended_buckets_per_tile': float(((mx + 63) // 64).float().mean()),
                                 'stage_ms_per_step': {k: v_[0] / PROFILE_STEPS for k, v_ in pr.items() if v_[1] > 0}}
         del g2, tg2, res

@@ -122,14 +122,16 @@ struct PrimitiveBuffers {             // cf. bu:45-94
 };
 struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed are tile-major here
     uint2* ranges; uint32_t* bucket_offsets; uint32_t* max_n_processed; float* final_T; uint32_t* n_processed;
+    uint32_t* tile_plan;              // K10's tile -> workgroup plan (plan_tiles_kernel)
     uint32_t* live_count;             // backward: number of live buckets (K11 planning pass)
     uint32_t* live_offsets;           // backward: first slot of each tile in the live-bucket list
     char* temp; size_t temp_bytes;
     static TileBuffers carve(Carver& c, uint32_t t, bool training) {
         TileBuffers b{};
         b.ranges = c.take<uint2>("ranges", t);
+        b.bucket_offsets = c.take<uint32_t>("bucket_offsets", t);         // inference too: the plan's block weights are differences of this scan
+        b.tile_plan = c.take<uint32_t>("tile_plan", kPlanWords);
         if (training) {
-            b.bucket_offsets = c.take<uint32_t>("bucket_offsets", t);
             b.max_n_processed = c.take<uint32_t>("max_n_processed", t);
             b.final_T = c.take<float>("final_T", (size_t)t * kTilePixels);
             b.n_processed = c.take<uint32_t>("n_processed", (size_t)t * kTilePixels);
@@ -176,6 +178,7 @@ struct BackwardScratch {
 };
 
 std::atomic<int> g_seq_tiles{kSeqTiles};           // fgs_debug_set_option key 5
+std::atomic<int> g_library_bucket_scan{0};         // fgs_debug_set_option key 11: 1 = rocPRIM scan for K8+K9 and no tile plan (round-2 form, A/B)
 std::atomic<int> g_fused_single_kernel{1};         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
@@ -352,9 +355,18 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     ba.width = settings->width; ba.height = settings->height; ba.grid_w = geo.grid_w; ba.n_tiles = geo.n_tiles;
     ba.to_chw = to_chw; ba.clamp_output = clamp_output;
     uint32_t n_buckets_cap = 0;
+    // K8+K9 (fwd:218-231) and K10's tile plan in one single-workgroup kernel; every mode (the inference blend is planned the same way)
+    if (g_library_bucket_scan && training) {
+        StageScope t(ST_BUCKET_SCAN, stream);
+        FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));
+    } else {
+        StageScope t(ST_BUCKET_SCAN, stream);
+        FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, tb.tile_plan, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
+        ba.tile_plan = tb.tile_plan;
+    }
+    ba.grid_h = geo.grid_h;
     if (training) {
-        // K8+K9 (fwd:218-231) and the bucket buffer sized by its bound (no read-back of n_buckets, fwd:234)
-        { StageScope t(ST_BUCKET_SCAN, stream); FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream)); }
+        // the bucket buffer sized by its bound (no read-back of n_buckets, fwd:234)
         n_buckets_cap = bucket_capacity(n_instances, geo.n_tiles);
         Carver bucket_size(nullptr);
         BucketBuffers::carve(bucket_size, n_buckets_cap);
@@ -1039,8 +1051,9 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
-        case 10: if (value < 0 || (value > 64 && value != 255)) return fail(FGS_ERR_INVALID_ARGUMENT, "row group must be 0 (bands), 255 (bands, bottom first) or 1..64");
+        case 10: if (value < 0 || (value > 64 && value != 255 && value != 254)) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
                  fgs::g_tile_row_group = value; return FGS_OK;
+        case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

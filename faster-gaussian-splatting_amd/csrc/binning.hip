@@ -9,6 +9,7 @@
 // Built with -ffp-contract=off (the exact-overlap test must agree bit-for-bit with the one in preprocess.hip).
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
+#include "fgs_tile_scan.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -366,7 +367,96 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
     return hipGetLastError();
 }
 
-// ---- K8+K9 (kf:350-360 + fwd:225-231) as one scan with a transform iterator -----------------------------------
+// ---- K8+K9 (kf:350-360 + fwd:225-231) + the tile -> workgroup plan of K10 ---------------------------------------------
+// ONE single-workgroup kernel (fgs_tile_scan.h) replaces the library scan (rocPRIM look-back, 15 us for 12 k tiles):
+//  (1) bucket_offsets[t] = inclusive scan of ceil(len_t / 64)                                          (kf:350-360, fwd:225-231)
+//  (2) the plan that K10 reads to decide which tile a workgroup blends (blend_forward.hip: tile_of_workgroup).
+// Why a plan: the hardware deals workgroups to the 8 XCDs round-robin (XCD = workgroup % 8), every XCD has its own L2, and a
+// Gaussian's record is re-read by every tile it overlaps -- so an XCD should own compact pieces of the image. Round 1/2 gave every
+// XCD one contiguous band of tile rows: good locality, but the bands differ in work (at S2 the top band has 30 ms of summed tile time
+// against 44-47 ms for the others; on a layered scene 47 against 210-220: XCD 0 idles for two thirds of the kernel) and the heaviest
+// rows came last in every band (profiles/r02_k10_timeline_before.txt). Interleaving single rows balances but gives up vertical
+// locality (+10 % layered, -9..16 % S2). The plan keeps both: the image is cut into 8 x 10 rectangular blocks of tiles (15 x 9 tiles
+// at 1080p: every XCD gets exactly 10 blocks, i.e. the same number of workgroups, which the round-robin deal requires); a block's
+// weight is its number of 64-Gaussian buckets (+ 1 per tile) -- known here, on the device, from the scan itself: no host read; the
+// blocks are sorted by weight and dealt in 10 rounds of 8, heaviest block of a round to the XCD with the least work so far; an XCD
+// walks its blocks in the order received = heaviest first, so the kernel's tail consists of the lightest blocks.
+__global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
+                                                                      uint32_t* __restrict__ tile_plan, const uint32_t n_tiles,
+                                                                      const uint32_t grid_w, const uint32_t grid_h) {
+    __shared__ TileScanShared s_scan;
+    __shared__ uint32_t s_weight[kPlanBlocks], s_sorted[kPlanBlocks];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < kPlanBlocks) s_weight[tid] = 0u;
+    uint32_t base = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += kTileScanThreads * kTileScanChunks) {          // one pass at 1080p (12 240 tiles)
+        uint32_t nb[kTileScanChunks], ex[kTileScanChunks];
+#pragma unroll
+        for (int c = 0; c < kTileScanChunks; ++c) {
+            const uint32_t t = t0 + static_cast<uint32_t>(c) * kTileScanThreads + tid;
+            uint2 r = make_uint2(0u, 0u);
+            if (t < n_tiles) r = ranges[t];
+            nb[c] = (r.y - r.x + kBucket - 1) / kBucket;                                      // kf:350-360
+        }
+        const uint32_t total = tile_scan_pass(nb, ex, s_scan, base);
+#pragma unroll
+        for (int c = 0; c < kTileScanChunks; ++c) {
+            const uint32_t t = t0 + static_cast<uint32_t>(c) * kTileScanThreads + tid;
+            if (t < n_tiles) bucket_offsets[t] = ex[c] + nb[c];                               // inclusive (fwd:225-231)
+        }
+        base += total;
+    }
+    __syncthreads();                                                                         // bucket_offsets visible to the workgroup
+    // block weights: one (block, tile row) pair per work item -- a difference of two scan values
+    const uint32_t bw = (grid_w + kPlanBlocksX - 1) / kPlanBlocksX, bh = (grid_h + kPlanBlocksY - 1) / kPlanBlocksY;
+    for (uint32_t i = tid; i < kPlanBlocks * bh; i += kTileScanThreads) {
+        const uint32_t b = i / bh, r = i - b * bh;
+        const uint32_t bx = b % kPlanBlocksX, by = b / kPlanBlocksX;
+        const uint32_t ty = by * bh + r, x0 = bx * bw, x1 = min(x0 + bw, grid_w);
+        if (ty < grid_h && x0 < x1) {
+            const uint32_t last = ty * grid_w + x1 - 1u, first = ty * grid_w + x0;
+            const uint32_t w = bucket_offsets[last] - (first != 0u ? bucket_offsets[first - 1u] : 0u) + (x1 - x0);
+            atomicAdd(&s_weight[b], w);
+        }
+    }
+    __syncthreads();
+    // sort the blocks by weight (descending, ties by index): rank by counting -- 80 broadcast reads per thread
+    if (tid < kPlanBlocks) {
+        const uint32_t w = s_weight[tid];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < kPlanBlocks; ++o) {
+            const uint32_t wo = s_weight[o];
+            rank += (wo > w || (wo == w && o < tid)) ? 1u : 0u;
+        }
+        s_sorted[rank] = tid;
+    }
+    __syncthreads();
+    if (tid < kWave) {                                                                       // wave 0: the deal, lanes 0..7 = the XCDs
+        uint32_t load = 0;
+        for (uint32_t round = 0; round < kPlanBlocksPerXcd; ++round) {
+            uint32_t rank = 0;                                                               // my position among the XCDs by work so far
+#pragma unroll
+            for (int x = 0; x < kXcds; ++x) {
+                const uint32_t lx = wave_read(load, x);
+                rank += (lx < load || (lx == load && static_cast<uint32_t>(x) < lane)) ? 1u : 0u;
+            }
+            if (lane < kXcds) {
+                const uint32_t b = s_sorted[round * kXcds + rank];                           // least work so far <- heaviest block of the round
+                load += s_weight[b];
+                tile_plan[kPlanHeader + lane * kPlanBlocksPerXcd + round] = b;
+            }
+        }
+        if (lane == 0) { tile_plan[0] = bw; tile_plan[1] = bh; tile_plan[2] = bw * bh; tile_plan[3] = kPlanBlocksPerXcd; }
+    }
+}
+
+hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint32_t* tile_plan, uint32_t n_tiles, uint32_t grid_w, uint32_t grid_h,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kTileScanThreads), 0, s, ranges, bucket_offsets, tile_plan, n_tiles, grid_w, grid_h);
+    return hipGetLastError();
+}
+
+// the library scan (rocPRIM): kept for A/B runs (fgs_debug_set_option(11, 1))
 struct BucketsOfRange {
     __host__ __device__ uint32_t operator()(const uint2& r) const { return (r.y - r.x + kBucket - 1) / kBucket; }
 };

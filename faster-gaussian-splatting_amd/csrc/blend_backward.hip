@@ -16,6 +16,7 @@
 //    loads instead of gathering 9 scalars from image-linear arrays per bucket.
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
+#include "fgs_tile_scan.h"
 
 namespace fgs {
 
@@ -316,41 +317,28 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
 //      gate multiplies sum(w g) once at the end (kb:426-427), dL/dopacity = -2 sum(hh) / opacity because G = alpha / opacity
 //      (kb:438), and dL/dmean2d = 2 [a b; b c] (sum(hh dx), sum(hh dy)) (kb:449-453) with hh = -alpha/2 dL/dalpha.
 //      About 50 VALU instructions per step remain.
-__global__ void __launch_bounds__(1024) plan_blend_backward_kernel(const BlendBackwardArgs a) {
-    // One workgroup: exclusive scan of the live-bucket count of every tile (tiles taken 1024 at a time: thread t <-> tile chunk * 1024 + t,
-    // coalesced; the loads of up to kPlanChunks chunks are all issued before the first scan -- a thread that walked "its" 12 consecutive
-    // tiles with dependent loads made this pass latency-bound at 33 us). live_offsets[tile] = first list slot of the tile; the entries
-    // themselves are written by stage_pixels_kernel (a single workgroup writing 115 k entries took 58 us on the layered scene).
-    constexpr int kPlanChunks = 16;                           // 16 Ki tiles (1080p: 12 240) per batch of loads
-    __shared__ uint32_t s_wave_total[2][1024 / kWave];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    uint32_t base = 0;                                        // live buckets in front of the current chunk (uniform)
-    int parity = 0;
-    for (unsigned t0 = 0; t0 < a.n_tiles; t0 += 1024u * kPlanChunks) {
-        uint32_t nl[kPlanChunks];
+__global__ void __launch_bounds__(kTileScanThreads) plan_blend_backward_kernel(const BlendBackwardArgs a) {
+    // One workgroup: exclusive scan of the live-bucket count of every tile (fgs_tile_scan.h: a thread takes the tiles c * 1024 + tid of
+    // sixteen chunks at once, three barriers per 16 Ki tiles; the first version -- one barrier per 1024-tile chunk -- took 15 us at 1080p,
+    // all of it latency). live_offsets[tile] = first list slot of the tile; the entries themselves are written by stage_pixels_kernel
+    // (a single workgroup writing 115 k entries took 58 us on the layered scene).
+    __shared__ TileScanShared s_scan;
+    const unsigned tid = threadIdx.x;
+    uint32_t base = 0;                                        // live buckets in front of the current pass (uniform)
+    for (unsigned t0 = 0; t0 < a.n_tiles; t0 += kTileScanThreads * kTileScanChunks) {
+        uint32_t nl[kTileScanChunks], ex[kTileScanChunks];
 #pragma unroll
-        for (int c = 0; c < kPlanChunks; ++c) {
-            const unsigned t = t0 + static_cast<unsigned>(c) * 1024u + tid;
+        for (int c = 0; c < kTileScanChunks; ++c) {
+            const unsigned t = t0 + static_cast<unsigned>(c) * kTileScanThreads + tid;
             nl[c] = t < a.n_tiles ? (a.max_n_processed[t] + kBucket - 1) / kBucket : 0u;          // live buckets of the tile (kb:295)
         }
+        const uint32_t total = tile_scan_pass(nl, ex, s_scan, base);
 #pragma unroll
-        for (int c = 0; c < kPlanChunks; ++c) {
-            const unsigned t = t0 + static_cast<unsigned>(c) * 1024u + tid;
-            if (t0 + static_cast<unsigned>(c) * 1024u >= a.n_tiles) break;                          // uniform
-            const uint32_t before_in_wave = wave_exclusive_sum(nl[c]);
-            if (lane == 63u) s_wave_total[parity][wv] = before_in_wave + nl[c];
-            __syncthreads();
-            uint32_t mine = base + before_in_wave, total = 0;
-#pragma unroll
-            for (unsigned w = 0; w < 1024 / kWave; ++w) {
-                const uint32_t wt = s_wave_total[parity][w];
-                mine += w < wv ? wt : 0u;
-                total += wt;
-            }
-            if (t < a.n_tiles) a.live_offsets[t] = mine;
-            base += total;
-            parity ^= 1;                                      // the next chunk writes the other LDS row: one barrier per chunk
+        for (int c = 0; c < kTileScanChunks; ++c) {
+            const unsigned t = t0 + static_cast<unsigned>(c) * kTileScanThreads + tid;
+            if (t < a.n_tiles) a.live_offsets[t] = ex[c];
         }
+        base += total;
     }
     if (tid == 0) *a.live_count = base;
 }
@@ -582,7 +570,7 @@ std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted 
 
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
     BlendBackwardArgs a = a_in;
-    if (g_backward_variant == 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(1024), 0, s, a);
+    if (g_backward_variant == 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(kTileScanThreads), 0, s, a);
     else a.live_offsets = nullptr;                            // the other variants walk all buckets: no list
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
     return hipGetLastError();

@@ -30,25 +30,42 @@ namespace fgs {
 // g = 1 0.663 / 0.646, g = 2 0.654 / 0.633 -- there balance wins 10 %. Bands walked bottom-up (255): no difference. Which of the two a scene
 // wants depends on how deep its tiles blend, which the host does not know at launch: the DEFAULT stays the bands (the benchmark workload),
 // fgs_debug_set_option(10, g) selects the other. Returns n_tiles for padding workgroups.
+// Round 3 (the default, row_group == kPlannedBlocks): the mapping is DATA -- plan_tiles_kernel (binning.hip) cuts the tile grid into 8 x 10
+// rectangular blocks, weighs them by their bucket counts on the device and deals them to the XCDs (heaviest first, least-loaded XCD first);
+// this function only looks its block up. Locality of the bands, balance of the interleaved rows, no host read.
 constexpr unsigned kBandsBottomFirst = 255u;     // row_group value: the round-1 bands, each walked from its last tile to its first
-std::atomic<int> g_tile_row_group{0};
-__device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, const unsigned grid_w, const unsigned n_tiles, const unsigned row_group) {
+std::atomic<int> g_tile_row_group{static_cast<int>(kPlannedBlocks)};
+__device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, const unsigned grid_w, const unsigned n_tiles, const unsigned row_group,
+                                                      const uint32_t* __restrict__ plan = nullptr, const unsigned grid_h = 0u) {
+    if (row_group == kPlannedBlocks) {
+        const unsigned bw = (grid_w + kPlanBlocksX - 1) / kPlanBlocksX, bh = (grid_h + kPlanBlocksY - 1) / kPlanBlocksY;   // = plan[0], plan[1]
+        const unsigned per_block = bw * bh;
+        const unsigned xcd = block % kXcds, q = block / kXcds;
+        const unsigned slot = q / per_block, local = q - slot * per_block;
+        if (slot >= kPlanBlocksPerXcd) return n_tiles;
+        const unsigned b = plan[kPlanHeader + xcd * kPlanBlocksPerXcd + slot];                 // wave-uniform: a scalar load
+        const unsigned ly = local / bw, lx = local - ly * bw;
+        const unsigned tx = (b % kPlanBlocksX) * bw + lx, ty = (b / kPlanBlocksX) * bh + ly;
+        return (tx < grid_w && ty < grid_h) ? ty * grid_w + tx : n_tiles;
+    }
     if (row_group == 0u || row_group == kBandsBottomFirst) {                                // one contiguous band per XCD, top-down or bottom-up
         const unsigned per_xcd = (n_tiles + kXcds - 1) / kXcds;
         const unsigned idx = block / kXcds;
         const unsigned tile = (block % kXcds) * per_xcd + (row_group == 0u ? idx : per_xcd - 1u - idx);
         return tile < n_tiles ? tile : n_tiles;
     }
-    const unsigned grid_h = n_tiles / grid_w;
+    const unsigned n_rows = n_tiles / grid_w;
     const unsigned xcd = block % kXcds, j = block / kXcds;
     const unsigned k = j / grid_w, col = j - k * grid_w;                                   // k-th row this XCD walks
-    const unsigned cycles = (grid_h + kXcds * row_group - 1) / (kXcds * row_group);        // groups per XCD
+    const unsigned cycles = (n_rows + kXcds * row_group - 1) / (kXcds * row_group);        // groups per XCD
     if (k >= cycles * row_group) return n_tiles;
     const unsigned kk = cycles * row_group - 1u - k;                                       // bottom of the image first
     const unsigned row = (kk / row_group) * (kXcds * row_group) + xcd * row_group + kk % row_group;
-    return row < grid_h ? row * grid_w + col : n_tiles;
+    return row < n_rows ? row * grid_w + col : n_tiles;
 }
 static unsigned blend_grid(const BlendArgs& a) {
+    if (a.row_group == kPlannedBlocks)
+        return kPlanBlocks * ((a.grid_w + kPlanBlocksX - 1) / kPlanBlocksX) * ((a.grid_h + kPlanBlocksY - 1) / kPlanBlocksY);
     if (a.row_group == 0u || a.row_group == kBandsBottomFirst) return ((a.n_tiles + kXcds - 1) / kXcds) * kXcds;
     const unsigned grid_h = a.n_tiles / a.grid_w;
     const unsigned cycles = (grid_h + kXcds * a.row_group - 1) / (kXcds * a.row_group);
@@ -64,7 +81,7 @@ __device__ unsigned long long g_k10_timeline[kK10TimelineTiles * 4];
 
 template <bool TRAINING>
 __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
-    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group);
+    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group, a.tile_plan, a.grid_h);
     if (tile >= a.n_tiles) return;
 #ifdef FGS_K10_TIMELINE
     const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();
@@ -212,7 +229,7 @@ namespace fgs {
 // one atomicAdd per (pixel, Gaussian) pair (kp:490); here the 64 lanes of a wave evaluate the SAME Gaussian, so their
 // scores are summed with 6 DPP adds and leave through one atomic per (Gaussian, wave).
 __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const BlendArgs a) {
-    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group);
+    const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group, a.tile_plan, a.grid_h);
     if (tile >= a.n_tiles) return;
     const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
@@ -293,6 +310,7 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
 hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
     BlendArgs a = a_in;
     a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    if (a.tile_plan == nullptr && a.row_group == kPlannedBlocks) a.row_group = 0u;
     hipLaunchKernelGGL(pruning_scores_kernel, dim3(blend_grid(a)), dim3(kBlendBlock), 0, s, a);
     return hipGetLastError();
 }
@@ -300,6 +318,7 @@ hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
 hipError_t launch_blend(bool training, const BlendArgs& a_in, hipStream_t s) {
     BlendArgs a = a_in;
     a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    if (a.tile_plan == nullptr && a.row_group == kPlannedBlocks) a.row_group = 0u;          // no plan was made: the bands
     const dim3 grid(blend_grid(a)), block(kBlendBlock);
     if (training) hipLaunchKernelGGL(blend_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(blend_kernel<false>, grid, block, 0, s, a);

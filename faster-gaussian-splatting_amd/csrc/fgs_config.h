@@ -44,6 +44,11 @@ constexpr unsigned kBackwardMaxBlocks = 1u << 16;   // K11 walks the live-bucket
 constexpr int kSplatRecordWords = 14;          // sharded path: PrimRec (12 words) + depth key + tile count = FGS_SPLAT_RECORD_BYTES / 4
 constexpr int kMaxBatchViews = 8;              // sharded path: views handled by one K1 / K12 launch (grid.y / in-kernel loop)
 constexpr int kAccRecordWords = 9;             // sharded path: the 9 pixel-space accumulators = FGS_ACC_RECORD_BYTES / 4
-constexpr int kXcds = 8;                       // tile -> workgroup mapping keeps image bands on one XCD's L2
+constexpr int kXcds = 8;                       // tile -> workgroup mapping keeps compact pieces of the image on one XCD's L2
+// K10's tile plan (binning.hip: plan_tiles_kernel): the tile grid is cut into kPlanBlocksX x kPlanBlocksY rectangular blocks, dealt to the
+// XCDs by weight; tile_plan = [block width, block height, tiles per block, blocks per XCD, then the block ids of XCD 0, XCD 1, ...]
+constexpr unsigned kPlanBlocksX = 8, kPlanBlocksY = 10, kPlanBlocks = kPlanBlocksX * kPlanBlocksY;
+constexpr unsigned kPlanBlocksPerXcd = kPlanBlocks / kXcds;
+constexpr unsigned kPlanHeader = 4, kPlanWords = kPlanHeader + kPlanBlocks;
 
 }  // namespace fgs

@@ -62,7 +62,8 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
 // The A/B switches behind fgs_debug_set_option are process-wide; atomics make concurrent set / launch well defined (a launch sees the
 // old or the new value, never a torn one).
-extern std::atomic<int> g_tile_row_group;            // blend_forward.hip: tile rows per XCD group of the tile -> workgroup mapping (0: round-1 bands)
+extern std::atomic<int> g_tile_row_group;            // blend_forward.hip: tile -> workgroup mapping (254: device-side block plan; 0: round-1 bands; 1..64 row groups)
+constexpr unsigned kPlannedBlocks = 254u;
 extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
 extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
@@ -76,8 +77,10 @@ hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32
 hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s);
 
-// K8+K9: inclusive scan of ceil(len/kBucket) per tile
-size_t bucket_scan_temp_bytes(uint32_t n_tiles);
+// K8+K9: inclusive scan of ceil(len/kBucket) per tile, and the tile -> workgroup plan of K10 (one single-workgroup kernel)
+hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint32_t* tile_plan, uint32_t n_tiles, uint32_t grid_w, uint32_t grid_h,
+                             hipStream_t s);
+size_t bucket_scan_temp_bytes(uint32_t n_tiles);      // the library scan, kept for A/B (fgs_debug_set_option(11, 1))
 hipError_t run_bucket_scan(void* temp, size_t temp_bytes, const uint2* ranges, uint32_t* bucket_offsets, uint32_t n_tiles, hipStream_t s);
 
 struct BlendArgs {                      // K10 / inference blend
@@ -87,6 +90,8 @@ struct BlendArgs {                      // K10 / inference blend
     uint32_t* bucket_tile; float4* ckpt;                                   // [B], [B][192]
     uint32_t width, height, grid_w, n_tiles;
     uint32_t row_group;                      // tile -> workgroup mapping (blend_forward.hip: tile_of_workgroup); set by the launchers
+    const uint32_t* tile_plan;               // [kPlanWords] written by plan_tiles_kernel (row_group == kPlannedBlocks)
+    uint32_t grid_h;
     int to_chw, clamp_output;
     float* scores;                        // pruning-score mode: accumulated per primitive [N]
 };

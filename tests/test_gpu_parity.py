@@ -40,8 +40,8 @@ def _grads_close(grads, g, tol=1e-4, truth=None, free_rows=2):
         e = helpers.rel_inf(a, g[k])
         assert e < tol, (k, e)
         if truth is not None:
-            fh, fo = helpers.elementwise_three_way(a, g[k], np.asarray(truth[k]).reshape(g[k].shape), kind=k, free_rows=free_rows)
-            assert helpers.three_way_ok(fh, fo), (k, 'element-wise 1e-4 (HIP vs fp64, oracle32 vs fp64)', fh, fo)
+            fh, fo, cnt = helpers.elementwise_three_way(a, g[k], np.asarray(truth[k]).reshape(g[k].shape), kind=k, free_rows=free_rows)
+            assert helpers.three_way_ok(fh, fo, cnt), (k, 'element-wise 1e-4 (HIP vs fp64, oracle32 vs fp64, entries)', fh, fo, cnt)
 
 
 def test_wave_primitives_selftest(hip_backend):

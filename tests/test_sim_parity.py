@@ -35,6 +35,26 @@ def _run(sim_backend, oracle, params, view, K=16, aa=False, bg=None, check_grads
     return res, f
 
 
+@pytest.mark.parametrize('w,h,n', [(128, 128, 1000), (333, 211, 600), (16, 12, 40), (1920, 1080, 300), (50, 700, 300)])
+def test_tile_plan_covers_every_tile_and_balances_the_xcds(sim_backend, w, h, n):
+    """K10's device-side tile -> workgroup plan (binning.hip: plan_tiles_kernel): whatever the image size and the distribution of the
+    Gaussians, every tile is blended by exactly one workgroup, every XCD gets ten blocks in descending weight, and the greedy deal keeps
+    the heaviest XCD within one block of the mean. Training and inference (which plans from the same scan)."""
+    p, v = make_s0(seed=5, n=n)
+    p['means'][:, 1] = p['means'][:, 1].abs()                  # everything in the lower half of the image: a strong vertical work gradient
+    v = View(v.w2c, v.position, w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, 0.2, 1e4, torch.zeros(3))
+    _, RS = helpers.settings_pair(v)
+    gw, gh = (w + 15) // 16, (h + 11) // 12
+    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(sim_backend, res, n, w, h)
+    info = helpers.check_tile_plan(dec['tile_plan'], dec['bucket_offsets'], gw, gh)
+    assert info['weights'].sum() == int(dec['bucket_offsets'][gw * gh - 1]) + gw * gh
+    inf = sim_backend.inference(*[p[k] for k in helpers.NAMES], RS, True, True, return_state=True)
+    lt = sim_backend.blob_layout(1, n, w, h, inf.state[1], inf.state[2])
+    plan = sim_backend.view(inf.buffers[1], lt, 'tile_plan', torch.int32).numpy().view(np.uint32)
+    assert np.array_equal(plan, dec['tile_plan'])
+
+
 def test_wave_primitives_selftest(sim_backend):
     out = torch.zeros(256, dtype=torch.int32)
     assert sim_backend.lib.fgs_debug_wave_selftest(out.data_ptr(), None) == 0
