@@ -65,7 +65,7 @@ def build_scene(args):
 
 
 PMC_KERNELS = {       # stage -> substring of the kernel name in the rocprofv3 trace
-    'adam': 'adam_kernel', 'blend_backward': 'blend_backward_compact_kernel', 'blend_forward': 'blend_kernel<true>',
+    'adam': 'fgs::adam_kernel', 'blend_backward': 'blend_backward_compact_kernel', 'blend_forward': 'blend_kernel<true>',
     'preprocess': 'preprocess_kernel<false>', 'create_instances': 'create_instances_kernel', 'fused_backward_adam': 'fused_backward_adam_kernel',
     'preprocess_backward': 'backward_gradients_kernel', 'sh_rest_backward': 'sh_rest_gradient_kernel', 'tile_sort': 'radix_scatter_kernel<unsigned short',
 }

@@ -356,13 +356,17 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     ba.to_chw = to_chw; ba.clamp_output = clamp_output;
     uint32_t n_buckets_cap = 0;
     // K8+K9 (fwd:218-231) and K10's tile plan in one single-workgroup kernel; every mode (the inference blend is planned the same way)
-    if (g_library_bucket_scan && training) {
+    if (!training && !(fgs::g_tile_row_group == static_cast<int>(kPlannedBlocks) || fgs::g_tile_row_group == static_cast<int>(kBandsThroughPlan))) {
+        // inference with a closed-form tile mapping: no bucket scan, no plan
+    } else if (g_library_bucket_scan && training) {
         StageScope t(ST_BUCKET_SCAN, stream);
         FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));
     } else {
         StageScope t(ST_BUCKET_SCAN, stream);
-        FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, tb.tile_plan, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
-        ba.tile_plan = tb.tile_plan;
+        // the block plan is made only when that mapping is selected (A/B, fgs_debug_set_option(10, 254)); the default mapping is closed-form
+        const bool plan = fgs::g_tile_row_group == static_cast<int>(kPlannedBlocks) || fgs::g_tile_row_group == static_cast<int>(kBandsThroughPlan);
+        FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, plan ? tb.tile_plan : nullptr, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
+        ba.tile_plan = plan ? tb.tile_plan : nullptr;
     }
     ba.grid_h = geo.grid_h;
     if (training) {
@@ -1051,9 +1055,10 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
-        case 10: if (value < 0 || (value > 64 && value != 255 && value != 254)) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
+        case 10: if (value < 0 || (value > 64 && (value < 251 || value > 255))) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
                  fgs::g_tile_row_group = value; return FGS_OK;
         case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
+        case 12: fgs::g_plan_experiment = value & 3; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

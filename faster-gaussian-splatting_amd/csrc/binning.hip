@@ -383,29 +383,45 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // walks its blocks in the order received = heaviest first, so the kernel's tail consists of the lightest blocks.
 __global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ bucket_offsets,
                                                                       uint32_t* __restrict__ tile_plan, const uint32_t n_tiles,
-                                                                      const uint32_t grid_w, const uint32_t grid_h) {
+                                                                      const uint32_t grid_w, const uint32_t grid_h, const int experiment) {
     __shared__ TileScanShared s_scan;
     __shared__ uint32_t s_weight[kPlanBlocks], s_sorted[kPlanBlocks];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid < kPlanBlocks) s_weight[tid] = 0u;
     uint32_t base = 0;
-    for (uint32_t t0 = 0; t0 < n_tiles; t0 += kTileScanThreads * kTileScanChunks) {          // one pass at 1080p (12 240 tiles)
-        uint32_t nb[kTileScanChunks], ex[kTileScanChunks];
+    int parity = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += kTileScanThreads * kTileScanPerThread, parity ^= 1) {   // one pass at 1080p (12 240 tiles)
+        uint32_t nb[kTileScanPerThread], ex[kTileScanPerThread];
+        const uint32_t first = t0 + tid * kTileScanPerThread;
+        if (first + kTileScanPerThread <= n_tiles) {                                         // 128 contiguous bytes: eight 16-byte loads
+            const uint4* q = reinterpret_cast<const uint4*>(ranges + first);
 #pragma unroll
-        for (int c = 0; c < kTileScanChunks; ++c) {
-            const uint32_t t = t0 + static_cast<uint32_t>(c) * kTileScanThreads + tid;
-            uint2 r = make_uint2(0u, 0u);
-            if (t < n_tiles) r = ranges[t];
-            nb[c] = (r.y - r.x + kBucket - 1) / kBucket;                                      // kf:350-360
+            for (int k = 0; k < kTileScanPerThread / 2; ++k) {
+                const uint4 r = q[k];
+                nb[2 * k] = (r.y - r.x + kBucket - 1) / kBucket;                              // kf:350-360
+                nb[2 * k + 1] = (r.w - r.z + kBucket - 1) / kBucket;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTileScanPerThread; ++k) {
+                uint2 r = make_uint2(0u, 0u);
+                if (first + k < n_tiles) r = ranges[first + k];
+                nb[k] = (r.y - r.x + kBucket - 1) / kBucket;
+            }
         }
-        const uint32_t total = tile_scan_pass(nb, ex, s_scan, base);
+        const uint32_t total = tile_scan_pass(nb, ex, s_scan, base, parity);
+        if (first + kTileScanPerThread <= n_tiles) {
+            uint4* o = reinterpret_cast<uint4*>(bucket_offsets + first);                      // inclusive (fwd:225-231)
 #pragma unroll
-        for (int c = 0; c < kTileScanChunks; ++c) {
-            const uint32_t t = t0 + static_cast<uint32_t>(c) * kTileScanThreads + tid;
-            if (t < n_tiles) bucket_offsets[t] = ex[c] + nb[c];                               // inclusive (fwd:225-231)
+            for (int k = 0; k < kTileScanPerThread / 4; ++k)
+                o[k] = make_uint4(ex[4 * k] + nb[4 * k], ex[4 * k + 1] + nb[4 * k + 1], ex[4 * k + 2] + nb[4 * k + 2], ex[4 * k + 3] + nb[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTileScanPerThread; ++k) if (first + k < n_tiles) bucket_offsets[first + k] = ex[k] + nb[k];
         }
         base += total;
     }
+    if (tile_plan == nullptr) return;                                                        // the default mapping of K10 is closed-form: no plan
     __syncthreads();                                                                         // bucket_offsets visible to the workgroup
     // block weights: one (block, tile row) pair per work item -- a difference of two scan values
     const uint32_t bw = (grid_w + kPlanBlocksX - 1) / kPlanBlocksX, bh = (grid_h + kPlanBlocksY - 1) / kPlanBlocksY;
@@ -428,7 +444,7 @@ __global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint
             const uint32_t wo = s_weight[o];
             rank += (wo > w || (wo == w && o < tid)) ? 1u : 0u;
         }
-        s_sorted[rank] = tid;
+        s_sorted[(experiment & 1) ? tid : rank] = tid;                                       // experiment bit 0: no sort (blocks in natural order)
     }
     __syncthreads();
     if (tid < kWave) {                                                                       // wave 0: the deal, lanes 0..7 = the XCDs
@@ -440,6 +456,7 @@ __global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint
                 const uint32_t lx = wave_read(load, x);
                 rank += (lx < load || (lx == load && static_cast<uint32_t>(x) < lane)) ? 1u : 0u;
             }
+            if (experiment & 1) rank = lane;                                                 // ... dealt statically: XCD x owns block column x
             if (lane < kXcds) {
                 const uint32_t b = s_sorted[round * kXcds + rank];                           // least work so far <- heaviest block of the round
                 load += s_weight[b];
@@ -450,9 +467,11 @@ __global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint
     }
 }
 
+std::atomic<int> g_plan_experiment{0};     // fgs_debug_set_option(12, bits): 1 = blocks unsorted and dealt statically (A/B of the deal itself)
 hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint32_t* tile_plan, uint32_t n_tiles, uint32_t grid_w, uint32_t grid_h,
                              hipStream_t s) {
-    hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kTileScanThreads), 0, s, ranges, bucket_offsets, tile_plan, n_tiles, grid_w, grid_h);
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kTileScanThreads), 0, s, ranges, bucket_offsets, tile_plan, n_tiles, grid_w, grid_h,
+                       g_plan_experiment.load());
     return hipGetLastError();
 }
 

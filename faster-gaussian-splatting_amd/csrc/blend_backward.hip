@@ -318,25 +318,37 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
 //      (kb:438), and dL/dmean2d = 2 [a b; b c] (sum(hh dx), sum(hh dy)) (kb:449-453) with hh = -alpha/2 dL/dalpha.
 //      About 50 VALU instructions per step remain.
 __global__ void __launch_bounds__(kTileScanThreads) plan_blend_backward_kernel(const BlendBackwardArgs a) {
-    // One workgroup: exclusive scan of the live-bucket count of every tile (fgs_tile_scan.h: a thread takes the tiles c * 1024 + tid of
-    // sixteen chunks at once, three barriers per 16 Ki tiles; the first version -- one barrier per 1024-tile chunk -- took 15 us at 1080p,
-    // all of it latency). live_offsets[tile] = first list slot of the tile; the entries themselves are written by stage_pixels_kernel
+    // One workgroup: exclusive scan of the live-bucket count of every tile (fgs_tile_scan.h: a thread sums 16 consecutive tiles, one DPP wave
+    // scan, one barrier per 16 Ki tiles; the first version -- one barrier per 1024-tile chunk -- took 15 us at 1080p, all of it latency). live_offsets[tile] = first list slot of the tile; the entries themselves are written by stage_pixels_kernel
     // (a single workgroup writing 115 k entries took 58 us on the layered scene).
     __shared__ TileScanShared s_scan;
     const unsigned tid = threadIdx.x;
     uint32_t base = 0;                                        // live buckets in front of the current pass (uniform)
-    for (unsigned t0 = 0; t0 < a.n_tiles; t0 += kTileScanThreads * kTileScanChunks) {
-        uint32_t nl[kTileScanChunks], ex[kTileScanChunks];
+    int parity = 0;
+    for (unsigned t0 = 0; t0 < a.n_tiles; t0 += kTileScanThreads * kTileScanPerThread, parity ^= 1) {
+        uint32_t nl[kTileScanPerThread], ex[kTileScanPerThread];
+        const unsigned first = t0 + tid * kTileScanPerThread;
+        const bool whole = first + kTileScanPerThread <= a.n_tiles;
+        if (whole) {
+            const uint4* q = reinterpret_cast<const uint4*>(a.max_n_processed + first);        // 64 contiguous bytes
 #pragma unroll
-        for (int c = 0; c < kTileScanChunks; ++c) {
-            const unsigned t = t0 + static_cast<unsigned>(c) * kTileScanThreads + tid;
-            nl[c] = t < a.n_tiles ? (a.max_n_processed[t] + kBucket - 1) / kBucket : 0u;          // live buckets of the tile (kb:295)
+            for (int k = 0; k < kTileScanPerThread / 4; ++k) {
+                const uint4 m = q[k];
+                nl[4 * k] = (m.x + kBucket - 1) / kBucket; nl[4 * k + 1] = (m.y + kBucket - 1) / kBucket;   // live buckets of the tile (kb:295)
+                nl[4 * k + 2] = (m.z + kBucket - 1) / kBucket; nl[4 * k + 3] = (m.w + kBucket - 1) / kBucket;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTileScanPerThread; ++k) nl[k] = first + k < a.n_tiles ? (a.max_n_processed[first + k] + kBucket - 1) / kBucket : 0u;
         }
-        const uint32_t total = tile_scan_pass(nl, ex, s_scan, base);
+        const uint32_t total = tile_scan_pass(nl, ex, s_scan, base, parity);
+        if (whole) {
+            uint4* o = reinterpret_cast<uint4*>(a.live_offsets + first);
 #pragma unroll
-        for (int c = 0; c < kTileScanChunks; ++c) {
-            const unsigned t = t0 + static_cast<unsigned>(c) * kTileScanThreads + tid;
-            if (t < a.n_tiles) a.live_offsets[t] = ex[c];
+            for (int k = 0; k < kTileScanPerThread / 4; ++k) o[k] = make_uint4(ex[4 * k], ex[4 * k + 1], ex[4 * k + 2], ex[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTileScanPerThread; ++k) if (first + k < a.n_tiles) a.live_offsets[first + k] = ex[k];
         }
         base += total;
     }

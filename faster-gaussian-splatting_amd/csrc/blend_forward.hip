@@ -30,11 +30,19 @@ namespace fgs {
 // g = 1 0.663 / 0.646, g = 2 0.654 / 0.633 -- there balance wins 10 %. Bands walked bottom-up (255): no difference. Which of the two a scene
 // wants depends on how deep its tiles blend, which the host does not know at launch: the DEFAULT stays the bands (the benchmark workload),
 // fgs_debug_set_option(10, g) selects the other. Returns n_tiles for padding workgroups.
-// Round 3 (the default, row_group == kPlannedBlocks): the mapping is DATA -- plan_tiles_kernel (binning.hip) cuts the tile grid into 8 x 10
-// rectangular blocks, weighs them by their bucket counts on the device and deals them to the XCDs (heaviest first, least-loaded XCD first);
-// this function only looks its block up. Locality of the bands, balance of the interleaved rows, no host read.
+// Round 3, measured on one box (tools/ab_tile_plan.py, profiles/r03_ab_tile_plan.txt; training blend S2 / layered scene, ms):
+//   bands (round 1/2 default)                          0.168 / 0.765
+//   single rows interleaved                            0.179 / 0.657
+//   8 x 10 blocks weighed on the device by their bucket counts, sorted, dealt heaviest-first to the least-loaded XCD
+//   (row_group == kPlannedBlocks, plan_tiles_kernel)   0.181 / 0.646   -- balance, but the scattered block order costs S2 what rows cost
+//   the same blocks in natural order, XCD x = block column x          0.164 / 0.673
+//   COLUMNS (kColumnsTopDown, the default now): XCD x owns the vertical strip of tile columns [x w, (x + 1) w), w = ceil(grid_w / 8),
+//   and walks it row by row from the top                              0.164 / 0.669   (bottom-up: 0.177 / 0.695)
+// The work gradient of a rendered view is vertical (sky on top, near ground at the bottom), so a vertical strip per XCD is balanced by
+// construction and as compact as a band: -2 % at S2 and -12 % on the layered scene against the bands, closed form, no device data. The
+// device-side plan stays as an A/B option (it wins 3 % more on the layered scene and loses 10 % at S2).
 constexpr unsigned kBandsBottomFirst = 255u;     // row_group value: the round-1 bands, each walked from its last tile to its first
-std::atomic<int> g_tile_row_group{static_cast<int>(kPlannedBlocks)};
+std::atomic<int> g_tile_row_group{static_cast<int>(kColumnsTopDown)};
 __device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, const unsigned grid_w, const unsigned n_tiles, const unsigned row_group,
                                                       const uint32_t* __restrict__ plan = nullptr, const unsigned grid_h = 0u) {
     if (row_group == kPlannedBlocks) {
@@ -47,6 +55,22 @@ __device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, cons
         const unsigned ly = local / bw, lx = local - ly * bw;
         const unsigned tx = (b % kPlanBlocksX) * bw + lx, ty = (b / kPlanBlocksX) * bh + ly;
         return (tx < grid_w && ty < grid_h) ? ty * grid_w + tx : n_tiles;
+    }
+    if (row_group == kColumnsTopDown || row_group == kColumnsBottomUp) {
+        // every XCD owns one vertical strip of the image, ceil(grid_w / 8) tiles wide, and walks it row by row: compact (the strip's rows
+        // follow each other in time, so a Gaussian's record is still in this XCD's L2 when the row below needs it), and balanced by
+        // construction against the dominant work gradient of a rendered scene -- the vertical one (sky / far background on top, near
+        // ground at the bottom): every XCD gets every image row
+        const unsigned bw = (grid_w + kXcds - 1) / kXcds;
+        const unsigned xcd = block % kXcds, q = block / kXcds;
+        const unsigned r = q / bw, c = q - r * bw;
+        const unsigned tx = xcd * bw + c, ty = row_group == kColumnsTopDown ? r : grid_h - 1u - r;
+        return (tx < grid_w && r < grid_h) ? ty * grid_w + tx : n_tiles;
+    }
+    if (row_group == kBandsThroughPlan) {                                                   // A/B: what does the plan's load alone cost?
+        const unsigned per_xcd = (n_tiles + kXcds - 1) / kXcds;
+        const unsigned tile = (block % kXcds) * per_xcd + block / kXcds + (plan[kPlanHeader + (block % kXcds) * kPlanBlocksPerXcd] >> 30);
+        return tile < n_tiles ? tile : n_tiles;
     }
     if (row_group == 0u || row_group == kBandsBottomFirst) {                                // one contiguous band per XCD, top-down or bottom-up
         const unsigned per_xcd = (n_tiles + kXcds - 1) / kXcds;
@@ -64,6 +88,8 @@ __device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, cons
     return row < n_rows ? row * grid_w + col : n_tiles;
 }
 static unsigned blend_grid(const BlendArgs& a) {
+    if (a.row_group == kColumnsTopDown || a.row_group == kColumnsBottomUp) return kXcds * ((a.grid_w + kXcds - 1) / kXcds) * a.grid_h;
+    if (a.row_group == kBandsThroughPlan) return ((a.n_tiles + kXcds - 1) / kXcds) * kXcds;
     if (a.row_group == kPlannedBlocks)
         return kPlanBlocks * ((a.grid_w + kPlanBlocksX - 1) / kPlanBlocksX) * ((a.grid_h + kPlanBlocksY - 1) / kPlanBlocksY);
     if (a.row_group == 0u || a.row_group == kBandsBottomFirst) return ((a.n_tiles + kXcds - 1) / kXcds) * kXcds;
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
 hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
     BlendArgs a = a_in;
     a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
-    if (a.tile_plan == nullptr && a.row_group == kPlannedBlocks) a.row_group = 0u;
+    if (a.tile_plan == nullptr && (a.row_group == kPlannedBlocks || a.row_group == kBandsThroughPlan)) a.row_group = 0u;
     hipLaunchKernelGGL(pruning_scores_kernel, dim3(blend_grid(a)), dim3(kBlendBlock), 0, s, a);
     return hipGetLastError();
 }
@@ -318,7 +344,7 @@ hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
 hipError_t launch_blend(bool training, const BlendArgs& a_in, hipStream_t s) {
     BlendArgs a = a_in;
     a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
-    if (a.tile_plan == nullptr && a.row_group == kPlannedBlocks) a.row_group = 0u;          // no plan was made: the bands
+    if (a.tile_plan == nullptr && (a.row_group == kPlannedBlocks || a.row_group == kBandsThroughPlan)) a.row_group = 0u;          // no plan was made: the bands
     const dim3 grid(blend_grid(a)), block(kBlendBlock);
     if (training) hipLaunchKernelGGL(blend_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(blend_kernel<false>, grid, block, 0, s, a);

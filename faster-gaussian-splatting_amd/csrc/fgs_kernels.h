@@ -64,6 +64,9 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // old or the new value, never a torn one).
 extern std::atomic<int> g_tile_row_group;            // blend_forward.hip: tile -> workgroup mapping (254: device-side block plan; 0: round-1 bands; 1..64 row groups)
 constexpr unsigned kPlannedBlocks = 254u;
+constexpr unsigned kColumnsTopDown = 252u, kColumnsBottomUp = 251u;   // one vertical strip of the image per XCD, walked row by row
+constexpr unsigned kBandsThroughPlan = 253u;         // A/B only: the round-1 bands, but with the plan's dependent load on every workgroup's path
+extern std::atomic<int> g_plan_experiment;
 extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
 extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);

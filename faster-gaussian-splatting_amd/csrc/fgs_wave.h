@@ -25,18 +25,26 @@ __device__ __forceinline__ float wave_read(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Inclusive prefix sum over the wave in 6 DPP-fused adds: a Hillis-Steele scan inside each 16-lane row (row_shr:1/2/4/8, lanes without a
+// source read 0), then row_bcast:15 carries a row's total into rows 1 and 3 and row_bcast:31 the total of rows 0-1 into rows 2 and 3 (the
+// gfx9 wave-scan idiom). Round 1/2 used __shfl_up (ds_bpermute through the LDS crossbar + a select per step: 18 instructions and six
+// LDS round trips); the single-workgroup planning kernels (fgs_tile_scan.h) spent most of their 15-19 us in those.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_read_u(unsigned x) {
+    return static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+    v += dpp_read_u<0x111 /*row_shr:1*/, 0xf>(v);
+    v += dpp_read_u<0x112 /*row_shr:2*/, 0xf>(v);
+    v += dpp_read_u<0x114 /*row_shr:4*/, 0xf>(v);
+    v += dpp_read_u<0x118 /*row_shr:8*/, 0xf>(v);
+    v += dpp_read_u<0x142 /*row_bcast:15*/, 0xa>(v);
+    v += dpp_read_u<0x143 /*row_bcast:31*/, 0xc>(v);
     return v;
 }
-// exclusive prefix sum over the wave (Hillis-Steele, 6 cross-lane steps)
-__device__ __forceinline__ unsigned wave_exclusive_sum(unsigned v) {
-    const unsigned lane = lane_id();
-    unsigned incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= static_cast<unsigned>(o)) incl += t; }
-    return incl - v;
+__device__ __forceinline__ unsigned wave_exclusive_sum(unsigned v) { return wave_inclusive_sum(v) - v; }
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum(v)), 63));
 }
 __device__ __forceinline__ unsigned wave_max(unsigned v) {
 #pragma unroll

@@ -58,6 +58,7 @@ inline unsigned wave_exclusive_sum(unsigned v) {
     for (int i = first; i < b.cur; ++i) if (b.lanes[i].gen_wave >= g) r += static_cast<unsigned>(b.lanes[i].slot[par][0]);
     return r;
 }
+inline unsigned wave_inclusive_sum(unsigned v) { return wave_exclusive_sum(v) + v; }
 inline unsigned wave_sum(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a + b; }); }
 inline unsigned wave_max(unsigned v) { return sim_reduce(v, [](unsigned a, unsigned b) { return a > b ? a : b; }); }
 

@@ -45,14 +45,23 @@ def test_tile_plan_covers_every_tile_and_balances_the_xcds(sim_backend, w, h, n)
     v = View(v.w2c, v.position, w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, 0.2, 1e4, torch.zeros(3))
     _, RS = helpers.settings_pair(v)
     gw, gh = (w + 15) // 16, (h + 11) // 12
-    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
-    dec = helpers.decode_forward(sim_backend, res, n, w, h)
-    info = helpers.check_tile_plan(dec['tile_plan'], dec['bucket_offsets'], gw, gh)
-    assert info['weights'].sum() == int(dec['bucket_offsets'][gw * gh - 1]) + gw * gh
-    inf = sim_backend.inference(*[p[k] for k in helpers.NAMES], RS, True, True, return_state=True)
-    lt = sim_backend.blob_layout(1, n, w, h, inf.state[1], inf.state[2])
-    plan = sim_backend.view(inf.buffers[1], lt, 'tile_plan', torch.int32).numpy().view(np.uint32)
-    assert np.array_equal(plan, dec['tile_plan'])
+    ref = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)                 # default mapping (closed-form columns)
+    assert sim_backend.lib.fgs_debug_set_option(10, 254) == 0                     # the block plan is an A/B option since the column mapping won
+    try:
+        res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+        dec = helpers.decode_forward(sim_backend, res, n, w, h)
+        info = helpers.check_tile_plan(dec['tile_plan'], dec['bucket_offsets'], gw, gh)
+        assert info['weights'].sum() == int(dec['bucket_offsets'][gw * gh - 1]) + gw * gh
+        assert torch.equal(res.image, ref.image)                                  # the mapping never changes a result
+        inf = sim_backend.inference(*[p[k] for k in helpers.NAMES], RS, True, True, return_state=True)
+        lt = sim_backend.blob_layout(1, n, w, h, inf.state[1], inf.state[2])
+        plan = sim_backend.view(inf.buffers[1], lt, 'tile_plan', torch.int32).numpy().view(np.uint32)
+        assert np.array_equal(plan, dec['tile_plan'])
+        for m in (0, 1, 251, 252):                                                # bands, interleaved rows, columns bottom-up / top-down
+            assert sim_backend.lib.fgs_debug_set_option(10, m) == 0
+            assert torch.equal(sim_backend.forward(*[p[k] for k in helpers.NAMES], RS).image, ref.image), m
+    finally:
+        sim_backend.lib.fgs_debug_set_option(10, 252)
 
 
 def test_wave_primitives_selftest(sim_backend):

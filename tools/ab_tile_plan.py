@@ -11,7 +11,7 @@ from harness import trainer as T
 sys.argv = ['bench.py']
 params, views, _ = bench.build_scene(bench.parse())
 dev = torch.device('cuda:0'); be = default_backend()
-VARIANTS = (('plan', 254, 0), ('bands', 0, 0), ('rows1', 1, 0), ('bands+rocprim-scan', 0, 1))
+VARIANTS = (('columns-top-down (default)', 252, 0, 0), ('bands', 0, 0, 0), ('bands+rocprim-scan', 0, 1, 0), ('plan', 254, 0, 0), ('rows1', 1, 0, 0))
 for shift in (0.0, -3.0):
     p2 = dict(params); p2['opacities'] = params['opacities'] + shift
     g = T.Gaussians(p2, dev)
@@ -21,8 +21,8 @@ for shift in (0.0, -3.0):
     tg = [T.render_image_benchmark(g, v).clone() * 0.9 for v in vs]
     res = {}
     for rnd in range(4):
-        for name, m, lib_scan in VARIANTS:
-            assert be.lib.fgs_debug_set_option(10, m) == 0 and be.lib.fgs_debug_set_option(11, lib_scan) == 0
+        for name, m, lib_scan, exp in VARIANTS:
+            assert be.lib.fgs_debug_set_option(10, m) == 0 and be.lib.fgs_debug_set_option(11, lib_scan) == 0 and be.lib.fgs_debug_set_option(12, exp) == 0
             for i in range(2): T.training_iteration(g, vs[i], tg[i], i)
             torch.cuda.synchronize(); be.profile_enable(True); be.profile_read()
             for i in range(8): T.training_iteration(g, vs[i], tg[i], 2 + i)
@@ -34,5 +34,5 @@ for shift in (0.0, -3.0):
     print(f'opacity shift {shift}: per round (blend_forward, bucket_scan / tile plan, stage_pixels incl. K11 plan, blend_backward, inference blend) ms')
     for name, v in res.items():
         best = [min(r[i] for r in v) for i in range(5)]
-        print(f'   {name:20s} best {best}   rounds {v}')
-be.lib.fgs_debug_set_option(10, 254); be.lib.fgs_debug_set_option(11, 0)
+        print(f'   {name:28s} best {best}   rounds {v}')
+be.lib.fgs_debug_set_option(10, 252); be.lib.fgs_debug_set_option(11, 0); be.lib.fgs_debug_set_option(12, 0)
