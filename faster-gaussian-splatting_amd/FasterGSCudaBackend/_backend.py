@@ -128,6 +128,12 @@ class Backend:
         if result.image.is_cuda:
             event = torch.cuda.Event()
             event.record(torch.cuda.current_stream(result.image.device))
+            # The copy is a raw hipMemcpyAsync that torch's caching host allocator knows nothing about: if the caller drops `host` before the
+            # copy has run (forward under no_grad, an exception, a freed graph), the pinned block would go back to the cache and the late copy
+            # would land in whoever got it next. Keep every buffer referenced here until its event has completed.
+            pending = self.__dict__.setdefault('_pending_counts', [])
+            pending[:] = [(h, e) for h, e in pending if not e.query()]
+            pending.append((host, event))
         return host, event
 
     def inference(self, means, scales, rotations, opacities, sh0, sh_rest, settings: RasterizerSettings, to_chw: bool,

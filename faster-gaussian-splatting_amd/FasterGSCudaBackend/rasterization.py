@@ -24,12 +24,15 @@ def set_gradient_buffers(provider) -> None:
 
 # ---- host-synchronisation-free training forward (fgs_forward_async) ------------------------------------------------------------------
 # The reference blocks the host three times per forward pass (forward.cu:100,102,234) to size its buffers; fgs_forward once. With
-# `set_async_forward(True)` the training path sizes the instance stages from what earlier passes needed -- the largest instances-per-
-# Gaussian ratio seen so far x the current Gaussian count x `headroom` -- and reads the counts back asynchronously; they are looked at in
-# `backward` (by then the copy has long completed). If a pass ever needs more than its capacity, its image was incomplete: backward repeats
-# the forward pass synchronously for the gradients and reports it (RuntimeWarning) -- with the default 25 % headroom that takes a jump of the
-# instance count between two consecutive iterations that training does not produce (densification grows N, and the bound scales with N).
-_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0}
+# `set_async_forward(True)` the training path sizes the instance stages from what an earlier pass OF THE SAME VIEW needed -- that view's
+# instances-per-Gaussian ratio x the current Gaussian count x `headroom` -- and reads the counts back asynchronously; they are looked at in
+# `backward` (by then the copy has long completed). A view that has not been seen yet (keyed by the address of its w2c tensor and the image
+# size), and any pass that does not need gradients (torch.no_grad(), detached inputs: nobody would ever look at the counts), takes the
+# synchronous path -- a ratio borrowed from other views overflows in the first epoch (round-2 advisor finding). If a pass still needs more
+# than its capacity (the instance count of one view jumped by more than the headroom between two of its visits), its image and therefore the
+# loss gradient were incomplete: backward reports it (RuntimeWarning), refreshes the view's ratio and returns ZERO gradients (and leaves
+# densification_info alone) -- mixing a re-rendered image with the gradient of a truncated one would be an inconsistent step.
+_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0, 'per_view': {}}
 
 # ---- live-block hand-over from this backward pass to FusedAdam.step ------------------------------------------------------------------
 # One third of the Gaussians is invisible in a view; their gradients are zeros that the backward pass writes (the gradient tensors are dense and
@@ -100,11 +103,17 @@ def match_live_blocks(gradients) -> 'torch.Tensor | None':
 def set_async_forward(enabled: bool, headroom: float = 1.25) -> None:
     _ASYNC.update(enabled=bool(enabled), headroom=float(headroom))
     if not enabled:
-        _ASYNC.update(ratio=0.0)
+        _ASYNC.update(ratio=0.0, per_view={})
 
 
 def async_forward_stats() -> dict:
-    return dict(_ASYNC)
+    """'ratio': the largest instances-per-Gaussian ratio of any view so far (informational); 'views': views with a recorded ratio."""
+    return {'enabled': _ASYNC['enabled'], 'headroom': _ASYNC['headroom'], 'ratio': _ASYNC['ratio'], 'overflows': _ASYNC['overflows'],
+            'views': len(_ASYNC['per_view'])}
+
+
+def _view_key(settings: RasterizerSettings):
+    return (settings.w2c.data_ptr(), int(settings.width), int(settings.height))
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -121,16 +130,21 @@ class _Rasterize(torch.autograd.Function):
                 rasterizer_settings: RasterizerSettings) -> torch.Tensor:
         _require_gpu(means)
         be, n = default_backend(), means.shape[0]
-        capacity = None
-        if _ASYNC['enabled'] and _ASYNC['ratio'] > 0.0 and n > 0:
-            capacity = int(_ASYNC['ratio'] * n * _ASYNC['headroom']) + 4096
+        capacity, key = None, None
+        if _ASYNC['enabled'] and n > 0:
+            key = _view_key(rasterizer_settings)
+            ratio = _ASYNC['per_view'].get(key, 0.0)
+            # only a pass whose backward will run ever looks at the asynchronous counts; everything else is checked now (synchronously)
+            if ratio > 0.0 and any(ctx.needs_input_grad[:6]):
+                capacity = int(ratio * n * _ASYNC['headroom']) + 4096
         res = be.forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings, capacity)
         if capacity is None:
-            if n > 0:
+            if key is not None:
+                _ASYNC['per_view'][key] = res.state[1] / n
                 _ASYNC['ratio'] = max(_ASYNC['ratio'], res.state[1] / n)
             ctx.async_check = None
         else:
-            ctx.async_check = be.forward_counts(res, n) + (sh_coefficients_0,)
+            ctx.async_check = be.forward_counts(res, n) + (key,)
         ctx.rasterizer_settings = rasterizer_settings
         ctx.buffer_state = res.state
         ctx.save_for_backward(res.image, means, scales, rotations, opacities, sh_coefficients_rest, *res.buffers)
@@ -144,18 +158,23 @@ class _Rasterize(torch.autograd.Function):
         image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
         state = ctx.buffer_state
         if ctx.async_check is not None:
-            host, event, sh0 = ctx.async_check
+            host, event, key = ctx.async_check
             if event is not None:
                 event.synchronize()
             n = means.shape[0]
+            _ASYNC['per_view'][key] = int(host[1]) / max(n, 1)
             _ASYNC['ratio'] = max(_ASYNC['ratio'], int(host[1]) / max(n, 1))
             if int(host[2]) != 0:          # the capacity was too small: the image (and the loss gradient) missed the instances beyond it
                 import warnings
                 _ASYNC['overflows'] += 1
-                warnings.warn(f'FasterGS async forward: {int(host[1])} instances exceeded the capacity {state[1]}; repeating the pass synchronously',
+                warnings.warn(f'FasterGS async forward: {int(host[1])} instances exceeded the capacity {state[1]} of this pass: its image was '
+                              f'incomplete, so this backward pass returns zero gradients (the view is rendered with the right capacity next time)',
                               RuntimeWarning)
-                res = default_backend().forward(means, scales, rotations, opacities, sh0, sh_rest, ctx.rasterizer_settings)
-                image, buffers, state = res.image, list(res.buffers), res.state
+                clear_live_blocks()
+                total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
+                zeros = tuple(torch.zeros(sh, dtype=torch.float32, device=means.device)
+                              for sh in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3)))
+                return (*zeros, None, None)
         n = means.shape[0]
         if _LIVE['enabled'] and _GRAD_OUT is None and n > 0:
             total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0

@@ -988,7 +988,8 @@ int32_t fgs_morton_order(const float* means, const float* lo, const float* hi, i
 
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
-    return sizeof(float) * (9 * static_cast<size_t>(width) * static_cast<size_t>(height) + l1_dssim_partials(width, height));
+    // three derivative maps, then the per-workgroup partial sums on an 8-byte boundary (read as float2: 9 W H is odd for odd x odd images)
+    return sizeof(float) * (((9 * static_cast<size_t>(width) * static_cast<size_t>(height) + 1) & ~static_cast<size_t>(1)) + l1_dssim_partials(width, height));
 }
 
 int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
@@ -998,7 +999,9 @@ int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width
     const size_t plane3 = 3 * static_cast<size_t>(width) * static_cast<size_t>(height);
     LossArgs a{};
     a.image = image; a.target = target; a.sums = sums; a.grad = grad_image;
-    a.d_mu = static_cast<float*>(scratch); a.d_m11 = a.d_mu + plane3; a.d_m12 = a.d_m11 + plane3; a.partials = a.d_m12 + plane3;
+    a.d_mu = static_cast<float*>(scratch); a.d_m11 = a.d_mu + plane3; a.d_m12 = a.d_m11 + plane3;
+    a.partials = a.d_mu + ((3 * plane3 + 1) & ~static_cast<size_t>(1));
+    if ((reinterpret_cast<uintptr_t>(a.partials) & 7u) != 0) return fail(FGS_ERR_INVALID_ARGUMENT, "scratch must be 8-byte aligned");
     a.width = width; a.height = height; a.lambda_l1 = lambda_l1; a.lambda_dssim = lambda_dssim;
     { StageScope t(ST_LOSS, stream); FGS_HIP(launch_l1_dssim(a, stream)); }
     return FGS_OK;

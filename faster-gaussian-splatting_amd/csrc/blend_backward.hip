@@ -375,15 +375,22 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
     // 32-byte lane stride the 16-byte read conflicts every 8 lanes and the 8-byte read four-fold -- SQ_LDS_BANK_CONFLICT 2.3 M -> 42.6 M
     // cycles per launch at S2, LDS busy 34 M -> 86 M, which ate the whole gain (profiles/r02_pmc_k11_lds.txt). 6.7 KB of LDS per wave
     // instead of 5.1: no effect on this kernel up to 8.2 KB (profiles/r02_k11_occupancy.txt).
-    __shared__ float4 s_pix_all[kCompactWaves][kTilePixels + 1];
-    __shared__ float2 s_xy_all[kCompactWaves][kTilePixels + 1];
-    float4* const s_pix = s_pix_all[wave_in_group];
-    float2* const s_xy = s_xy_all[wave_in_group];
+    // Round 3: the two arrays are RINGS of kRing = 256 slots (live pixels in [0, n_px), sentinels with rel 0 behind them): lane l reads slot
+    // (step - l) mod 256, which is a sentinel both before the lane's first pixel arrives (negative -> 193..255) and after its last one has
+    // passed (n_px .. n_px + 62 <= 254). The per-step index arithmetic was five vector instructions (step - lane, + look-ahead, unsigned min
+    // against n_px, two shifts for the two strides); on the ring it is three: the byte offset into the 8-byte ring walks by 8 and wraps
+    // (add, and), the 16-byte ring's offset is one shift-add of it. ONE shared block per wave with the 8-byte ring at offset 0, so that its
+    // address IS the ring offset (no base to add): [xy 2 KB | pix 4 KB | inj 2 KB] = 8 KB.
+    constexpr unsigned kRing = 256;
+    constexpr unsigned kXyBytes = kRing * 8u, kPixBytes = kRing * 16u, kInjBytes = (kTilePixels + kWave) * 8u;
+    __shared__ __attribute__((aligned(16))) char s_block[kCompactWaves][kXyBytes + kPixBytes + kInjBytes];
+    char* const s_base = s_block[wave_in_group];
+    float2* const s_xy = reinterpret_cast<float2*>(s_base);
+    float4* const s_pix = reinterpret_cast<float4*>(s_base + kXyBytes);
     // T_ckpt, S - g_w: enters the pipeline at lane 0. Slots n_px .. n_px + 63 are zero: lane 0 reads slot (step + 1) without a clamp
     // until the last step, and lanes 1..63 read slot n_px (zero) in every step, which makes "shift up by one lane, inject at lane 0"
     // ONE DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
-    __shared__ float2 s_inj_all[kCompactWaves][kTilePixels + kWave];
-    float2* const s_inj = s_inj_all[wave_in_group];
+    float2* const s_inj = reinterpret_cast<float2*>(s_base + kXyBytes + kPixBytes);
     const unsigned n_live = *a.live_count;
     const float lane_f = static_cast<float>(lane);
     const bool lane0 = lane == 0;
@@ -429,7 +436,9 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
                 }
                 n_px += static_cast<unsigned>(__popcll(m));
             }
-            if (lane0) { s_pix[n_px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[n_px] = make_float2(0.0f, 0.0f); }   // rel_last 0: never contributes
+            for (unsigned sl = n_px + lane; sl < kRing; sl += kWave) {          // sentinels (rel_last 0: never contributes): 1 to 4 rounds
+                s_pix[sl] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[sl] = make_float2(0.0f, 0.0f);
+            }
             s_inj[n_px + lane] = make_float2(0.0f, 0.0f);
         }
 
@@ -455,6 +464,11 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             hot_slot_word = __float_as_uint(r2.w);
         }
         wave_lds_fence();
+        // exponent of the Gaussian in base 2 with the constants folded per lane (kb:415-418): -1/2 d^T Sigma^-1 d * log2(e) =
+        // dx (A dx + B dy) + C dy dy -- five instructions and a bare v_exp_f32 per step instead of six, a multiply by log2(e) and the
+        // v_exp_f32 that __expf expands to. alpha differs from the forward pass's by a rounding (1e-7 relative), like any re-association.
+        constexpr float kLog2e = 1.4426950408889634f;
+        const float eA = (-0.5f * kLog2e) * ca, eB = -kLog2e * cb, eC = (-0.5f * kLog2e) * cc;
 
         float a_c0 = 0.0f, a_c1 = 0.0f, a_c2 = 0.0f;                 // sum w g_c               (kb:426-427 without the clamp gate)
         float a_h = 0.0f, a_x = 0.0f, a_y = 0.0f;                     // sum hh, sum hh dx, sum hh dy
@@ -466,17 +480,15 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         // several times an FMA on this chip (tools/valu_rate.hip), and the empty-mask branch of the `if` is the wave-uniform skip.
         unsigned inj_slot = lane0 ? 0u : n_px;                        // lane 0: slot of the step; other lanes: the zero slot
         const unsigned inj_step = lane0 ? 1u : 0u;
-        // pixel slot of this lane in the step whose reads are issued next; negative (as unsigned: huge) or past the list -> the sentinel, with
-        // ONE unsigned min
-        unsigned pix_idx = static_cast<unsigned>(-static_cast<int>(lane));
+        // byte offset into the 8-byte ring of the slot this lane reads for the step whose reads are issued next: (step - lane) mod 256
+        unsigned ring_at = ((0u - lane) & (kRing - 1u)) * 8u;
         struct PixRead { float4 g; float2 xy; };
         auto read_inj = [&]() { const float2 v = s_inj[inj_slot]; inj_slot += inj_step; return v; };
         auto read_pix = [&]() {
-            const unsigned at = min(pix_idx, n_px);
-            ++pix_idx;
             PixRead r;
-            r.g = s_pix[at];
-            r.xy = s_xy[at];
+            r.xy = *reinterpret_cast<const float2*>(s_base + ring_at);
+            r.g = *reinterpret_cast<const float4*>(s_base + (2u * ring_at + kXyBytes));
+            ring_at = (ring_at + 8u) & (kXyBytes - 1u);
             return r;
         };
         auto step = [&](const float2 inj, const PixRead pr) {
@@ -485,8 +497,8 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             const float4 px = pr.g;
             const float rel = px.w;
             const float dx = mx - pr.xy.x, dy = my - pr.xy.y;
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float alpha = op * __expf(fminf(power, 0.0f));
+            const float power2 = dx * (eA * dx + eB * dy) + (eC * dy) * dy;
+            const float alpha = op * fast_exp2(fminf(power2, 0.0f));
             if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
                 const float T = sT;
                 const float w = T * alpha;

@@ -98,6 +98,7 @@ __device__ __forceinline__ void store_float4_nt(float* p, const float4 v) {
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); } // v_exp_f32, 1 ulp (__expf = this after a multiply by log2 e)
 
 // One step of the backward pixel pipeline for NV per-pixel values:
 //   feed[]  rotates down by one lane (lane l takes lane l+1, lane 63 takes lane 0)      -- DPP wave_rol:1

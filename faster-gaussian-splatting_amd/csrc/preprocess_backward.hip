@@ -420,11 +420,11 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
     const uint32_t count = (a.n - first < kWave ? a.n - first : kWave) * R * 3u;
     float* const out = sh.grad_sh_rest + (size_t)first * R * 3u;
     for (uint32_t e = 4u * lane; e < count; e += 4u * kWave) {
-        if (e + 4u <= count) {
+        if (e + 4u <= count && a.vector_ok) {                          // 16-byte stores need a 16-byte aligned gradient tensor (checked at launch)
             const float4 g = any_visible ? *reinterpret_cast<const float4*>(slice + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             *reinterpret_cast<float4*>(out + e) = g;
         } else {
-            for (uint32_t j = e; j < count; ++j) out[j] = any_visible ? slice[j] : 0.0f;
+            for (uint32_t j = e; j < count && j < e + 4u; ++j) out[j] = any_visible ? slice[j] : 0.0f;
         }
     }
 }
@@ -434,7 +434,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 hipError_t launch_backward_gradients(const PreprocessBackwardArgs& a_in, const ShRestArgs& sh, hipStream_t s) {
     if (a_in.n == 0) return hipSuccess;
     if (sh.total_sh_rest > 15) return hipErrorInvalidValue;
-    const PreprocessBackwardArgs& a = a_in;
+    PreprocessBackwardArgs a = a_in;
+    a.vector_ok = aligned16(sh.grad_sh_rest) ? 1 : 0;                  // a wave's block starts 64 * R * 12 bytes into the tensor: aligned iff the tensor is
     const dim3 grid((a.n + 255u) / 256u), block(256);
     if (sh.total_sh_rest == 15) hipLaunchKernelGGL(backward_gradients_kernel<15>, grid, block, 0, s, a, sh);
     else hipLaunchKernelGGL(backward_gradients_kernel<0>, grid, block, 0, s, a, sh);

@@ -52,9 +52,17 @@ def _moments(g: Gaussians):
     if opt is None:
         return None, None
     states = [opt.state.get(group['params'][0]) for group in opt.param_groups]
-    if not all(states):
+    complete = lambda st: bool(st) and st.get('exp_avg') is not None and st.get('exp_avg_sq') is not None
+    if not any(complete(st) for st in states):
         return None, None
-    by_name = {group['name']: st for group, st in zip(opt.param_groups, states)}
+    # Mixed case (a checkpoint saved a group without moments, or a group never received a gradient): the groups WITH state must keep their
+    # moments row-aligned with the parameters through the gather / scatter, so the others get the state Adam would create lazily -- zero
+    # moments, step 0 -- instead of everything being rebound without moments (stale row counts -> out-of-bounds reads in the next step).
+    for group, st in zip(opt.param_groups, states):
+        if not complete(st):
+            param = group['params'][0]
+            opt.state[param] = {'step': (st or {}).get('step', 0), 'exp_avg': torch.zeros_like(param), 'exp_avg_sq': torch.zeros_like(param)}
+    by_name = {group['name']: opt.state[group['params'][0]] for group in opt.param_groups}
     return [by_name[k]['exp_avg'] for k in PARAM_ORDER], [by_name[k]['exp_avg_sq'] for k in PARAM_ORDER]
 
 

@@ -314,3 +314,36 @@ def test_harness_densify_uses_the_device_passes(sim_backend):
     mask = torch.zeros(ga.means.shape[0], dtype=torch.bool); mask[::3] = True
     D.prune(ga, mask); D.prune(gb, mask, ops_backend=sim_backend)
     assert torch.equal(ga.sh_coefficients_rest, gb.sh_coefficients_rest)
+
+
+@pytest.mark.parametrize('device_passes', [False, True])
+def test_partial_optimizer_state_keeps_moments_row_aligned(sim_backend, device_passes):
+    """Round-2 advisor finding: with optimizer state on only SOME groups (a group that never received a gradient, a checkpoint saved
+    without one group's moments) the device passes used to rebind every group without moments, leaving the groups that had state with
+    moments of the OLD row count -- the next Adam step would read past them. Now the missing groups get the state Adam creates lazily
+    (zero moments) and every group goes through the same gather / scatter; the torch-op path leaves stateless groups stateless."""
+    g = _gaussians(150)
+    n = g.means.shape[0]
+    opt = g.optimizer
+    for grp in opt.param_groups:
+        if grp['name'] in ('rotations', 'sh_coefficients_rest'):
+            del opt.state[grp['params'][0]]
+    info = torch.zeros(2, n)
+    info[0] = 10.0
+    info[1, :20] = 10.0 * 1e-3
+    g.densification_info = info
+    with torch.no_grad():
+        g.scales[:20] = math.log(0.01)
+        g.opacities[50:60] = -10.0
+    be = sim_backend if device_passes else None
+    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0), ops_backend=be)
+    assert g.means.shape[0] == stats['total'] == n + 20 - 10
+    D.prune(g, torch.arange(g.means.shape[0]) % 3 == 0, ops_backend=be)
+    for grp in g.optimizer.param_groups:
+        p = grp['params'][0]
+        st = g.optimizer.state.get(p)
+        if grp['name'] in ('rotations', 'sh_coefficients_rest'):
+            assert not st or (st['exp_avg'].shape == p.shape and float(st['exp_avg'].abs().max()) == 0.0)
+        else:
+            assert st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape, grp['name']
+            assert float(st['exp_avg'][0].abs().max()) == 0.5        # survivors keep their moments

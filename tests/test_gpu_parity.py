@@ -459,9 +459,9 @@ def test_full_size_properties(hip_backend):
 
 
 def test_async_forward_through_the_public_operators(hip_backend, oracle):
-    """set_async_forward(True): after one synchronous pass the training forward issues no host wait (fgs_forward_async, capacity from the
-    instances-per-Gaussian ratio seen so far); image and gradients stay those of the synchronous path. With a headroom below 1 the capacity
-    is exceeded: backward notices, repeats the pass synchronously (RuntimeWarning) and still returns the right gradients."""
+    """set_async_forward(True): after one synchronous pass PER VIEW the training forward issues no host wait (fgs_forward_async, capacity from
+    that view's instances-per-Gaussian ratio); image and gradients stay those of the synchronous path. Passes without gradients are checked
+    synchronously. With a headroom below 1 the capacity is exceeded: backward notices (RuntimeWarning) and returns zero gradients."""
     import warnings
     from FasterGSCudaBackend import async_forward_stats, diff_rasterize, set_async_forward
     params, view = make_s0(n=3000)
@@ -479,18 +479,32 @@ def test_async_forward_through_the_public_operators(hip_backend, oracle):
     ref_image, _ = step()
     try:
         set_async_forward(True)
-        step()                                   # synchronous: establishes the ratio
-        assert async_forward_stats()['ratio'] > 0
+        step()                                   # first visit of this view: synchronous, records the view's ratio
+        st = async_forward_stats()
+        assert st['ratio'] > 0 and st['views'] == 1
         for _ in range(2):
             image, grads = step()                # asynchronous
             assert torch.equal(image, ref_image)
             _grads_close(grads, g)
         assert async_forward_stats()['overflows'] == 0
-        set_async_forward(True, headroom=0.4)    # capacity < need
+        # a pass that needs no gradient is checked synchronously: the image is complete whatever the recorded ratio says
+        set_async_forward(True, headroom=0.4)
+        with torch.no_grad():
+            img = diff_rasterize(*[params[k].to(DEV) for k in helpers.NAMES], torch.empty(0, device=DEV), RS)
+        assert torch.equal(img, ref_image) and async_forward_stats()['overflows'] == 0
+        # capacity < need (headroom 0.4): backward notices, warns and returns ZERO gradients -- never a gradient of a truncated image
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
             _, grads = step()
         assert any('exceeded the capacity' in str(x.message) for x in w) and async_forward_stats()['overflows'] == 1
+        assert all(float(t.abs().max()) == 0.0 for t in grads)
+        set_async_forward(True)                  # default headroom again: the refreshed ratio renders the view completely
+        image, grads = step()
+        assert torch.equal(image, ref_image)
         _grads_close(grads, g)
+        # another view (another w2c tensor) starts with its own synchronous pass
+        RS2 = RS._replace(w2c=RS.w2c.clone())
+        P = [torch.nn.Parameter(params[k].to(DEV)) for k in helpers.NAMES]
+        assert torch.equal(diff_rasterize(*P, torch.empty(0, device=DEV), RS2), ref_image) and async_forward_stats()['views'] == 2
     finally:
         set_async_forward(False)
