@@ -347,8 +347,7 @@ class Backend:
         acc = out if out is not None else torch.empty((n, 9), dtype=torch.float32, device=device)
         if acc.dtype != torch.float32 or acc.numel() < 9 * n or not acc.is_contiguous() or acc.device != device:
             raise RuntimeError('accumulator records must be contiguous float32 [n_records, 9]')
-        scratch = torch.empty(max(int(self.lib.fgs_records_backward_scratch_bytes(n, int(settings.width), int(settings.height))), 1),
-                              dtype=torch.uint8, device=device)
+        scratch = self._scratch(n, settings, device)
         st = _lib.ForwardState(*state)
         self._check(self.lib.fgs_backward_to_records(_ptr(grad_image), _ptr(image), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]),
                                                      _ptr(buffers[3]), scratch.data_ptr(), _ptr(acc), n, C.byref(S), C.byref(st),

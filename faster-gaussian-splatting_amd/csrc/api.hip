@@ -178,13 +178,6 @@ struct BackwardScratch {
 };
 
 std::atomic<int> g_seq_tiles{kSeqTiles};           // fgs_debug_set_option key 5
-// Renderer of the sharded path: record j of the concatenated records becomes primitive j + j / spread of the pipeline, i.e. one empty
-// slot after every `spread` records. On the single-GPU path a third of the primitive indices are invisible Gaussians -- gaps in the nine
-// accumulator planes K11 adds into -- and the same-line atomic rate bounds K11's tail; dense record slots pack 32 receivers into every
-// 128-byte line instead of ~21 (profiles/r03_ab_sharded_k11.txt). 0 = dense (round 1/2). fgs_debug_set_option(13, spread).
-std::atomic<int> g_record_spread{2};
-uint32_t record_slots(uint32_t n_records, int spread) { return spread > 0 ? n_records + n_records / static_cast<uint32_t>(spread) + 1u : n_records; }
-constexpr int kSpreadShift = 8;                    // fgs_forward_state::selector carries the spread of the pass above its low byte
 std::atomic<int> g_library_bucket_scan{0};         // fgs_debug_set_option key 11: 1 = rocPRIM scan for K8+K9 and no tile plan (round-2 form, A/B)
 std::atomic<int> g_fused_single_kernel{1};         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
@@ -652,8 +645,6 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
         return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_records=%d, n_instances=%d)", n_records, n_instances);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const uint32_t n = static_cast<uint32_t>(n_records);
-    const int spread = g_record_spread.load();
-    const uint32_t n_slots = record_slots(n, spread);
     const Geometry geo = geometry_of(settings->width, settings->height);
     Carver tile_size(nullptr);
     TileBuffers::carve(tile_size, geo.n_tiles, true);
@@ -662,17 +653,15 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
     Carver tile_c(tile_blob);
     TileBuffers tb = TileBuffers::carve(tile_c, geo.n_tiles, true);
     Carver prim_size(nullptr);
-    PrimitiveBuffers::carve(prim_size, n_slots);
+    PrimitiveBuffers::carve(prim_size, n);
     void* prim_blob = resize(resize_user, FGS_BUF_PRIMITIVE, prim_size.total());
     if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
     Carver prim_c(prim_blob);
-    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n_slots);
+    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
     FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
-      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, static_cast<uint32_t>(spread), pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, stream)); }
-    const int rc = forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
-    if (rc == FGS_OK) state_out->selector |= spread << kSpreadShift;        // fgs_backward_to_records must find the same slots
-    return rc;
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, stream)); }
+    return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
 int32_t fgs_backward_to_records(const float* grad_image, const float* image,
@@ -680,24 +669,14 @@ int32_t fgs_backward_to_records(const float* grad_image, const float* image,
                                 void* scratch, float* acc_records_out, int32_t n_records,
                                 const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
     BackwardPlan P;
-    if (!state || n_records < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad state / n_records");
-    const int spread = state->selector >> kSpreadShift;
-    const int32_t n_slots = static_cast<int32_t>(record_slots(static_cast<uint32_t>(n_records), spread));
-    fgs_forward_state st = *state;
-    st.selector &= (1 << kSpreadShift) - 1;
-    if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_slots, settings, &st)) return rc;
+    if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_records, settings, state)) return rc;
     if (!grad_image || !image) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL image / grad_image");
     if (n_records == 0) return FGS_OK;
     if (!acc_records_out) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL acc_records_out");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (int rc = run_blend_backward(P, grad_image, image, n_slots, settings, &st, stream)) return rc;
-    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), static_cast<uint32_t>(n_slots), static_cast<uint32_t>(spread), acc_records_out, stream)); }
+    if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream)) return rc;
+    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), acc_records_out, stream)); }
     return FGS_OK;
-}
-
-size_t fgs_records_backward_scratch_bytes(int32_t n_records, int32_t width, int32_t height) {
-    if (n_records < 0) return 0;       // the largest spread any pass can have been rendered with (the option may change between the two calls)
-    return fgs_backward_scratch_bytes(static_cast<int32_t>(record_slots(static_cast<uint32_t>(n_records), 1)), width, height);
 }
 
 size_t fgs_shard_backward_scratch_bytes(int32_t n_primitives, int32_t n_views) {
@@ -1083,8 +1062,6 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
                  fgs::g_tile_row_group = value; return FGS_OK;
         case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
         case 12: fgs::g_plan_experiment = value & 3; return FGS_OK;
-        case 13: if (value < 0 || value > 64) return fail(FGS_ERR_INVALID_ARGUMENT, "record spread must be 0 (dense) or 1..64 (one empty slot per that many records)");
-                 g_record_spread = value; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

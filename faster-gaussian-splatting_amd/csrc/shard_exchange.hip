@@ -47,10 +47,7 @@ __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecor
 
 // Renderer side: the concatenated records of all shards become primitives 0..n-1 of a pipeline that starts at K2.
 // Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
-// `spread` > 0: record j becomes primitive j + j / spread -- one empty slot after every `spread` records, so that the accumulator planes K11 adds
-// into are as sparsely populated as on the single-GPU path (where invisible Gaussians leave the gaps); 0: primitive j.
-__device__ __forceinline__ uint32_t slot_of_record(uint32_t j, uint32_t spread) { return spread != 0u ? j + j / spread : j; }
-__global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, const uint32_t spread, PrimRec* __restrict__ rec,
+__global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, PrimRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
                                                                    uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles,
                                                                    uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count) {
@@ -76,25 +73,23 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
         if (lane == static_cast<unsigned>(leader)) base = atomicAdd(hot_count, static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hot_mask))));
         base = wave_read(base, leader);
         const unsigned slot = base + lanes_below(hot_mask);
-        if (hot && slot < kMaxHot) { hot_list[slot] = slot_of_record(j, spread); slot_word = slot + 1u; }
+        if (hot && slot < kMaxHot) { hot_list[slot] = j; slot_word = slot + 1u; }
     }
     if (!in_range) return;
-    const uint32_t p = slot_of_record(j, spread);
-    uint4* r = reinterpret_cast<uint4*>(rec + p);
+    uint4* r = reinterpret_cast<uint4*>(rec + j);
     r[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
     r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
     r[2] = make_uint4(w4.x, w4.y, w5.x, slot_word);
-    depth_keys[j] = w6.x; prim_idx[j] = p; n_touched[p] = w6.y;
+    depth_keys[j] = w6.x; prim_idx[j] = j; n_touched[j] = w6.y;
 }
 
 // planar accumulators [9][n] (what K11 adds into) -> one 36-byte record per record j, ready to be cut into per-shard segments
-__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, uint32_t n_slots, uint32_t spread, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, float* __restrict__ out) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n) return;
-    const uint32_t p = slot_of_record(j, spread);
     float v[kAccRecordWords];
 #pragma unroll
-    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n_slots + p];
+    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n + j];
 #pragma unroll
     for (int k = 0; k < kAccRecordWords; ++k) out[(size_t)kAccRecordWords * j + k] = v[k];
 }
@@ -106,16 +101,16 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, uint32_t spread, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
+hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
                                        uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, hipStream_t s) {
     const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, spread, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_acc(const float* acc, uint32_t n, uint32_t n_slots, uint32_t spread, float* out, hipStream_t s) {
+hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, n, n_slots, spread, out);
+    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, n, out);
     return hipGetLastError();
 }
 

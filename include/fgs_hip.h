@@ -191,9 +191,7 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
                                  float* image, fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
 
 /* K11 over the buffers of fgs_forward_from_records; acc_records_out[n_records] (36 bytes each, record order).
- * scratch: fgs_records_backward_scratch_bytes(n_records, width, height) -- the renderer spreads the records over more primitive
- * slots than there are records (api.hip: g_record_spread), so this is larger than fgs_backward_scratch_bytes(n_records, ...). */
-size_t fgs_records_backward_scratch_bytes(int32_t n_records, int32_t width, int32_t height);
+ * scratch: fgs_backward_scratch_bytes(n_records, width, height). */
 int32_t fgs_backward_to_records(const float* grad_image, const float* image,
                                 void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
                                 void* scratch, float* acc_records_out, int32_t n_records,

@@ -30,8 +30,7 @@ for vi, v in enumerate(views):
         be.backward_to_records(gl, res.image, res.buffers, S, res.state, 15)
         return res.state
     out = {}
-    for name, fn, spread in (('whole', whole, 0), ('cut dense', cut, 0), ('cut spread 2', cut, 2), ('cut spread 1', cut, 1), ('cut spread 4', cut, 4)):
-        assert be.lib.fgs_debug_set_option(13, spread) == 0
+    for name, fn in (('whole', whole), ('cut', cut)):
         for _ in range(2): st = fn()
         torch.cuda.synchronize(); be.profile_enable(True); be.profile_read()
         for _ in range(4): fn()
