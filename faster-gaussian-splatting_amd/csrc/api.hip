@@ -37,10 +37,10 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-stage timing with HIP events recorded on the caller's stream (fgs_profile_enable / fgs_profile_read) ----
 enum Stage { ST_PREPROCESS, ST_DEPTH_SORT, ST_OFFSETS_SCAN, ST_CREATE_INSTANCES, ST_TILE_SORT, ST_RANGES, ST_BUCKET_SCAN,
-             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_RECORDS, ST_FUSED_BACKWARD_ADAM, ST_SH_COLOUR, ST_COUNT };
+             ST_BLEND_FORWARD, ST_STAGE_PIXELS, ST_BLEND_BACKWARD, ST_PREPROCESS_BACKWARD, ST_SH_REST_BACKWARD, ST_ADAM, ST_LOSS, ST_RECORDS, ST_FUSED_BACKWARD_ADAM, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "offsets_scan", "create_instances", "tile_sort", "extract_ranges",
                                            "bucket_scan", "blend_forward", "stage_pixels", "blend_backward", "preprocess_backward",
-                                           "sh_rest_backward", "adam", "l1_dssim_loss", "shard_records", "fused_backward_adam", "sh_colour_overlapped"};
+                                           "sh_rest_backward", "adam", "l1_dssim_loss", "shard_records", "fused_backward_adam"};
 struct StageRecord { int stage; hipEvent_t start, stop; };
 struct Profiler {
     bool enabled = false;
@@ -232,24 +232,6 @@ CounterReadback* counter_readback() {
     return (c.host && c.ready) ? &c : nullptr;
 }
 
-// A second stream for work that is independent of the caller's stream for a while (fork: the side stream waits for `fork`, recorded on the
-// caller's stream; join: the caller's stream waits for `join`, recorded on the side stream): the SH colour of the visible Gaussians during
-// K2-K9, the clearing of the backward accumulators during the pixel staging pass. Per (host thread, device) like the read-back slot.
-// fgs_debug_set_option(14, 0) runs everything on the caller's stream (A/B).
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-std::atomic<int> g_overlap{1};
-SideStream* side_stream() {
-    if (!g_overlap) return nullptr;
-    thread_local SideStream slots[kMaxDevices];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    SideStream& c = slots[dev];
-    if (!c.stream && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) c.stream = nullptr;
-    if (!c.fork && hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) c.fork = nullptr;
-    if (!c.join && hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) c.join = nullptr;
-    return (c.stream && c.fork && c.join) ? &c : nullptr;
-}
-
 AdamHyper adam_hyper(int step, double lr, double beta1, double beta2, double eps) {   // adam.cu:52-54
     const double bc1_rcp = 1.0 / (1.0 - std::pow(beta1, step));
     const double bc2_sqrt_rcp = 1.0 / std::sqrt(1.0 - std::pow(beta2, step));
@@ -265,8 +247,7 @@ enum ForwardMode { MODE_TRAINING, MODE_INFERENCE, MODE_SCORES };
 
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
                  uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
-                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts = false,
-                 hipEvent_t join_before_blend = nullptr);
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts = false);
 
 int run_forward(ForwardMode mode, const float* means, const float* scales, const float* rotations, const float* opacities,
                 const float* sh0, const float* sh_rest, int32_t n_primitives, const fgs_settings* settings, float* image,
@@ -303,16 +284,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     pa.hot_list = pb.hot_list;
     pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles; pa.seq_tiles = g_seq_tiles;
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
-    SideStream* const side = n > 0 ? side_stream() : nullptr;
-    { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, side == nullptr, pa, stream)); }
-    hipEvent_t colour_done = nullptr;
-    if (side != nullptr) {            // the colour floats of the records: on the side stream, joined in forward_tail right before the blend
-        FGS_HIP(hipEventRecord(side->fork, stream));
-        FGS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-        { StageScope t(ST_SH_COLOUR, side->stream); FGS_HIP(launch_sh_colour(!training, pa, side->stream)); }
-        FGS_HIP(hipEventRecord(side->join, side->stream));
-        colour_done = side->join;
-    }
+    { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
 
     if (instance_capacity > 0) {
         // Host-synchronisation-free form (fgs_forward_async): nothing is read back. Every launch behind K1 is sized by a bound -- the
@@ -325,7 +297,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
             FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), stream));
         }
         return forward_tail(mode, pb, tb, geo, n, static_cast<uint32_t>(instance_capacity), depth_sel, settings, image, to_chw, clamp_output, resize, user,
-                            state_out, stream, scores, true, colour_done);
+                            state_out, stream, scores, true);
     }
 
     // the one host read of the pass: V and I (fwd:99-102). The depth sort does not need them on the host (radix_sort.hip reads
@@ -344,16 +316,14 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     FGS_HIP(hipEventSynchronize(ready));
     const uint32_t n_visible = host[0], n_instances = host[1];
 
-    return forward_tail(mode, pb, tb, geo, n_visible, n_instances, depth_sel, settings, image, to_chw, clamp_output, resize, user, state_out, stream, scores,
-                        false, colour_done);
+    return forward_tail(mode, pb, tb, geo, n_visible, n_instances, depth_sel, settings, image, to_chw, clamp_output, resize, user, state_out, stream, scores);
 }
 
 // K2..K10 over a filled primitive buffer (rec, n_touched, depth keys + indices of the n_visible visible entries; depth_sel >= 0:
 // already depth-sorted, the sorted half is depth_sel)
 int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuffers& tb, const Geometry& geo, uint32_t n_visible,
                  uint32_t n_instances, int depth_sel, const fgs_settings* settings, float* image, int to_chw, int clamp_output,
-                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts,
-                 hipEvent_t join_before_blend) {
+                 fgs_resize_fn resize, void* user, fgs_forward_state* state_out, hipStream_t stream, float* scores, bool device_counts) {
     const bool training = mode == MODE_TRAINING;
     PrimitiveBuffers pb = pb_in;
     // device_counts: n_visible / n_instances are BOUNDS (primitive count / caller's instance capacity); the exact counts stay on the device:
@@ -411,7 +381,6 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
         ba.bucket_offsets = tb.bucket_offsets; ba.final_T = tb.final_T; ba.n_processed = tb.n_processed;
         ba.max_n_processed = tb.max_n_processed; ba.bucket_tile = bb.tile_index; ba.ckpt = bb.ckpt;
     }
-    if (join_before_blend != nullptr) FGS_HIP(hipStreamWaitEvent(stream, join_before_blend, 0));      // the records' colours (side stream)
     if (mode == MODE_SCORES) { ba.scores = scores; StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_pruning_scores(ba, stream)); }
     else { StageScope t(ST_BLEND_FORWARD, stream); FGS_HIP(launch_blend(training, ba, stream)); }   // K10 (fwd:239)
 
@@ -445,17 +414,7 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
 int run_blend_backward(const BackwardPlan& P, const float* grad_image, const float* image, int32_t n_primitives,
                        const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream) {
     // replaces api:127-134: only the 9-float accumulators (and the hot Gaussians' replicas behind them) are cleared
-    // ... on the side stream, while the planning pass and the pixel staging run (108 MB at 3 M Gaussians); joined in front of K11
-    SideStream* const side = n_primitives > 0 ? side_stream() : nullptr;
-    const size_t acc_bytes = static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc));
-    if (side != nullptr) {
-        FGS_HIP(hipEventRecord(side->fork, stream));
-        FGS_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-        FGS_HIP(hipMemsetAsync(P.sc.acc, 0, acc_bytes, side->stream));
-        FGS_HIP(hipEventRecord(side->join, side->stream));
-    } else if (n_primitives > 0) {
-        FGS_HIP(hipMemsetAsync(P.sc.acc, 0, acc_bytes, stream));
-    }
+    if (n_primitives > 0) FGS_HIP(hipMemsetAsync(P.sc.acc, 0, static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc)), stream));
     BlendBackwardArgs a{};
     a.ranges = P.tb.ranges; a.bucket_offsets = P.tb.bucket_offsets; a.inst_prims = P.ib.prims[state->selector]; a.rec = P.pb.rec;
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
@@ -467,7 +426,6 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
     { StageScope t(ST_STAGE_PIXELS, stream); FGS_HIP(launch_stage_pixels(a, stream)); }
-    if (side != nullptr) FGS_HIP(hipStreamWaitEvent(stream, side->join, 0));
     { StageScope t(ST_BLEND_BACKWARD, stream); FGS_HIP(launch_blend_backward(a, stream)); }     // K11 (bwd:56)
     return FGS_OK;
 }
@@ -1104,7 +1062,6 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
                  fgs::g_tile_row_group = value; return FGS_OK;
         case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
         case 12: fgs::g_plan_experiment = value & 3; return FGS_OK;
-        case 14: g_overlap = value ? 1 : 0; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

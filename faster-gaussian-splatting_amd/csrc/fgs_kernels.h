@@ -25,9 +25,7 @@ struct PreprocessArgs {                 // K1
     int count_appended;                            // sharded path: counters[2] counts the huge-footprint entries appended to the list
     CameraArgs cam;
 };
-// with_colour = false: the records' colour floats are left to launch_sh_colour (a second stream, concurrent with K2-K9)
-hipError_t launch_preprocess(bool inference, bool with_colour, const PreprocessArgs& a, hipStream_t s);
-hipError_t launch_sh_colour(bool inference, const PreprocessArgs& a, hipStream_t s);
+hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s);
 // sharded path: the same Gaussians projected for up to kMaxBatchViews cameras in ONE launch (grid.y = view); a shard is too
 // small to fill the chip per view (3 M / 8 Gaussians = 733 workgroups) and 8 back-to-back launches measured 2.2x the time
 struct PreprocessBatch { int n_views; PreprocessArgs v[kMaxBatchViews]; };

@@ -38,11 +38,7 @@ __device__ unsigned long long g_k1_phase[kK1TimerWaves * 8];
 #define FGS_K1_FLUSH do { } while (0)
 #endif
 
-// COLOUR = false (round 3, the single-view paths): the SH colour is NOT evaluated here. Nothing between K1 and the blend needs it -- depth sort,
-// offsets, instances, tile sort and ranges work on depths, bounds and bitmaps -- so sh_colour_kernel fills the three colour floats of the
-// records on a second stream while that chain runs (api.hip: run_forward): reading and evaluating the 192 bytes of coefficients per visible
-// Gaussian was 0.06 ms of this kernel's 0.22 (profiles/r02_k1_sh_share.txt), and it took 45 floats' worth of registers with it.
-template <bool INFERENCE, bool COLOUR>
+template <bool INFERENCE>
 __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     FGS_K1_START;
     const Camera cam = load_camera(a.cam);
@@ -212,13 +208,11 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 if (hot && slot < kMaxHot) { a.hot_list[slot] = idx; slot_word = slot + 1u; }
             }
             if (visible || huge) {
-                float col[3] = {0.0f, 0.0f, 0.0f};
-                if (COLOUR) {
-                    const float* k = a.sh_rest + (size_t)idx * cam.total_sh_rest * 3;
-                    sh_to_color(a.sh0 + 3 * (size_t)idx, k, m[0] - cam.pos[0], m[1] - cam.pos[1], m[2] - cam.pos[2],
-                                (unsigned)cam.active_sh_bases, col);
-                    if (INFERENCE) { col[0] = fmaxf(col[0], 0.0f); col[1] = fmaxf(col[1], 0.0f); col[2] = fmaxf(col[2], 0.0f); }  // ki:200
-                }
+                float col[3];
+                const float* k = a.sh_rest + (size_t)idx * cam.total_sh_rest * 3;
+                sh_to_color(a.sh0 + 3 * (size_t)idx, k, m[0] - cam.pos[0], m[1] - cam.pos[1], m[2] - cam.pos[2],
+                            (unsigned)cam.active_sh_bases, col);
+                if (INFERENCE) { col[0] = fmaxf(col[0], 0.0f); col[1] = fmaxf(col[1], 0.0f); col[2] = fmaxf(col[2], 0.0f); }  // ki:200
                 float4* dst = reinterpret_cast<float4*>(a.rec + idx);
                 dst[0] = make_float4(m2x, m2y, ca, cb);
                 dst[1] = make_float4(cc, opacity, col[0], col[1]);
@@ -269,28 +263,9 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     FGS_K1_FLUSH;
 }
 
-template <bool INFERENCE, bool COLOUR>
-__global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE, COLOUR>(a); }
-__global__ void __launch_bounds__(kPreprocessBlock) preprocess_batch_kernel(const PreprocessBatch b) { preprocess_body<false, true>(b.v[blockIdx.y]); }
-
-// SH colour of the visible Gaussians (sh_utils.cuh:32-69; clamped at store for inference, ki:200) into the colour floats of their records:
-// rec words 6, 7, 8. Runs after preprocess_kernel<.., false> + preprocess_huge_kernel (n_touched final), concurrently with K2-K9.
 template <bool INFERENCE>
-__global__ void __launch_bounds__(256) sh_colour_kernel(const PreprocessArgs a) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    const bool visible = i < a.n && a.n_touched[i] != 0u;
-    if (wave_ballot(visible) == 0) return;                          // wave-uniform: a third of the Gaussians is culled, mostly in whole waves
-    if (!visible) return;
-    const Camera cam = load_camera(a.cam);
-    const float mx = a.means[3 * (size_t)i], my = a.means[3 * (size_t)i + 1], mz = a.means[3 * (size_t)i + 2];
-    float col[3];
-    sh_to_color(a.sh0 + 3 * (size_t)i, a.sh_rest + (size_t)i * cam.total_sh_rest * 3, mx - cam.pos[0], my - cam.pos[1], mz - cam.pos[2],
-                (unsigned)cam.active_sh_bases, col);
-    if (INFERENCE) { col[0] = fmaxf(col[0], 0.0f); col[1] = fmaxf(col[1], 0.0f); col[2] = fmaxf(col[2], 0.0f); }
-    float* r = reinterpret_cast<float*>(a.rec + i);
-    *reinterpret_cast<float2*>(r + 6) = make_float2(col[0], col[1]);
-    r[8] = col[2];
-}
+__global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE>(a); }
+__global__ void __launch_bounds__(kPreprocessBlock) preprocess_batch_kernel(const PreprocessBatch b) { preprocess_body<false>(b.v[blockIdx.y]); }
 
 // Exact tile count + compaction for the few screen-filling footprints: one 256-thread workgroup per Gaussian, 256 candidate
 // tiles per step (kernel_utils.cuh:117-180 with the whole workgroup cooperating instead of one warp).
@@ -331,22 +306,12 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
 __global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessArgs a) { preprocess_huge_body(a); }
 __global__ void __launch_bounds__(256) preprocess_huge_batch_kernel(const PreprocessBatch b) { preprocess_huge_body(b.v[blockIdx.y]); }
 
-hipError_t launch_preprocess(bool inference, bool with_colour, const PreprocessArgs& a, hipStream_t s) {
+hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);
-    if (inference && with_colour) hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, s, a);
-    else if (inference) hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, block, 0, s, a);
-    else if (with_colour) hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, block, 0, s, a);
+    if (inference) hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, s, a);
     hipLaunchKernelGGL(preprocess_huge_kernel, dim3(a.n < 1024u ? a.n : 1024u), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_sh_colour(bool inference, const PreprocessArgs& a, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
-    const dim3 grid((a.n + 255u) / 256u), block(256);
-    if (inference) hipLaunchKernelGGL(sh_colour_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(sh_colour_kernel<false>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 
