@@ -258,6 +258,8 @@ def main():
         return ViewParallelTrainer(be, full, lrs, mode=mode)
 
     vp = make_trainer(args.dp_mode) if use_dp else None
+    if vp is not None and hasattr(vp, 'time_comm'):
+        vp.time_comm = world > 1
     settings_of = {id(v): T.extract_settings(v, g.active_sh_bases, v.background_color) for v in views}
 
     def dp_step(trainer, mode: str, i: int) -> None:
@@ -347,6 +349,7 @@ def main():
             tb = float(tmax.item())
         block_ms.append(tb / args.steps * 1e3)
     headline_vram = peak_vram(reset=True)
+    exposed_comm_ms = vp.comm_ms_per_step() if (vp is not None and hasattr(vp, 'comm_ms_per_step') and world > 1) else None
     # who took part: every rank reports its device and the Gaussians it saw (proves N ranks ran)
     roster = None
     if dist.is_initialized():
@@ -479,7 +482,10 @@ def main():
                    'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if dist.is_initialized() else None,
                    'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
                    'device': f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
-                   'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0},
+                   'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0,
+                   # sharded exchange on rank 0: time inside the step's three exchanges (counts all-gather, records all-to-all, accumulators
+                   # all-to-all), averaged over all blocks incl. warm-up; nothing overlaps them (harness/sharded.py), so exposed = total
+                   'exposed_comm_ms_per_step': exposed_comm_ms},
         'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_note, 'avg_kernel_ms': dom_s * 1e3,
                      'algorithmic_bytes_per_launch': stage_bytes[dom],

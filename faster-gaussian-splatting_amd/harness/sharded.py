@@ -94,23 +94,55 @@ class ShardedTrainer:
         self.records = torch.empty((self.world, max(self.n, 1), _lib.SPLAT_RECORD_BYTES), dtype=torch.uint8, device=device)
         self.counts = torch.zeros((self.world, 2), dtype=torch.int32, device=device)
         self.last_counts = None       # [G shards, G views, 2] of the last step (host), for reporting
+        # Exposed communication time (bench.py --gpus N): the three exchanges of a step are bracketed by events when `time_comm` is set.
+        # Nothing overlaps them: a step is a chain (K1 -> counts -> records -> K2..K11 -> accumulators -> K12 + Adam), every phase needs
+        # ALL of the previous one's output (K12 sums a Gaussian's accumulators over the G views in registers), and the next step's K1 needs
+        # this step's parameter update -- so exposed = total.
+        self.time_comm, self._comm_events = False, []
 
     # ---- exchanges ------------------------------------------------------------------------------------------------
+    def _timed(self, fn):
+        if not (self.time_comm and self.device.type == 'cuda'):
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self._comm_events.append((a, b))
+        return out
+
+    def comm_ms_per_step(self) -> float:
+        """Mean time per step between the start and the end of the step's exchanges on this rank's stream (set time_comm = True first);
+        clears the record. Includes the wait for the slowest peer, as an exposed exchange does."""
+        if not self._comm_events or self.step_count == 0:
+            return 0.0
+        torch.cuda.synchronize(self.device)
+        total = sum(a.elapsed_time(b) for a, b in self._comm_events)
+        steps = max(len(self._comm_events) // 3, 1)              # three exchanges per step
+        self._comm_events = []
+        return total / steps
+
     def _all_to_all(self, pieces: Sequence[torch.Tensor], recv_rows: Sequence[int]) -> torch.Tensor:
         """pieces[j] goes to rank j; returns the concatenation of what ranks 0..G-1 sent here (rows along dim 0)."""
         if self.world == 1:
             return pieces[0]
-        send = torch.cat(list(pieces), dim=0)
-        recv = torch.empty((sum(recv_rows),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(recv, send, [int(x) for x in recv_rows], [int(p.shape[0]) for p in pieces], group=self.group)
-        return recv
+
+        def run():
+            send = torch.cat(list(pieces), dim=0)
+            recv = torch.empty((sum(recv_rows),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            dist.all_to_all_single(recv, send, [int(x) for x in recv_rows], [int(p.shape[0]) for p in pieces], group=self.group)
+            return recv
+        return self._timed(run)
 
     def _gather_counts(self) -> torch.Tensor:
         if self.world == 1:
             return self.counts.cpu().view(1, 1, 2)
-        table = torch.empty(self.world * self.world * 2, dtype=torch.int32, device=self.device)
-        dist.all_gather_into_tensor(table, self.counts.view(-1), group=self.group)
-        return table.cpu().view(self.world, self.world, 2)       # the one host synchronisation of the step
+
+        def run():
+            table = torch.empty(self.world * self.world * 2, dtype=torch.int32, device=self.device)
+            dist.all_gather_into_tensor(table, self.counts.view(-1), group=self.group)
+            return table
+        return self._timed(run).cpu().view(self.world, self.world, 2)       # the one host synchronisation of the step
 
     def image_gradient(self, image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         if self.loss == 'l1':
