@@ -50,42 +50,78 @@ __device__ __forceinline__ void stage_region(float (*dst)[kRegionH][kRegionW], c
     }
 }
 
-__global__ void __launch_bounds__(256) ssim_forward_kernel(const LossArgs a, const GaussWindow gw) {
+// LDS: the staged x / y region (14.1 KB) is dead once the horizontal pass has read it -- the L1 term of the tile's own pixels is taken there,
+// from registers -- so the fifth filtered map lives in ITS memory: 14.1 + 4 x 5.4 = 35.6 KB per workgroup instead of 41.0, i.e. four
+// workgroups per CU instead of three (160 KB), and the register budget is capped to match (FGS_LOSS_FWD_WAVES waves per SIMD). Round 2's
+// counters had this kernel at 9 resident waves per CU, 45 % of the issue slots, LDS busy a fifth of the time: latency-bound at low occupancy.
+#ifndef FGS_LOSS_FWD_WAVES
+#define FGS_LOSS_FWD_WAVES 4
+#endif
+#if FGS_LOSS_FWD_WAVES > 0
+#define FGS_LOSS_FWD_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGS_LOSS_FWD_WAVES, FGS_LOSS_FWD_WAVES)))
+#else
+#define FGS_LOSS_FWD_BOUNDS __launch_bounds__(256)
+#endif
+__global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const GaussWindow gw) {
+    constexpr int kMapFloats = kRegionH * kLossTileW;                                 // one horizontally filtered map
+    static_assert(2 * kRegionH * kRegionW >= kMapFloats + 8, "the fifth map and the reduction scratch fit in the staged region");
     __shared__ float sxy[2][kRegionH][kRegionW];
-    __shared__ float hz[5][kRegionH][kLossTileW];
-    __shared__ float s_red[2][4];
+    __shared__ float hz4[4][kRegionH][kLossTileW];
+    float (*const hz_last)[kLossTileW] = reinterpret_cast<float (*)[kLossTileW]>(&sxy[0][0][0]);      // map 4, written after the barrier below
+    float* const s_red = &sxy[0][0][0] + kMapFloats;                                   // 8 floats behind it
     const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ X = a.image + c * plane; const float* __restrict__ Y = a.target + c * plane;
     stage_region<2>(sxy, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? X[e] : Y[e]; });
     __syncthreads();
-    for (int item = threadIdx.x; item < kRegionH * kHzGroups; item += 256) {       // horizontal taps: 4 outputs from 14 inputs
-        const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
-        float p[14], q[14];
+    float l1_sum = 0.0f;
+    constexpr int kItems = kRegionH * kHzGroups, kItemsPerThread = (kItems + 255) / 256;
+    float keep[kItemsPerThread][4];                                                    // map 4 of this thread's items, until sxy may be overwritten
 #pragma unroll
-        for (int t = 0; t < 14; ++t) { p[t] = sxy[0][ry][cx + t]; q[t] = sxy[1][ry][cx + t]; }
+    for (int it = 0; it < kItemsPerThread; ++it) {                                     // horizontal taps: 4 outputs from 14 inputs
+        const int item = threadIdx.x + it * 256;
+        if (item < kItems) {
+            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+            float p[14], q[14];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            float m1 = 0.0f, m2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
+            for (int t = 0; t < 14; ++t) { p[t] = sxy[0][ry][cx + t]; q[t] = sxy[1][ry][cx + t]; }
+            const int gy = y0 + ry - kHalo;
+            const bool own_row = ry >= kHalo && ry < kHalo + kLossTileH && gy < a.height;
 #pragma unroll
-            for (int t = 0; t < kTaps; ++t) {
-                const float w = gw.w[t], pp = p[o + t], qq = q[o + t];
-                m1 += w * pp; m2 += w * qq; m11 += w * pp * pp; m22 += w * qq * qq; m12 += w * pp * qq;
+            for (int o = 0; o < 4; ++o) {
+                float m1 = 0.0f, m2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
+#pragma unroll
+                for (int t = 0; t < kTaps; ++t) {
+                    const float w = gw.w[t], pp = p[o + t], qq = q[o + t];
+                    m1 += w * pp; m2 += w * qq; m11 += w * pp * pp; m22 += w * qq * qq; m12 += w * pp * qq;
+                }
+                hz4[0][ry][cx + o] = m1; hz4[1][ry][cx + o] = m2; hz4[2][ry][cx + o] = m11; hz4[3][ry][cx + o] = m22;
+                keep[it][o] = m12;
+                if (own_row && x0 + cx + o < a.width) l1_sum += fabsf(p[o + kHalo] - q[o + kHalo]);     // the tile's own pixel (cx + o, ry - 5)
             }
-            hz[0][ry][cx + o] = m1; hz[1][ry][cx + o] = m2; hz[2][ry][cx + o] = m11; hz[3][ry][cx + o] = m22; hz[4][ry][cx + o] = m12;
+        }
+    }
+    __syncthreads();                                                                   // every read of sxy is done
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const int item = threadIdx.x + it * 256;
+        if (item < kItems) {
+            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) hz_last[ry][cx + o] = keep[it][o];
         }
     }
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    float ssim_sum = 0.0f, l1_sum = 0.0f;
+    float ssim_sum = 0.0f;
     const int ox = threadIdx.x % kLossTileW, oy0 = (threadIdx.x / kLossTileW) * kRowsPerThread;   // lanes of a wave: adjacent columns
     const int gx = x0 + ox;
     float v[5][kRowsPerThread];
 #pragma unroll
-    for (int m = 0; m < 5; ++m) {                                                   // vertical taps: 8 outputs from 18 inputs per map
+    for (int m = 0; m < 5; ++m) {                                                   // vertical taps: 4 outputs from 14 inputs per map
         float col[kRowsPerThread + kTaps - 1];
 #pragma unroll
-        for (int t = 0; t < kRowsPerThread + kTaps - 1; ++t) col[t] = hz[m][oy0 + t][ox];
+        for (int t = 0; t < kRowsPerThread + kTaps - 1; ++t) col[t] = m < 4 ? hz4[m][oy0 + t][ox] : hz_last[oy0 + t][ox];
 #pragma unroll
         for (int o = 0; o < kRowsPerThread; ++o) {
             float acc = 0.0f;
@@ -103,15 +139,14 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(const LossArgs a, con
             const float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
             const float den = B1 * B2;
             ssim_sum += (A1 * A2) / den;
-            l1_sum += fabsf(sxy[0][oy + kHalo][ox + kHalo] - sxy[1][oy + kHalo][ox + kHalo]);
             const size_t e = c * plane + (size_t)gy * a.width + gx;
             a.d_mu[e] = ((2.0f * mu2 * A2 - 2.0f * mu2 * A1) * den - A1 * A2 * (2.0f * mu1 * B2 - 2.0f * mu1 * B1)) / (den * den);
             a.d_m11[e] = -(A1 * A2) / (B1 * B2 * B2);
             a.d_m12[e] = 2.0f * A1 / den;
         }
     }
-    const float bl = block_sum_256(l1_sum, s_red[0]);
-    const float bs = block_sum_256(ssim_sum, s_red[1]);
+    const float bl = block_sum_256(l1_sum, s_red);
+    const float bs = block_sum_256(ssim_sum, s_red + 4);
     // per-workgroup partial sums, reduced by ssim_reduce_kernel: thousands of workgroups adding to two words would serialise on the
     // same-address atomic rate (measured 0.28 ms at 1080p), and a fixed order makes the loss reproducible
     if (threadIdx.x == 255) {
@@ -136,27 +171,49 @@ __global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, cons
 }
 
 __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, const GaussWindow gw) {
+    // The horizontally filtered maps go back into the memory of the staged region (dead once every thread has read its inputs into
+    // registers): 21.2 KB per workgroup instead of 37.3 -- six workgroups per CU (register-limited) instead of four.
+    constexpr int kMapFloats = kRegionH * kLossTileW;
+    static_assert(3 * kRegionH * kRegionW >= 3 * kMapFloats, "the three filtered maps fit in the staged region");
     __shared__ float sd[3][kRegionH][kRegionW];
-    __shared__ float hz[3][kRegionH][kLossTileW];
+    float (*const hz)[kRegionH][kLossTileW] = reinterpret_cast<float (*)[kRegionH][kLossTileW]>(&sd[0][0][0]);
     const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ m0 = a.d_mu + c * plane; const float* __restrict__ m1 = a.d_m11 + c * plane; const float* __restrict__ m2 = a.d_m12 + c * plane;
     stage_region<3>(sd, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? m0[e] : (k == 1 ? m1[e] : m2[e]); });
     __syncthreads();
-    for (int item = threadIdx.x; item < kRegionH * kHzGroups; item += 256) {
-        const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+    constexpr int kItems = kRegionH * kHzGroups, kItemsPerThread = (kItems + 255) / 256;
+    float keep[kItemsPerThread][3][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float p[14];
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const int item = threadIdx.x + it * 256;
+        if (item < kItems) {
+            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
 #pragma unroll
-            for (int t = 0; t < 14; ++t) p[t] = sd[k][ry][cx + t];
+            for (int k = 0; k < 3; ++k) {
+                float p[14];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float f = 0.0f;
+                for (int t = 0; t < 14; ++t) p[t] = sd[k][ry][cx + t];
 #pragma unroll
-                for (int t = 0; t < kTaps; ++t) f += gw.w[t] * p[o + t];
-                hz[k][ry][cx + o] = f;
+                for (int o = 0; o < 4; ++o) {
+                    float f = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < kTaps; ++t) f += gw.w[t] * p[o + t];
+                    keep[it][k][o] = f;
+                }
             }
+        }
+    }
+    __syncthreads();                                                                   // every read of sd is done
+#pragma unroll
+    for (int it = 0; it < kItemsPerThread; ++it) {
+        const int item = threadIdx.x + it * 256;
+        if (item < kItems) {
+            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) hz[k][ry][cx + o] = keep[it][k][o];
         }
     }
     __syncthreads();
