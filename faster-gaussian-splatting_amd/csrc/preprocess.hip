@@ -263,8 +263,20 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     FGS_K1_FLUSH;
 }
 
+// The register budget is capped for FGS_K1_WAVES waves per SIMD. Uncapped the kernel takes 116 VGPRs = 4 waves = TWO 512-thread workgroups per
+// CU, and it is latency-bound (35 % of the HBM rate, 40 % of the issue slots, round 2). Measured on one box (profiles/r03_ab_k1_occupancy.txt,
+// S2): uncapped 0.216 ms; 6 waves (80 VGPRs, 43 registers spilled to scratch: THREE workgroups per CU) 0.196 ms; 5 waves (no more workgroups)
+// 0.215; 8 waves (64 VGPRs, 66 spilled, four workgroups) 0.222 -- the spills eat it. 0 = no cap.
+#ifndef FGS_K1_WAVES
+#define FGS_K1_WAVES 6
+#endif
+#if FGS_K1_WAVES > 0
+#define FGS_K1_BOUNDS __launch_bounds__(kPreprocessBlock) __attribute__((amdgpu_waves_per_eu(FGS_K1_WAVES, FGS_K1_WAVES)))
+#else
+#define FGS_K1_BOUNDS __launch_bounds__(kPreprocessBlock)
+#endif
 template <bool INFERENCE>
-__global__ void __launch_bounds__(kPreprocessBlock) preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE>(a); }
+__global__ void FGS_K1_BOUNDS preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE>(a); }
 __global__ void __launch_bounds__(kPreprocessBlock) preprocess_batch_kernel(const PreprocessBatch b) { preprocess_body<false>(b.v[blockIdx.y]); }
 
 // Exact tile count + compaction for the few screen-filling footprints: one 256-thread workgroup per Gaussian, 256 candidate
