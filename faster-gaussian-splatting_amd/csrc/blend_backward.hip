@@ -380,17 +380,21 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
     // passed (n_px .. n_px + 62 <= 254). The per-step index arithmetic was five vector instructions (step - lane, + look-ahead, unsigned min
     // against n_px, two shifts for the two strides); on the ring it is three: the byte offset into the 8-byte ring walks by 8 and wraps
     // (add, and), the 16-byte ring's offset is one shift-add of it. ONE shared block per wave with the 8-byte ring at offset 0, so that its
-    // address IS the ring offset (no base to add): [xy 2 KB | pix 4 KB | inj 2 KB] = 8 KB.
+    // address IS the ring offset (no base to add): [xy ring 2 KB | inj 1.5 KB | pix ring 4 KB] = 7 680 bytes = six LDS allocation granules
+    // (1 280 bytes on this part: with 8 KB the timeline showed 17 waves per CU in flight, with 6.7 KB before the ring 19).
     constexpr unsigned kRing = 256;
-    constexpr unsigned kXyBytes = kRing * 8u, kPixBytes = kRing * 16u, kInjBytes = (kTilePixels + kWave) * 8u;
-    __shared__ __attribute__((aligned(16))) char s_block[kCompactWaves][kXyBytes + kPixBytes + kInjBytes];
+    constexpr unsigned kXyBytes = kRing * 8u, kInjBytes = kTilePixels * 8u, kPixBytes = kRing * 16u, kPixBase = kXyBytes + kInjBytes;
+    static_assert(kPixBase % 16u == 0, "the 16-byte ring is 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) char s_block[kCompactWaves][kXyBytes + kInjBytes + kPixBytes];
     char* const s_base = s_block[wave_in_group];
     float2* const s_xy = reinterpret_cast<float2*>(s_base);
-    float4* const s_pix = reinterpret_cast<float4*>(s_base + kXyBytes);
-    // T_ckpt, S - g_w: enters the pipeline at lane 0. Slots n_px .. n_px + 63 are zero: lane 0 reads slot (step + 1) without a clamp
-    // until the last step, and lanes 1..63 read slot n_px (zero) in every step, which makes "shift up by one lane, inject at lane 0"
-    // ONE DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
-    float2* const s_inj = reinterpret_cast<float2*>(s_base + kXyBytes + kPixBytes);
+    float4* const s_pix = reinterpret_cast<float4*>(s_base + kPixBase);
+    // T_ckpt, S - g_w of the live pixels: enters the pipeline at lane 0, which walks this array one slot per step -- and on into the bytes
+    // behind it for the 63 (+ look-ahead) steps after the last pixel: what it reads there is never used, because every lane that the value
+    // reaches sees a sentinel pixel (rel 0) in that step and contributes nothing, and the state registers are cleared per work item. Lanes
+    // 1..63 read a zero in every step (slot 255 of the xy ring: always a sentinel), which makes "shift up by one lane, inject at lane 0" ONE
+    // DPP-fused add per value (shifted-in zero at lane 0 + the lane's own read) instead of a DPP move plus a select.
+    float2* const s_inj = reinterpret_cast<float2*>(s_base + kXyBytes);
     const unsigned n_live = *a.live_count;
     const float lane_f = static_cast<float>(lane);
     const bool lane0 = lane == 0;
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             for (unsigned sl = n_px + lane; sl < kRing; sl += kWave) {          // sentinels (rel_last 0: never contributes): 1 to 4 rounds
                 s_pix[sl] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[sl] = make_float2(0.0f, 0.0f);
             }
-            s_inj[n_px + lane] = make_float2(0.0f, 0.0f);
+
         }
 
         const unsigned tp = first_gaussian + lane;
@@ -478,16 +482,16 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         // One pipeline step. `inj` / `px`: what this lane read for THIS step (software pipelined: the reads of the following step
         // are issued first). Contributions are made under the lane mask of `contrib` (EXEC), not by selects: a v_cndmask costs
         // several times an FMA on this chip (tools/valu_rate.hip), and the empty-mask branch of the `if` is the wave-uniform skip.
-        unsigned inj_slot = lane0 ? 0u : n_px;                        // lane 0: slot of the step; other lanes: the zero slot
-        const unsigned inj_step = lane0 ? 1u : 0u;
+        unsigned inj_at = lane0 ? kXyBytes : (kRing - 1u) * 8u;       // byte offsets: lane 0 the slot of the step, other lanes the zero slot
+        const unsigned inj_step = lane0 ? 8u : 0u;
         // byte offset into the 8-byte ring of the slot this lane reads for the step whose reads are issued next: (step - lane) mod 256
         unsigned ring_at = ((0u - lane) & (kRing - 1u)) * 8u;
         struct PixRead { float4 g; float2 xy; };
-        auto read_inj = [&]() { const float2 v = s_inj[inj_slot]; inj_slot += inj_step; return v; };
+        auto read_inj = [&]() { const float2 v = *reinterpret_cast<const float2*>(s_base + inj_at); inj_at += inj_step; return v; };
         auto read_pix = [&]() {
             PixRead r;
             r.xy = *reinterpret_cast<const float2*>(s_base + ring_at);
-            r.g = *reinterpret_cast<const float4*>(s_base + (2u * ring_at + kXyBytes));
+            r.g = *reinterpret_cast<const float4*>(s_base + (2u * ring_at + kPixBase));
             ring_at = (ring_at + 8u) & (kXyBytes - 1u);
             return r;
         };
