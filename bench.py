@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--scene', default='S2', choices=['S0', 'S1', 'S2', 'S3'])
     ap.add_argument('--n-gaussians', type=int, default=0, help='override the scene size (debug)')
+    ap.add_argument('--ply', default='', help='bench a trained scene instead of the synthetic one: a 3DGS / FasterGS PLY export (Model.py:511-542 layout), '
+                                              'viewed from 8 orbit cameras around its centroid (the training cameras are not in a PLY; +y is taken as down)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / fused side measurements')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
@@ -56,6 +58,16 @@ def parse():
 
 def build_scene(args):
     from harness.scenes import SCENE_SIZES, make_garden_like, make_s0, orbit_views
+    if args.ply:
+        from harness.ply import load_ply
+        from harness.scenes import look_at_view
+        import math
+        params = load_ply(args.ply)
+        c = params['means'].median(dim=0).values
+        r = float((params['means'] - c).norm(dim=1).quantile(0.9)) * 1.2
+        views = [look_at_view((float(c[0]) + r * math.cos(2 * math.pi * k / 8), float(c[1]) - 0.3 * r, float(c[2]) + r * math.sin(2 * math.pi * k / 8)),
+                              tuple(float(x) for x in c), 1920, 1080, 1420.0) for k in range(8)]
+        return params, views, f'PLY {Path(args.ply).name}: {params["means"].shape[0]} Gaussians, 1920x1080, 8 orbit views at radius {r:.2f} around the median'
     if args.scene == 'S0':
         params, view = make_s0()
         return params, [view], 'S0: 1k Gaussians, 128x128'

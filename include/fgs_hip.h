@@ -321,8 +321,11 @@ int32_t fgs_debug_set_backward_variant(int32_t variant);
  * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop),
  * 8 = Adam walks the arenas from the end (1, default) or the start (0), 9 = depth sort: bit 0 key - bits(near) in 9-bit passes, bit 1
  * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower), 10 = forward-blend tile -> workgroup
- * mapping: 0 (default) = one contiguous band of tile rows per XCD, g = 1..64 = groups of g rows dealt to the XCDs in turn, bottom of the image
- * first (10 % faster on deeply layered scenes, 9-16 % slower at two blended buckets per tile), 255 = the bands walked bottom-up.
+ * mapping: 252 (default) = one vertical strip of tile columns per XCD, walked row by row from the top (251: from the bottom), 0 = one
+ * contiguous band of tile rows per XCD (rounds 1-2), g = 1..64 = groups of g rows dealt to the XCDs in turn, 255 = the bands walked
+ * bottom-up, 254 = blocks of tiles weighed and dealt to the XCDs on the device (plan_tiles_kernel), 253 = the bands read through the plan
+ * table (blend_forward.hip has the measurements), 11 = 1: rocPRIM scan for the per-tile bucket offsets (and no block plan), 12 = 1: the
+ * block plan without sorting (XCD x = block column x).
  * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
