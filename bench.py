@@ -176,7 +176,7 @@ def main():
         import tempfile
         log_dir = tempfile.mkdtemp(prefix='fgs_bench_ranks_', dir='/tmp')
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), '--log-dir', log_dir, '--redirects', '2', '--tee', '1', str(Path(__file__).resolve())] + sys.argv[1:]
+               '--master-port', str(port), '--log-dir', log_dir, '--redirects', '3', str(Path(__file__).resolve())] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         # own process group: on a timeout exactly this launcher and its ranks are killed (never by pattern)
         proc = subprocess.Popen(cmd, env=env, start_new_session=True)
@@ -187,6 +187,8 @@ def main():
             os.killpg(proc.pid, signal.SIGKILL)
             rc = 124
             print(f'bench.py: the {args.gpus}-rank run exceeded {args.watchdog + 120} s and was killed', file=sys.stderr)
+        for f in sorted(Path(log_dir).rglob('stdout.log')):     # rank 0's stdout is the JSON line (the other ranks print nothing)
+            sys.stdout.write(f.read_text(errors='replace'))
         if rc != 0:                                     # relay what every rank wrote to stderr (torchrun keeps it in --log-dir)
             for f in sorted(Path(log_dir).rglob('stderr.log')):
                 tail = f.read_text(errors='replace')[-3000:]
@@ -194,13 +196,23 @@ def main():
         raise SystemExit(rc)
     if world != args.gpus and not args.cpu_baseline_only:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}')
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to stdout when it creates a communicator, other libraries
+    # may do the same -- so file descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        sys.stdout.flush()
+        os.write(json_fd, (line + '\n').encode())
+
     if args.watchdog and not args.cpu_baseline_only:
         import faulthandler                              # a rank stuck in a collective dumps every thread's stack to stderr and exits, instead
         faulthandler.dump_traceback_later(args.watchdog, exit=True)      # of hanging the whole job until the driver's own limit
     params, views, workload = build_scene(args)
 
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(params, views, {})))
+        emit(json.dumps(cpu_baseline(params, views, {})))
         return
 
     import torch.distributed as dist
@@ -365,7 +377,7 @@ def main():
     # who took part: every rank reports its device and the Gaussians it saw (proves N ranks ran)
     roster = None
     if dist.is_initialized():
-        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(device), 'n_gaussians_on_rank': int(vp.n_local) if hasattr(vp, 'n_local') else n,
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(device), 'n_gaussians_on_rank': int(getattr(vp, 'n', n)) if vp is not None else n,
                 'n_visible_view0': int(stats[id(my_views[0])]['V']), 'visible_devices': torch.cuda.device_count()}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -628,7 +640,7 @@ def main():
         except Exception as exc:   # the baseline must never take the GPU number down with it
             out['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {exc}'}
     if rank == 0:
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
 
