@@ -78,3 +78,28 @@ def test_trainers_over_rccl_world1_equal_single_gpu_step(hip_backend, rccl_world
         # float atomics in a different order: compare the step taken, relative to the largest step of the tensor
         assert helpers.rel_inf((got[k] - dp[k]).cpu().numpy(), (ref[k] - dp[k]).cpu().numpy()) < 1e-4, (mode, k)
     assert helpers.rel_inf(tr.densification_info.cpu().numpy(), ref_info.cpu().numpy()) < 1e-4
+
+
+def test_bench_under_torchrun_world1_prints_one_json_line_of_the_single_gpu_iteration():
+    """The driver launches bench.py for N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`. With N = 1 the
+    same launch must time the single-GPU iteration (the N = 1 point of a scaling curve IS the BENCH number), print exactly ONE line on
+    stdout -- RCCL's version banner and everything else goes to stderr -- and name the ranks that took part."""
+    import json
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           str(helpers.REPO / 'bench.py'), '--gpus', '1', '--scene', 'S0', '--steps', '3', '--warmup', '1', '--blocks', '2', '--no-extras',
+           '--no-cpu-baseline', '--no-pmc']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['parallelism'] == 'single GPU' and d['config']['world'] == 1
+    assert d['config']['backend'] == 'nccl' and d['config']['rccl_version'] and len(d['config']['ranks']) == 1
+    assert d['config']['ranks'][0]['rank'] == 0 and d['config']['ranks'][0]['n_gaussians_on_rank'] == 1000
+    assert len(d['repeatability']['ms_per_step']) == 2 and d['peak_vram_GB']['peak_allocated_GB'] > 0
+    assert d['roofline']['frac'] > 0 and 'stage_ms_per_step' in d
