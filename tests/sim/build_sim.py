@@ -1,28 +1,36 @@
 """Builds tests/sim/_build/libfgs_sim.so: the product's .hip sources compiled by g++ against the stand-in headers
-(see README.md). Test infrastructure only."""
+(see README.md). Test infrastructure only. The translation units are compiled in parallel (one g++ per source) and linked."""
 from __future__ import annotations
 
+import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 SIM = Path(__file__).resolve().parent
 REPO = SIM.parent.parent
 CSRC = REPO / 'faster-gaussian-splatting_amd' / 'csrc'
 OUT = SIM / '_build' / 'libfgs_sim.so'
+FLAGS = ['-std=c++17', '-O2', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas', '-Wno-sign-compare',
+         '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-Wno-attributes', f'-I{SIM / "include"}', f'-I{CSRC}', f'-I{REPO / "include"}']
 
 
 def build(force: bool = False) -> Path:
     srcs = sorted(CSRC.glob('*.hip'))
-    deps = srcs + sorted(CSRC.glob('*.h')) + sorted(SIM.glob('include/**/*.h*')) + [REPO / 'include' / 'fgs_hip.h']
-    if not force and OUT.exists() and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return OUT
+    headers = sorted(CSRC.glob('*.h')) + sorted(SIM.glob('include/**/*.h*')) + [REPO / 'include' / 'fgs_hip.h']
+    newest_header = max(h.stat().st_mtime for h in headers)
     OUT.parent.mkdir(exist_ok=True)
-    cmd = ['g++', '-std=c++17', '-O2', '-fPIC', '-shared', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
-           '-Wno-unknown-pragmas', '-Wno-sign-compare', '-Wno-unused-variable', '-Wno-unused-but-set-variable',
-           f'-I{SIM / "include"}', f'-I{CSRC}', f'-I{REPO / "include"}', '-o', str(OUT)]
-    for s in srcs:
-        cmd += ['-x', 'c++', str(s)]
-    subprocess.run(cmd, check=True)
+
+    def compile_one(src: Path) -> Path:
+        obj = OUT.parent / (src.stem + '.o')
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, newest_header):
+            subprocess.run(['g++', *FLAGS, '-c', '-x', 'c++', str(src), '-o', str(obj)], check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    if force or not OUT.exists() or any(OUT.stat().st_mtime < o.stat().st_mtime for o in objs):
+        subprocess.run(['g++', '-shared', '-fPIC', '-o', str(OUT), *[str(o) for o in objs]], check=True)
     return OUT
 
 

@@ -8,17 +8,8 @@ import sys
 import helpers
 
 
-def test_cpu_baseline_only_prints_exactly_one_json_line():
-    r = subprocess.run([sys.executable, str(helpers.REPO / 'bench.py'), '--cpu-baseline-only', '--scene', 'S0'], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout[:500]
-    d = json.loads(lines[0])
-    assert d['kind'] == 'port' and d['unit'] == 'iters/s' and d['value'] > 0 and d['cores'] >= 1
-
-
-def test_library_noise_on_stdout_lands_on_stderr():
-    """A print from inside the run (as a library would do) must not reach stdout."""
+def test_cpu_baseline_only_prints_exactly_one_json_line_whatever_the_libraries_print():
+    """np.sign (called inside the timed oracle loop) is wrapped to print a banner, as a library would: it must not reach stdout."""
     code = ("import sys, runpy; sys.argv = ['bench.py', '--cpu-baseline-only', '--scene', 'S0']; "
             "import numpy as _np; _orig = _np.sign\n"
             "def noisy(*a, **k):\n    print('BANNER: not json'); return _orig(*a, **k)\n"
@@ -26,5 +17,8 @@ def test_library_noise_on_stdout_lands_on_stderr():
             f"runpy.run_path({str(helpers.REPO / 'bench.py')!r}, run_name='__main__')")
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert 'BANNER' in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[:300]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d['kind'] == 'port' and d['unit'] == 'iters/s' and d['value'] > 0 and d['cores'] >= 1
