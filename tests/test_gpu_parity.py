@@ -4,8 +4,8 @@ Tolerances (BASELINE.json north_star): integer / index work bit-exact; floats wi
 Two facts bound what "bit-exact" can mean on real hardware ('fast-math parity'):
  * preprocess is built without FMA contraction and with IEEE div/sqrt, so it differs from the oracle only through
    ULP-level differences of expf/logf (ocml vs glibc); a screen bound / exact tile count can flip for the rare primitive
-   whose floor/ceil/threshold input lies within an ULP of an integer. Tests therefore allow at most max(1, 0.1%) of the
-   primitives to differ in integer intermediates and compare the downstream integer arrays exactly when none does.
+   whose floor/ceil/threshold input lies within an ULP of an integer. On the fixed scenes of this file that never happens
+   (round 3: asserted, _forward_check); the large and the randomised scenes (flip-aware tests) tolerate and mask such primitives.
  * the blend kernels use the hardware exp (v_exp_f32) and FMA contraction; an alpha within ~1e-6 relative of the 1/255
    threshold can be kept on one side and dropped on the other, changing that pixel by up to ~4e-3. The oracle NAMES the pixels
    (and Gaussians) that own such a pair (oracle.threshold_risk -> helpers.flip_masks); per-pixel outputs (image, final_T,
@@ -55,7 +55,11 @@ def test_wave_primitives_selftest(hip_backend):
     assert np.array_equal(o[128:192], (l + 2) // 3) and np.all(o[192:] == 2142), (o[128:192], o[192:196])
 
 
-def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None):
+def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None, int_budget=False):
+    """Every forward intermediate against the oracle. The integer ones (screen bounds, tile counts and everything derived from them) are
+    compared bit for bit: on the fixed scenes of this file no primitive's bounds differ from the oracle's on an MI355X (logged per call under
+    FGS_TOL_LOG, `profiles/r03_gpu_tolerance_slack.txt` part 3: 16 of 16), so the libm-ULP budget of rounds 1-2 -- up to max(1, n / 1000)
+    primitives, after which the downstream exact comparisons were dropped -- is now opt-in (`int_budget`) and used by no fixed scene."""
     S, RS = helpers.settings_pair(view, K, aa, bg, device=DEV)
     dp = _to(params)
     n = dp['means'].shape[0]
@@ -65,8 +69,9 @@ def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None):
     dec = helpers.decode_forward(hip_backend, res, n, view.width, view.height)
     vis = f['n_touched'] > 0
     bad = int((dec['n_touched'] != f['n_touched']).sum()) + int((dec['screen_bounds'][vis] != f['screen_bounds'][vis]).any(axis=1).sum())
+    helpers.log_note('int_mismatch_primitives', bad, n=n)
+    assert bad == 0 or int_budget, ('integer intermediates differ from the oracle', bad, n)
     budget = 0 if bad == 0 else max(1, n // 1000)
-    helpers.log_note('int_mismatch_primitives', bad, n=n)          # how often the budget branch below is taken at all
     pixel_mask = helpers.flip_masks(oracle, f, S, dec)['pixel']      # pixels within an ULP-scale margin of the alpha / T thresholds
     if bad == 0:
         helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy(), pixel_mask=pixel_mask)
