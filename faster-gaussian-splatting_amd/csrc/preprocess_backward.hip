@@ -238,6 +238,53 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
         }
 }
 
+// ---- the wave's SH-rest gradient block, kept FACTORED in LDS ---------------------------------------------------------
+// The gradient of sh_coefficients_rest[g][k][c] is basis_k(dir_g) * dL/dcolour_c(g) (sh_utils.cuh:90-111): 18 numbers per Gaussian
+// (3 colour gradients + 15 basis values) instead of 45 products: 4.5 KB of LDS per wave instead of 11.25 KB, and the product is formed when
+// a 16-byte piece of the [N, R, 3] block is assembled -- the same single multiplication, so the result is bit-identical. A float4 piece
+// starting at element e0 of the wave's block covers exactly the (Gaussian, basis) pairs e0/3 and e0/3 + 1. Used by the fused kernel, where
+// the slice is also the staging area of phase A (one 14 x 64 array at a time); the unfused K12 keeps the block of products (measured: the
+// piece assembly costs it 0.003 ms and it gains nothing from the LDS, profiles/r03_ab_fused_factored.txt).
+constexpr uint32_t kShFactorStride = 18;                 // floats per Gaussian: colour gradient 3, basis values 15
+constexpr uint32_t kShFactorFloats = kWave * kShFactorStride;
+
+__device__ __forceinline__ void put_sh_factors(float* const slice, const uint32_t lane, const bool visible, const float (&dir)[3],
+                                               const float (&gcol)[3], const int active_sh_bases) {
+    float B[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) B[k] = 0.0f;                         // degrees above the active one keep a zero gradient
+    if (visible && active_sh_bases > 1) sh_basis(dir[0], dir[1], dir[2], active_sh_bases, B);
+    float* const mine = slice + lane * kShFactorStride;
+    mine[0] = gcol[0]; mine[1] = gcol[1]; mine[2] = gcol[2];           // zeros for an invisible Gaussian
+#pragma unroll
+    for (int k = 0; k < 15; ++k) mine[3 + k] = B[k];
+}
+
+template <int RT>
+__device__ __forceinline__ float sh_rest_gradient_at(const float* const slice, const uint32_t e, const uint32_t R) {
+    const uint32_t pair = e / 3u, c = e - 3u * pair;
+    const uint32_t g = RT > 0 ? pair / static_cast<uint32_t>(RT) : pair / R, k = pair - g * R;
+    const float* const f = slice + g * kShFactorStride;
+    return f[3u + k] * f[c];
+}
+
+template <int RT>
+__device__ __forceinline__ float4 sh_rest_gradient_piece(const float* const slice, const uint32_t e0, const uint32_t R) {
+    const uint32_t p0 = e0 / 3u, r0 = e0 - 3u * p0;                    // first pair of the piece, channel its first element starts at
+    const uint32_t g0 = RT > 0 ? p0 / static_cast<uint32_t>(RT) : p0 / R, k0 = p0 - g0 * R;
+    const bool wrap = k0 + 1u == R;                                    // the second pair belongs to the next Gaussian
+    const float* const f0 = slice + g0 * kShFactorStride;
+    const float* const f1 = wrap ? f0 + kShFactorStride : f0;
+    const float b0 = f0[3u + k0], b1 = f1[wrap ? 3u : 4u + k0];
+    const float v0 = b0 * f0[0], v1 = b0 * f0[1], v2 = b0 * f0[2], v3 = b1 * f1[0], v4 = b1 * f1[1], v5 = b1 * f1[2];
+    float4 g;                                                          // elements r0 .. r0 + 3 of (v0 .. v5)
+    g.x = r0 == 0u ? v0 : r0 == 1u ? v1 : v2;
+    g.y = r0 == 0u ? v1 : r0 == 1u ? v2 : v3;
+    g.z = r0 == 0u ? v2 : r0 == 1u ? v3 : v4;
+    g.w = r0 == 0u ? v3 : r0 == 1u ? v4 : v5;
+    return g;
+}
+
 // ---- single-GPU fused backward + Adam (BASELINE.json configs[3]): ONE kernel for all 59 floats of a Gaussian -----------
 // A wave owns 64 consecutive Gaussians. Phase A, one lane per Gaussian: the 14 small floats and their moments are requested,
 // the gradient of the Gaussian is formed (gaussian_backward, which also gathers the lane's 45 SH-rest coefficients for the
@@ -249,9 +296,13 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
 // leaves registers, and the 15 basis values are evaluated once per Gaussian instead of once per (Gaussian, basis) pair.
 // Bytes per Gaussian: 59 x 24 (state in / out) + 36 + 4 (accumulators, tile count) [+ 16 densification] = 1456.
 constexpr int kFusedUnroll = 3;          // 16-byte pieces of each of the three streams in flight per lane
+#ifndef FGS_FUSED_WAVES
+#define FGS_FUSED_WAVES 3
+#endif
 template <int RT>
-__global__ void __launch_bounds__(256) fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) {
-    __shared__ __attribute__((aligned(16))) float s_grad[256 / kWave][kWave * 15 * 3];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FGS_FUSED_WAVES, FGS_FUSED_WAVES)))
+fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) {
+    __shared__ __attribute__((aligned(16))) float s_grad[256 / kWave][kShFactorFloats];   // >= the 14 x 64 floats phase A stages per array
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : sh.total_sh_rest;
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t first = blockIdx.x * 256u + wv * kWave;            // first Gaussian of this wave
@@ -265,81 +316,109 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
     // ---- phase A: the 14 small floats of parameters and both moments. A wave's 64 x w floats of a group are contiguous: they come in (and
     // go out) as ONE coalesced 16-byte access per lane and pass through LDS, instead of w scalar accesses per lane at a stride of 4 w bytes --
     // 42 loads + 42 stores per lane before, more memory instructions than phase B issues for three times the data. ----
+    // The parameters come first (the gradient needs them); the moments are requested after the gradient is formed, so 28 registers are not
+    // held across gaussian_backward, and every array passes through the same 3.5 KB of the slice. Round 3, one box: 0.850 -> 0.812 ms
+    // (profiles/r03_ab_fused_factored.txt; 3 or 4 waves per SIMD measure the same, 5 spills; requesting phase B's first pieces before the
+    // gradient, or double-buffering phase B, measured slower at every depth tried).
+    constexpr int kLanes[5] = {48, 48, 16, 48, 64};                   // 64 w / 4 float4 pieces
     float st_p[14], st_m[14], st_v[14];
+    const uint32_t ic = in_range ? i : a.n - 1u;                      // partial wave: out-of-range lanes shadow the last Gaussian (loads only)
     if (whole) {
+        float4 in[5];
 #pragma unroll
-        for (int arr = 0; arr < 3; ++arr)
+        for (int grp = 0; grp < 5; ++grp)
+            if (lane < static_cast<uint32_t>(kLanes[grp])) in[grp] = load_float4_nt(a.p[grp] + (size_t)first * kGroupWidth[grp] + 4u * lane);
 #pragma unroll
-            for (int grp = 0; grp < 5; ++grp) {
-                constexpr int kLanes[5] = {48, 48, 16, 48, 64};       // 64 w / 4 float4 pieces
-                const float* const src = (arr == 0 ? a.p[grp] : arr == 1 ? a.m[grp] : a.v[grp]) + (size_t)first * kGroupWidth[grp];
-                if (lane < static_cast<uint32_t>(kLanes[grp]))
-                    *reinterpret_cast<float4*>(slice + (arr * 14 + kGroupOffset[grp]) * kWave + 4u * lane) = load_float4_nt(src + 4u * lane);
-            }
+        for (int grp = 0; grp < 5; ++grp)
+            if (lane < static_cast<uint32_t>(kLanes[grp])) *reinterpret_cast<float4*>(slice + kGroupOffset[grp] * kWave + 4u * lane) = in[grp];
         wave_lds_fence();
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
-            for (int k = 0; k < kGroupWidth[grp]; ++k) {
-                const int o = kGroupOffset[grp] + k;
-                const uint32_t at = kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k;
-                st_p[o] = slice[at]; st_m[o] = slice[14 * kWave + at]; st_v[o] = slice[28 * kWave + at];
-            }
-    } else {                                                         // the last, partial wave: scalar accesses
-        const uint32_t ic = in_range ? i : a.n - 1u;                  // out-of-range lanes shadow the last Gaussian (loads only)
+            for (int k = 0; k < kGroupWidth[grp]; ++k) st_p[kGroupOffset[grp] + k] = slice[kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k];
+        wave_lds_fence();                                             // the moments overwrite the slice
+    } else {
+#pragma unroll
+        for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+            for (int k = 0; k < kGroupWidth[grp]; ++k) st_p[kGroupOffset[grp] + k] = a.p[grp][(size_t)ic * kGroupWidth[grp] + k];
+    }
+    float grad[14], dir[3] = {0.0f, 0.0f, 0.0f}, gcol[3] = {0.0f, 0.0f, 0.0f};
+    bool visible = false;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) grad[k] = 0.0f;
+    if (in_range) visible = gaussian_backward<true, false, true>(a, i, st_p, grad, dir, gcol);
+    if (whole) {
+        float4 in[2][5];
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr)
+#pragma unroll
+            for (int grp = 0; grp < 5; ++grp)
+                if (lane < static_cast<uint32_t>(kLanes[grp]))
+                    in[arr][grp] = load_float4_nt((arr == 0 ? a.m[grp] : a.v[grp]) + (size_t)first * kGroupWidth[grp] + 4u * lane);
+#pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+#pragma unroll
+            for (int grp = 0; grp < 5; ++grp)
+                if (lane < static_cast<uint32_t>(kLanes[grp])) *reinterpret_cast<float4*>(slice + kGroupOffset[grp] * kWave + 4u * lane) = in[arr][grp];
+            wave_lds_fence();
+#pragma unroll
+            for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+                for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                    const float x = slice[kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k];
+                    if (arr == 0) st_m[kGroupOffset[grp] + k] = x; else st_v[kGroupOffset[grp] + k] = x;
+                }
+            wave_lds_fence();
+        }
+    } else {
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
             for (int k = 0; k < kGroupWidth[grp]; ++k) {
                 const size_t e = (size_t)ic * kGroupWidth[grp] + k;
-                st_p[kGroupOffset[grp] + k] = a.p[grp][e]; st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
+                st_m[kGroupOffset[grp] + k] = a.m[grp][e]; st_v[kGroupOffset[grp] + k] = a.v[grp][e];
             }
     }
-    float grad[14], dir[3] = {0.0f, 0.0f, 0.0f}, gcol[3] = {0.0f, 0.0f, 0.0f};
-    bool visible = false;
     if (in_range) {
-        visible = gaussian_backward<true, false, true>(a, i, st_p, grad, dir, gcol);
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
             for (int k = 0; k < kGroupWidth[grp]; ++k) {
                 const int o = kGroupOffset[grp] + k;
                 adam_update(st_p[o], st_m[o], st_v[o], grad[o], a.h[grp]);
-                if (whole) {
-                    const uint32_t at = kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k;
-                    slice[at] = st_p[o]; slice[14 * kWave + at] = st_m[o]; slice[28 * kWave + at] = st_v[o];
-                } else {
+                if (!whole) {
                     const size_t e = (size_t)i * kGroupWidth[grp] + k;
                     a.p[grp][e] = st_p[o]; a.m[grp][e] = st_m[o]; a.v[grp][e] = st_v[o];
                 }
             }
     }
     if (whole) {
-        wave_lds_fence();
 #pragma unroll
-        for (int arr = 0; arr < 3; ++arr)
+        for (int arr = 0; arr < 3; ++arr) {
+#pragma unroll
+            for (int grp = 0; grp < 5; ++grp)
+#pragma unroll
+                for (int k = 0; k < kGroupWidth[grp]; ++k) {
+                    const int o = kGroupOffset[grp] + k;
+                    slice[kGroupOffset[grp] * kWave + lane * kGroupWidth[grp] + k] = arr == 0 ? st_p[o] : arr == 1 ? st_m[o] : st_v[o];
+                }
+            wave_lds_fence();
 #pragma unroll
             for (int grp = 0; grp < 5; ++grp) {
-                constexpr int kLanes[5] = {48, 48, 16, 48, 64};
                 float* const dst = (arr == 0 ? a.p[grp] : arr == 1 ? a.m[grp] : a.v[grp]) + (size_t)first * kGroupWidth[grp];
                 if (lane < static_cast<uint32_t>(kLanes[grp]))
-                    store_float4_nt(dst + 4u * lane, *reinterpret_cast<const float4*>(slice + (arr * 14 + kGroupOffset[grp]) * kWave + 4u * lane));
+                    store_float4_nt(dst + 4u * lane, *reinterpret_cast<const float4*>(slice + kGroupOffset[grp] * kWave + 4u * lane));
             }
-        wave_lds_fence();                                             // the slice is about to be rewritten with the SH-rest gradient block
+            wave_lds_fence();                                         // the slice is rewritten by the next array, then by the SH-rest factors
+        }
     }
     if (R == 0) return;
 
-    // ---- the wave's SH-rest gradient block -> LDS (skipped when no lane of the wave is visible: the block is zero) ----
+    // ---- the wave's SH-rest gradient factors -> LDS (skipped when no lane of the wave is visible: the block is zero) ----
     const bool any_visible = wave_ballot(visible) != 0;
     if (any_visible) {
-        float B[15];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) B[k] = 0.0f;                     // degrees above the active one keep a zero gradient
-        if (visible && sh.active_sh_bases > 1) sh_basis(dir[0], dir[1], dir[2], sh.active_sh_bases, B);
-        float* const mine = slice + lane * R * 3u;
-#pragma unroll
-        for (int k = 0; k < 15; ++k)
-            if (static_cast<uint32_t>(k) < R) { mine[3 * k] = B[k] * gcol[0]; mine[3 * k + 1] = B[k] * gcol[1]; mine[3 * k + 2] = B[k] * gcol[2]; }
+        put_sh_factors(slice, lane, visible, dir, gcol, sh.active_sh_bases);
         wave_lds_fence();
     }
 
@@ -360,14 +439,14 @@ __global__ void __launch_bounds__(256) fused_backward_adam_kernel(const Preproce
         for (int u = 0; u < kFusedUnroll; ++u) {
             const uint32_t e = e0 + 4u * kWave * static_cast<uint32_t>(u);
             if (full[u]) {
-                const float4 g = any_visible ? *reinterpret_cast<const float4*>(slice + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float4 g = any_visible ? sh_rest_gradient_piece<RT>(slice, e, R) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 adam_update(p4[u].x, m4[u].x, v4[u].x, g.x, sh.h); adam_update(p4[u].y, m4[u].y, v4[u].y, g.y, sh.h);
                 adam_update(p4[u].z, m4[u].z, v4[u].z, g.z, sh.h); adam_update(p4[u].w, m4[u].w, v4[u].w, g.w, sh.h);
                 store_float4_nt(P + e, p4[u]); store_float4_nt(M + e, m4[u]); store_float4_nt(V + e, v4[u]);
             } else if (e < count) {                                                    // ragged tail of the last wave: < 4 floats
                 for (uint32_t j = e; j < count; ++j) {
                     float pp = P[j], mm = M[j], vv = V[j];
-                    adam_update(pp, mm, vv, any_visible ? slice[j] : 0.0f, sh.h);
+                    adam_update(pp, mm, vv, any_visible ? sh_rest_gradient_at<RT>(slice, j, R) : 0.0f, sh.h);
                     P[j] = pp; M[j] = mm; V[j] = vv;
                 }
             }
