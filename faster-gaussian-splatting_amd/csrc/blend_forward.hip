@@ -132,12 +132,14 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
         for (unsigned b = tid; b < nb; b += kBlendBlock) a.bucket_tile[bucket_base + b] = tile;   // kf:407-411
     }
 
-    __shared__ float4 s_a[kBlendBlock];   // mean.x mean.y conic.a conic.b
-    __shared__ float4 s_b[kBlendBlock];   // conic.c opacity r g
-    __shared__ float4 s_c[kBlendBlock];   // b bounds_x bounds_y -
+    __shared__ float4 s_rec[3 * kBlendBlock];                        // one array: the walk addresses all three rows off one register
+    float4* const s_a = s_rec;                                        // mean.x mean.y conic.a conic.b
+    float4* const s_b = s_rec + kBlendBlock;                          // conic.c opacity r g
+    float4* const s_c = s_rec + 2 * kBlendBlock;                      // b bounds_x bounds_y -
     __shared__ unsigned s_max[kBlendBlock / kWave];
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;
+    float gate = inside ? kMinAlphaThreshold : __builtin_inff();       // the alpha a pair has to reach to be blended (see the walk below)
     unsigned n_used = 0;
     // "done" (kf:424,477) is not carried as a flag: a pixel is finished exactly when its transmittance has dropped below the threshold
     // (T only ever decreases and the flag is set right after the update that takes it there), or when it lies outside the image. A
@@ -179,24 +181,37 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
             const uint64_t mine = inside ? (half ? mask_r : mask_l) : 0ull;            // pixels outside the image never blend
             uint64_t pending = mask_l | mask_r;
             if (wave_ballot(!done) == 0) pending = 0;
-            while (pending != 0) {                                                     // wave-uniform scalar loop
-                const int k = __ffsll(static_cast<unsigned long long>(pending)) - 1;
-                pending &= pending - 1;
-                const unsigned jj = chunk + static_cast<unsigned>(k);
-                const float4 ga = s_a[jj], gb = s_b[jj];
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
-                const float gauss = __expf(fminf(power, 0.0f));
-                const float alpha = gb.y * gauss;
-                // ONE predicate per (pixel, Gaussian) pair -- own sub-tile overlaps (kf:445-451), pixel not finished (kf:424,477), alpha
-                // test (kf:467) -- instead of three nested early-outs: every nested `continue` costs an EXEC save / branch / restore on
-                // the scalar unit (rocprofv3 on the layered scene, round 2: SQ_INSTS_SALU = SQ_INSTS_VALU = 457 M per launch, i.e. 0.74 ms
-                // of the kernel's 1.13 ms at one scalar instruction per cycle and CU).
-                if (((mine >> k) & 1ull) != 0 && T >= kTransmittanceThreshold && alpha >= kMinAlphaThreshold) {
-                    const float w = T * alpha;
-                    cr += w * gb.z; cg += w * gb.w; cb += w * s_c[jj].x;
-                    T *= 1.0f - alpha;
-                    n_used = batch_start + jj + 1;                                     // kf:474
+            // The walk over the set bits saturates the scalar unit (ONE per CU for four SIMDs; rocprofv3 on the layered scene, round 2:
+            // SQ_INSTS_SALU = SQ_INSTS_VALU = 457 M per launch), so every test of a (pixel, Gaussian) pair is ONE vector compare:
+            //  * the 64-bit list is walked as two bit-reversed 32-bit words from the top (count-leading-zeros / clear on single registers);
+            //  * "this Gaussian overlaps my sub-tile" (kf:445-451): the lane's complemented, reversed word shifted left by the same count
+            //    has its sign bit set exactly when it does NOT, and that bit is OR-ed into alpha -- a negative alpha fails the alpha test;
+            //  * "pixel not finished" (kf:424,477) is folded into the threshold: `gate` is 1/255 (kf:467) while the pixel is alive and
+            //    +inf from the update that takes T below the threshold (or outside the image), refreshed where T changes.
+            // Three compares, two scalar ANDs and a 64-bit vector shift before; the arithmetic is untouched (bit-identical images).
+#pragma unroll
+            for (unsigned word = 0; word < 2u; ++word) {
+                uint32_t pend = __brev(static_cast<uint32_t>(word ? pending >> 32 : pending));
+                const uint32_t not_mine = __brev(~static_cast<uint32_t>(word ? mine >> 32 : mine));
+                const unsigned j0 = chunk + 32u * word;
+                const unsigned row0 = in_vector_register(j0 * 16u);                     // byte offset of entry j0, kept out of the scalar unit
+                while (pend != 0) {                                                    // wave-uniform scalar loop
+                    const unsigned k = static_cast<unsigned>(__clz(static_cast<int>(pend)));
+                    pend &= ~(0x80000000u >> k);
+                    const float4* const entry = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k << 4)));
+                    const float4 ga = entry[0], gb = entry[kBlendBlock];
+                    const float dx = ga.x - pxf, dy = ga.y - pyf;
+                    const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                    const float gauss = __expf(fminf(power, 0.0f));
+                    const float alpha = gb.y * gauss;
+                    const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha));
+                    if (tested >= gate) {
+                        const float w = T * alpha;
+                        cr += w * gb.z; cg += w * gb.w; cb += w * entry[2 * kBlendBlock].x;
+                        T *= 1.0f - alpha;
+                        gate = T < kTransmittanceThreshold ? __builtin_inff() : gate;
+                        n_used = batch_start + j0 + k + 1;                             // kf:474
+                    }
                 }
             }
         }

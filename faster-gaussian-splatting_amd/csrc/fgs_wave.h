@@ -98,6 +98,9 @@ __device__ __forceinline__ void store_float4_nt(float* p, const float4 v) {
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+// A value the compiler must keep in a vector register (and cannot fold back into scalar address arithmetic): moves the per-pair LDS address
+// of the blend walk from two scalar instructions + a copy to one vector shift-add, in a loop bound by the scalar unit.
+__device__ __forceinline__ unsigned in_vector_register(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); } // v_exp_f32, 1 ulp (__expf = this after a multiply by log2 e)
 
 // One step of the backward pixel pipeline for NV per-pixel values:

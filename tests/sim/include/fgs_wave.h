@@ -85,6 +85,7 @@ inline float wave_shift_up1_zero(float v) {
 inline void wave_lds_fence() { sim::sync_scope(true); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_exp2(float x) { return exp2f(x); }
+inline unsigned in_vector_register(unsigned x) { return x; }
 inline float4 load_float4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
 inline void store_float4_nt(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

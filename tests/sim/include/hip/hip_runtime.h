@@ -164,6 +164,8 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll(static_cast<long long>(v)); }
+inline int __clz(int v) { return v ? __builtin_clz(static_cast<unsigned>(v)) : 32; }
+inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }

@@ -1,6 +1,6 @@
 """Stage times of the training iteration on S2 and on the layered scene (S2, opacity logits - 3) for the library named by FGS_HIP_LIBRARY (default:
 the current build) -- the process-level half of tools/ab_two_libs.sh. Prints one line per scene: ms / iteration and the stages named on the
-command line (default: the blend kernels)."""
+command line (default: the blend kernels; `all` = every stage and their sum)."""
 import sys, time, torch
 sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd']
 import bench
@@ -22,5 +22,6 @@ for shift in (0.0, -3.0):
     be.profile_enable(True); be.profile_read()
     for i in range(8): T.training_iteration(g, vs[i], tg[i], 20 + i)
     torch.cuda.synchronize(); pr = be.profile_read(); be.profile_enable(False)
-    print(f'shift {shift:4.1f}  {ms:.3f} ms/it  ' + '  '.join(f'{k} {pr[k][0] / 8:.4f}' for k in keys), flush=True)
+    ks = [k for k in pr if pr[k][1] > 0] if keys == ['all'] else keys
+    print(f'shift {shift:4.1f}  {ms:.3f} ms/it  ' + '  '.join(f'{k} {pr[k][0] / 8:.4f}' for k in ks) + (f'  sum {sum(pr[k][0] for k in ks) / 8:.3f}' if keys == ['all'] else ''), flush=True)
     del g, tg
