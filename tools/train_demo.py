@@ -4,7 +4,7 @@ subsample of it with perturbed means / grey colours / opacity 0.1 (Model.py:202-
 0.8 L1 + 0.2 DSSIM, FusedAdam, the SH-degree schedule, adaptive density control, opacity reset and Morton re-ordering on a
 compressed schedule. Prints one JSON line: PSNR before/after, Gaussian counts, iterations/s including the maintenance callbacks.
 
-usage: python tools/train_demo.py [--n 1000000] [--iters 600]
+usage: python tools/train_demo.py [--n 1000000] [--iters 600] [--save-ply out.ply]   (the export feeds `bench.py --ply`: a TRAINED scene's it/s)
 """
 import argparse, json, math, sys, time
 sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd']
@@ -14,6 +14,7 @@ from harness import trainer as T
 from harness.scenes import make_garden_like, orbit_views
 
 ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=1_000_000); ap.add_argument('--iters', type=int, default=600)
+ap.add_argument('--save-ply', default='')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 gt_params = make_garden_like(a.n)
@@ -46,6 +47,9 @@ for it in range(a.iters):
     v = it % len(views)
     loss = T.training_iteration(g, views[v], targets[v], it, densification_end=schedule['densification_end'])
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
+if a.save_ply:
+    from harness.ply import save_ply
+    save_ply(g, a.save_ply)
 print(json.dumps({'scene': f'garden-like {a.n} Gaussians ground truth, 8 views 1920x1080', 'iterations': a.iters, 'psnr_start_db': p0, 'psnr_end_db': mean_psnr(),
                   'gaussians_start': n0, 'gaussians_end': g.means.shape[0], 'counts_after_density_control': counts, 'final_loss': float(loss),
                   'active_sh_degree': g.active_sh_degree, 'iters_per_sec_incl_callbacks': a.iters / dt,
