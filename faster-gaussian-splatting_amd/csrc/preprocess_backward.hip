@@ -432,7 +432,7 @@ fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) 
 #pragma unroll
         for (int u = 0; u < kFusedUnroll; ++u) {
             const uint32_t e = e0 + 4u * kWave * static_cast<uint32_t>(u);
-            full[u] = e + 4u <= count;
+            full[u] = e + 4u <= count && a.vector_ok != 0;                             // 16-byte pieces need 16-byte aligned tensors (checked at launch)
             if (full[u]) { p4[u] = load_float4_nt(P + e); m4[u] = load_float4_nt(M + e); v4[u] = load_float4_nt(V + e); }
         }
 #pragma unroll
@@ -443,8 +443,8 @@ fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) 
                 adam_update(p4[u].x, m4[u].x, v4[u].x, g.x, sh.h); adam_update(p4[u].y, m4[u].y, v4[u].y, g.y, sh.h);
                 adam_update(p4[u].z, m4[u].z, v4[u].z, g.z, sh.h); adam_update(p4[u].w, m4[u].w, v4[u].w, g.w, sh.h);
                 store_float4_nt(P + e, p4[u]); store_float4_nt(M + e, m4[u]); store_float4_nt(V + e, v4[u]);
-            } else if (e < count) {                                                    // ragged tail of the last wave: < 4 floats
-                for (uint32_t j = e; j < count; ++j) {
+            } else if (e < count) {                                                    // ragged tail of the last wave (< 4 floats), or unaligned tensors
+                for (uint32_t j = e; j < count && j < e + 4u; ++j) {
                     float pp = P[j], mm = M[j], vv = V[j];
                     adam_update(pp, mm, vv, any_visible ? sh_rest_gradient_at<RT>(slice, j, R) : 0.0f, sh.h);
                     P[j] = pp; M[j] = mm; V[j] = vv;
@@ -527,6 +527,7 @@ hipError_t launch_fused_backward_adam(const PreprocessBackwardArgs& a_in, const 
     PreprocessBackwardArgs a = a_in;
     a.vector_ok = 1;
     for (int g = 0; g < 5; ++g) a.vector_ok = a.vector_ok && aligned16(a.p[g]) && aligned16(a.m[g]) && aligned16(a.v[g]);
+    a.vector_ok = a.vector_ok && aligned16(sh.p) && aligned16(sh.m) && aligned16(sh.v);          // phase B: a wave's block starts 64 * R * 12 bytes in
     const dim3 grid((a.n + 255u) / 256u), block(256);
     if (sh.total_sh_rest == 15) hipLaunchKernelGGL(fused_backward_adam_kernel<15>, grid, block, 0, s, a, sh);
     else hipLaunchKernelGGL(fused_backward_adam_kernel<0>, grid, block, 0, s, a, sh);

@@ -21,7 +21,15 @@ GRAD_OF = {'means': 'means', 'sh_coefficients_0': 'sh0', 'sh_coefficients_rest':
 LRS = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
 
 
-def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, label='', single_kernel=True, masked_budget=None):
+def _odd(t):
+    """The same values in a tensor that starts 4 bytes past a 16-byte boundary (a view one float into a buffer)."""
+    o = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)[1:].view(t.shape)
+    o.copy_(t)
+    assert t.numel() == 0 or o.data_ptr() % 16 == 4
+    return o
+
+
+def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, label='', single_kernel=True, masked_budget=None, unaligned=False):
     S, RS = helpers.settings_pair(view, K, aa, device=DEV)
     n = params['means'].shape[0]
     gen = torch.Generator().manual_seed(7)
@@ -29,6 +37,8 @@ def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, l
     M0 = {k: torch.randn(params[k].shape, generator=gen) * 1e-3 for k in ORDER}
     V0 = {k: torch.rand(params[k].shape, generator=gen) * 1e-6 for k in ORDER}
     dP, dM, dV = ({k: d[k].to(DEV).contiguous().clone() for k in ORDER} for d in (P0, M0, V0))
+    if unaligned:
+        dP, dM, dV = ({k: _odd(d[k]) for k in ORDER} for d in (dP, dM, dV))
     oP, oM, oV = ({k: np.ascontiguousarray(d[k].numpy().copy()) for k in ORDER} for d in (P0, M0, V0))
     gi = torch.randn(3, view.height, view.width, generator=gen) / (view.height * view.width)
     gi_np, gi_dev = gi.numpy(), gi.to(DEV)
@@ -97,6 +107,14 @@ def test_fused_ragged_sizes_sh_degrees_antialiasing(hip_backend, oracle, n, w, h
     p['means'][: n // 10, 2] = -10.0
     v = View(v.w2c, v.position, w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, 0.2, 1e4, torch.tensor([0.2, 0.5, 0.7]))
     _run(hip_backend, oracle, p, v, K, aa, steps=2, label=f'n{n}')
+
+
+def test_fused_unaligned_parameters_and_moments(hip_backend, oracle):
+    """Parameters and both moments of all six groups start 4 bytes past a 16-byte boundary: the kernel's 16-byte accesses (phase A's staged
+    blocks, phase B's SH-rest pieces) have to give way to the scalar path -- same values."""
+    p, v = make_s0(seed=5, n=333)
+    p['means'][:30, 2] = -10.0
+    _run(hip_backend, oracle, p, v, steps=2, label='unaligned', unaligned=True)
 
 
 def test_fused_two_kernel_form_s0(hip_backend, oracle):

@@ -200,9 +200,10 @@ def test_adam_single_and_multi(sim_backend, oracle):
     assert np.array_equal(tp[4].numpy(), P[4])
 
 
-@pytest.mark.parametrize('K', [16, 4])
-def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K):
-    """fused == backward -> FusedAdam.step() for all six groups, including invisible Gaussians."""
+@pytest.mark.parametrize('K,unaligned', [(16, False), (4, False), (16, True)])
+def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, unaligned):
+    """fused == backward -> FusedAdam.step() for all six groups, including invisible Gaussians. `unaligned`: the fused side's
+    parameters and moments start 4 bytes past a 16-byte boundary, which sends the fused kernel down its scalar path (same values)."""
     params, view = make_s0(n=400)
     params['means'][:40, 2] = -10.0                      # some invisible Gaussians: zero grad, moments still decay
     S, RS = helpers.settings_pair(view, K)
@@ -212,6 +213,14 @@ def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K):
     ref_m = {k: torch.randn_like(params[k]) * 1e-3 for k in order}
     ref_v = {k: torch.rand_like(params[k]) * 1e-6 for k in order}
     fus_p, fus_m, fus_v = ({k: d[k].clone() for k in order} for d in (ref_p, ref_m, ref_v))
+    if unaligned:
+        def odd(t):
+            base = torch.empty(t.numel() + 8, dtype=t.dtype)
+            shift = (1 - base.data_ptr() // 4) % 4                      # first float whose address is 4 bytes past a 16-byte boundary
+            o = base[shift:shift + t.numel()].view(t.shape); o.copy_(t)
+            assert o.data_ptr() % 16 == 4
+            return o
+        fus_p, fus_m, fus_v = ({k: odd(d[k]) for k in order} for d in (fus_p, fus_m, fus_v))
     gi = torch.randn(3, view.height, view.width, generator=torch.Generator().manual_seed(2))
     dens_ref, dens_fus = torch.zeros(2, 400), torch.zeros(2, 400)
     for step in (1, 2):
