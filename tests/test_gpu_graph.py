@@ -26,6 +26,19 @@ def _iteration(be, P, M, V, RS, target, capacity, step):
 
 def test_training_iteration_captures_into_a_graph(hip_backend):
     params, view = make_s0(n=5000)
+    # Distinct view depths: Gaussians whose depth keys are bit-identical are blended in the order the preprocess kernel's counter atomics
+    # arrive (kf:204-208 does the same with one atomicAdd per Gaussian), and that order may differ between an eager pass and a replay. The
+    # plain scene has 7 such pairs (camera looking down z from 4 units away: depth = z + 4 drops low bits); the test is about capture.
+    w2c = view.w2c.numpy().astype(np.float32)
+    for _ in range(8):
+        m = params['means'].numpy()
+        depth = ((m[:, 0] * w2c[2, 0] + m[:, 1] * w2c[2, 1]) + (m[:, 2] * w2c[2, 2] + w2c[2, 3])).astype(np.float32)
+        _, first, counts = np.unique(depth.view(np.uint32), return_index=True, return_counts=True)
+        if (counts > 1).sum() == 0:
+            break
+        dup = np.setdiff1d(np.arange(len(depth)), first)
+        params['means'][torch.from_numpy(dup), 2] += 1e-4 * (1.0 + torch.arange(len(dup), dtype=torch.float32))
+    assert (counts > 1).sum() == 0
     _, RS = helpers.settings_pair(view, device=DEV)
     target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(1)).to(DEV)
     seeds = {k: helpers.seeded_moments(params[k].shape, 11 + i) for i, k in enumerate(ORDER)}   # non-zero moments: see helpers.seeded_moments
