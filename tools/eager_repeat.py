@@ -1,0 +1,56 @@
+"""How reproducible are two EAGER training iterations (tests/test_gpu_graph.py's scene and step)? Runs them 24 times from the same start and
+counts the distinct outcomes per tensor, and the largest difference between any two in units of the test's bar (rel_inf of the movement)."""
+import hashlib, sys
+sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd', '/root/repo/tests']
+import numpy as np, torch
+import helpers
+from harness.scenes import make_s0
+from test_gpu_graph import _iteration, ORDER
+be = helpers.backend_modules()[1].default_backend() if hasattr(helpers.backend_modules()[1], 'default_backend') else None
+from FasterGSCudaBackend._backend import default_backend
+be = default_backend()
+DEV = 'cuda'
+params, view = make_s0(n=5000)
+if len(sys.argv) > 1 and sys.argv[1] == 'detie':
+    w2c = view.w2c.numpy().astype(np.float32)
+    for _ in range(8):
+        m = params['means'].numpy()
+        depth = ((m[:, 0] * w2c[2, 0] + m[:, 1] * w2c[2, 1]) + (m[:, 2] * w2c[2, 2] + w2c[2, 3])).astype(np.float32)
+        _, first, counts = np.unique(depth.view(np.uint32), return_index=True, return_counts=True)
+        if (counts > 1).sum() == 0: break
+        dup = np.setdiff1d(np.arange(len(depth)), first)
+        params['means'][torch.from_numpy(dup), 2] += 1e-4 * (1.0 + torch.arange(len(dup), dtype=torch.float32))
+    print('ties left', int((counts > 1).sum()))
+_, RS = helpers.settings_pair(view, device=DEV)
+target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(1)).to(DEV)
+seeds = {k: helpers.seeded_moments(params[k].shape, 11 + i) for i, k in enumerate(ORDER)}
+fresh = lambda: ({k: params[k].to(DEV).clone() for k in ORDER}, {k: seeds[k][0].to(DEV) for k in ORDER}, {k: seeds[k][1].to(DEV) for k in ORDER})
+sync = be.forward(*[params[k].to(DEV) for k in helpers.NAMES], RS)
+capacity = int(1.25 * sync.state[1]) + 4096
+outs = []
+for r in range(24):
+    P, M, V = fresh()
+    for _ in range(2): _iteration(be, P, M, V, RS, target, capacity, 1)
+    torch.cuda.synchronize()
+    outs.append({k: P[k].cpu().numpy().copy() for k in ORDER})
+start = {k: params[k].numpy() for k in ORDER}
+for k in ORDER:
+    hs = [hashlib.md5(o[k].tobytes()).hexdigest()[:6] for o in outs]
+    worst = max(helpers.rel_inf(o[k] - start[k], outs[0][k] - start[k]) for o in outs)
+    print(f'{k:22s} distinct outcomes {len(set(hs)):2d} of 24   worst rel_inf of the movement vs run 0: {worst:.3e}')
+
+# where do two outcomes differ, and do the Gaussians involved share a depth key on the device?
+a = outs[0]['means']; b = next((o['means'] for o in outs if not np.array_equal(o['means'], a)), None)
+if b is not None:
+    rows = np.where((a != b).any(axis=1))[0]
+    dec = helpers.decode_forward(be, sync, 5000, view.width, view.height)
+    sel = 0 if dec['I'] >= 0 else 0
+    keys = None
+    for nm in ('depth_keys0', 'depth_keys1'):
+        if nm in dec: keys = dec[nm]; prim = dec['prim_idx' + nm[-1]]; break
+    print('rows that differ:', rows[:20], 'count', len(rows))
+    if keys is not None:
+        V = dec['V']; k = np.asarray(keys[:V]); pr = np.asarray(prim[:V])
+        u, c = np.unique(k, return_counts=True)
+        tied = set(pr[np.isin(k, u[c > 1])].tolist())
+        print('device depth-key ties among visible:', int((c > 1).sum()), ' differing rows that are tied:', [int(r) for r in rows if int(r) in tied][:20])

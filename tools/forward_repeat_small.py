@@ -1,0 +1,31 @@
+"""Forward / backward of the graph-test scene repeated from the same parameters: which outputs are not bit-reproducible?"""
+import hashlib, sys
+sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd', '/root/repo/tests']
+import numpy as np, torch
+import helpers
+from harness.scenes import make_s0
+from FasterGSCudaBackend._backend import default_backend
+be = default_backend(); DEV = 'cuda'
+params, view = make_s0(n=5000)
+_, RS = helpers.settings_pair(view, device=DEV)
+target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(1)).to(DEV)
+dp = {k: params[k].to(DEV) for k in helpers.NAMES}
+h = lambda a: hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()[:6]
+seen = {}
+G = []
+for r in range(24):
+    res = be.forward(*[dp[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(be, res, 5000, view.width, view.height)
+    gi = be.l1_dssim(res.image, target, 0.8, 0.2)[1]
+    grads = be.backward(None, gi, res.image, dp['means'], dp['scales'], dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    torch.cuda.synchronize()
+    items = {'image': res.image.cpu().numpy(), 'grad_image': gi.cpu().numpy(), 'n_touched': dec['n_touched'], 'mean2d': dec['mean2d'], 'conic_opacity': dec['conic_opacity'],
+             'color': dec['color'], 'inst_prims': dec['inst_prims'], 'inst_keys': dec['inst_keys'], 'n_processed': dec['n_processed_tiles'], 'final_T': dec['final_T_tiles']}
+    for k, g in zip(helpers.NAMES, grads): items['grad_' + k] = g.cpu().numpy()
+    G.append(items['grad_means'].copy())
+    for k, v in items.items(): seen.setdefault(k, set()).add(h(v))
+for k, v in seen.items(): print(f'{k:22s} distinct {len(v)}')
+a = G[0]
+for b in G[1:]:
+    if not np.array_equal(a, b):
+        rows = np.where((a != b).any(axis=1))[0]; print('grad_means rows that differ:', rows[:10], a[rows[0]], b[rows[0]]); break
