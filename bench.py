@@ -326,6 +326,12 @@ def main():
         del r_
         return caps
 
+    # Setup, outside warm-up and timing: one iteration per view of this rank, so that the scratch blobs (sized per view through the resize
+    # callback) and torch's caching allocator have reached their steady state whatever --warmup is. A view first met inside the timed region
+    # costs a device allocation there (one 20-step block read 2.63 ms against 2.34-2.35 for the others, profiles/README.md round 3).
+    for i in range(len(my_views) if vp is None else 2):
+        step(i)
+    fence()
     torch.cuda.reset_peak_memory_stats(device)
     for i in range(args.warmup):
         step(i)
