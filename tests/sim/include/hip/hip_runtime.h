@@ -3,7 +3,6 @@
 // sources + the C-ABI host orchestration against the oracle in the GPU-less build container (tests/test_sim_parity.py).
 // It is never built by, shipped with, or loaded from the product package; see tests/sim/README.md.
 #pragma once
-#include <ucontext.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -34,11 +33,40 @@ inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
+// Fiber switch: the six callee-saved registers and the stack pointer (System V x86-64), nothing else -- glibc's swapcontext / getcontext make a
+// signal-mask system call per switch, and a forward pass of 200 Gaussians runs ~0.5 M fibers through here (the fixed-size grids of the sort's
+// row scans alone are 3 x 512 workgroups of 256 work-items): 1.6 s per pass with ucontext. A file-local symbol per translation unit.
+#if !defined(__x86_64__)
+#error "the CPU simulation's fiber switch is written for x86-64"
+#endif
+asm(R"(
+    .text
+    .type fgs_sim_switch_local,@function
+fgs_sim_switch_local:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size fgs_sim_switch_local, .-fgs_sim_switch_local
+)");
+extern "C" void fgs_sim_switch(void** save_sp, void** load_sp) asm("fgs_sim_switch_local");
+
 namespace sim {
 
 constexpr int kSlots = 24;
 struct Lane {
-    ucontext_t ctx;
+    void* sp = nullptr;          // saved stack pointer while the fiber is not running
     bool alive = false;
     unsigned gen_wave = 0, gen_block = 0;
     uint64_t slot[2][kSlots];
@@ -48,21 +76,22 @@ struct Block {
     std::vector<char> stacks;
     int n = 0, cur = 0;
     unsigned block_idx = 0, block_idy = 0, block_idz = 0, block_dim = 0, grid_dim = 0, grid_dimy = 1, grid_dimz = 1;
-    ucontext_t main_ctx;
+    void* main_sp = nullptr;
     std::function<void()> body;
     unsigned long progress = 0;
 };
 inline Block& blk() { static Block b; return b; }
 inline Lane& me() { return blk().lanes[blk().cur]; }
 inline unsigned tid() { return static_cast<unsigned>(blk().cur); }
-inline void yield() { Block& b = blk(); swapcontext(&b.lanes[b.cur].ctx, &b.main_ctx); }
+inline void yield() { Block& b = blk(); fgs_sim_switch(&b.lanes[b.cur].sp, &b.main_sp); }
 
 inline void trampoline() {
     Block& b = blk();
     b.body();
     b.lanes[b.cur].alive = false;
     ++b.progress;
-    swapcontext(&b.lanes[b.cur].ctx, &b.main_ctx);
+    fgs_sim_switch(&b.lanes[b.cur].sp, &b.main_sp);      // never resumed
+    abort();
 }
 
 inline void run_block(unsigned block_idx, unsigned block_dim, unsigned grid_dim, const std::function<void()>& body) {
@@ -73,11 +102,15 @@ inline void run_block(unsigned block_idx, unsigned block_dim, unsigned grid_dim,
     for (int i = 0; i < b.n; ++i) {
         Lane& L = b.lanes[i];
         L.alive = true; L.gen_wave = 0; L.gen_block = 0;
-        getcontext(&L.ctx);
-        L.ctx.uc_stack.ss_sp = b.stacks.data() + kStack * i;
-        L.ctx.uc_stack.ss_size = kStack;
-        L.ctx.uc_link = &b.main_ctx;
-        makecontext(&L.ctx, (void (*)())trampoline, 0);
+        // a fresh fiber: six zeroed callee-saved registers and the entry point as the return address of the first switch; the entry point
+        // must see the stack as after a CALL (rsp = 8 mod 16), and a zero return address ends any unwinder's walk
+        uintptr_t top = reinterpret_cast<uintptr_t>(b.stacks.data() + kStack * (i + 1));
+        top &= ~static_cast<uintptr_t>(15);
+        void** sp = reinterpret_cast<void**>(top);
+        *--sp = nullptr;                                            // fake return address of trampoline: rsp = 8 mod 16 at its first instruction
+        *--sp = reinterpret_cast<void*>(&trampoline);
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        L.sp = sp;
     }
     int alive = b.n;
     unsigned long stale_rounds = 0;
@@ -87,7 +120,7 @@ inline void run_block(unsigned block_idx, unsigned block_dim, unsigned grid_dim,
         for (int i = 0; i < b.n; ++i) {
             if (!b.lanes[i].alive) continue;
             b.cur = i;
-            swapcontext(&b.main_ctx, &b.lanes[i].ctx);
+            fgs_sim_switch(&b.main_sp, &b.lanes[i].sp);
             if (b.lanes[i].alive) ++alive;
         }
         if (b.progress == before && alive > 0) {
