@@ -14,27 +14,7 @@ from test_gpu_parity import _flip_aware_forward_backward
 pytestmark = pytest.mark.gpu
 
 
-def _configuration(seed: int):
-    rng = np.random.default_rng(7000 + seed)
-    n = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 500, 1000, 2047, 2049, 3000]))
-    W, H = int(rng.integers(17, 420)), int(rng.integers(13, 300))
-    near, far = float(rng.choice([0.01, 0.2, 1.0, 3.2])), float(rng.choice([4.6, 100.0, 1.0e4]))
-    K, aa = int(rng.choice([1, 4, 9, 16])), bool(rng.integers(0, 2))
-    p, v = make_s0(seed=100 + seed, n=n)
-    g = torch.Generator().manual_seed(seed)
-    pick = lambda frac: torch.rand(n, generator=g) < frac
-    p['scales'][pick(0.03)] += 2.5                               # screen-filling: medium / huge / hot footprint paths
-    p['scales'][pick(0.05)] -= 3.0                               # sub-pixel
-    p['means'][pick(0.05), 2] = -9.0                             # behind the camera
-    p['means'][pick(0.03), 2] = 2.0e4                            # beyond every far plane
-    p['rotations'][pick(0.02)] = 0.0                             # |q|^2 < 1e-8
-    p['opacities'][pick(0.05)] = float(np.log((1 / 255) / (1 - 1 / 255))) + 1e-3     # sigmoid just above the cut
-    p['opacities'][pick(0.02)] = -20.0
-    focal = float(W) * float(rng.uniform(0.6, 1.4))
-    bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
-    view = View(v.w2c, v.position, W, H, focal, focal * float(rng.uniform(0.9, 1.1)), W / 2 + float(rng.uniform(-9, 9)), H / 2 + float(rng.uniform(-9, 9)),
-                near, far, bg)
-    return p, view, K, aa, f'seed {seed}: n={n} {W}x{H} near={near} far={far} K={K} aa={aa}'
+_configuration = helpers.fuzz_configuration
 
 
 @pytest.mark.parametrize('seed', range(32))

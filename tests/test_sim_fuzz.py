@@ -1,0 +1,14 @@
+"""CPU test: the seeded random configurations of tests/test_gpu_fuzz.py (ragged counts, odd image sizes, near / far planes, every SH degree, both
+antialiasing modes, screen-filling / sub-pixel / culled / degenerate Gaussians, opacities on the 1/255 cut) through the product sources in the
+fiber simulator against the oracle: every forward intermediate and the image BIT-EXACT (the simulator shares libm with the oracle and keeps
+the reference's operation order), the gradients to 1e-5 (summation order)."""
+import pytest
+
+import helpers
+from test_sim_parity import _run
+
+
+@pytest.mark.parametrize('seed', range(32))
+def test_random_configuration_in_the_simulator(sim_backend, oracle, seed):
+    p, view, K, aa, label = helpers.fuzz_configuration(seed)
+    _run(sim_backend, oracle, p, view, K, aa)
