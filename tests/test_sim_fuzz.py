@@ -5,10 +5,17 @@ the reference's operation order), the gradients to 1e-5 (summation order)."""
 import pytest
 
 import helpers
-from test_sim_parity import _run
+from test_sim_parity import _run, fused_equals_backward_then_adam
 
 
 @pytest.mark.parametrize('seed', range(32))
 def test_random_configuration_in_the_simulator(sim_backend, oracle, seed):
     p, view, K, aa, label = helpers.fuzz_configuration(seed)
     _run(sim_backend, oracle, p, view, K, aa)
+
+
+@pytest.mark.parametrize('seed', range(0, 32, 5))
+def test_random_configuration_fused_equals_unfused_in_the_simulator(sim_backend, seed):
+    """The same configurations: fgs_backward_adam_fused == fgs_backward -> fgs_adam_step_multi, two steps, bit for bit."""
+    p, view, K, aa, label = helpers.fuzz_configuration(seed)
+    fused_equals_backward_then_adam(sim_backend, p, view, K, aa)

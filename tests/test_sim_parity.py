@@ -200,13 +200,11 @@ def test_adam_single_and_multi(sim_backend, oracle):
     assert np.array_equal(tp[4].numpy(), P[4])
 
 
-@pytest.mark.parametrize('K,unaligned', [(16, False), (4, False), (16, True)])
-def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, unaligned):
-    """fused == backward -> FusedAdam.step() for all six groups, including invisible Gaussians. `unaligned`: the fused side's
-    parameters and moments start 4 bytes past a 16-byte boundary, which sends the fused kernel down its scalar path (same values)."""
-    params, view = make_s0(n=400)
-    params['means'][:40, 2] = -10.0                      # some invisible Gaussians: zero grad, moments still decay
-    S, RS = helpers.settings_pair(view, K)
+def fused_equals_backward_then_adam(sim_backend, params, view, K=16, aa=False, unaligned=False):
+    """fused == backward -> FusedAdam.step() for all six groups, including invisible Gaussians, bit for bit in the simulator.
+    `unaligned`: the fused side's parameters and moments start 4 bytes past a 16-byte boundary (the fused kernel's scalar path)."""
+    n = params['means'].shape[0]
+    S, RS = helpers.settings_pair(view, K, aa)
     order = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
     lrs = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
     ref_p = {k: params[k].clone() for k in order}
@@ -222,7 +220,7 @@ def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, u
             return o
         fus_p, fus_m, fus_v = ({k: odd(d[k]) for k in order} for d in (fus_p, fus_m, fus_v))
     gi = torch.randn(3, view.height, view.width, generator=torch.Generator().manual_seed(2))
-    dens_ref, dens_fus = torch.zeros(2, 400), torch.zeros(2, 400)
+    dens_ref, dens_fus = torch.zeros(2, n), torch.zeros(2, n)
     for step in (1, 2):
         res = sim_backend.forward(*[ref_p[k] for k in helpers.NAMES], RS)
         grads = sim_backend.backward(dens_ref, gi, res.image, ref_p['means'], ref_p['scales'], ref_p['rotations'], ref_p['opacities'],
@@ -237,6 +235,13 @@ def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, u
             assert torch.equal(fus_p[k], ref_p[k]), (step, k)
             assert torch.equal(fus_m[k], ref_m[k]) and torch.equal(fus_v[k], ref_v[k]), (step, k)
     assert torch.equal(dens_ref, dens_fus)
+
+
+@pytest.mark.parametrize('K,unaligned', [(16, False), (4, False), (16, True)])
+def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, unaligned):
+    params, view = make_s0(n=400)
+    params['means'][:40, 2] = -10.0                      # some invisible Gaussians: zero grad, moments still decay
+    fused_equals_backward_then_adam(sim_backend, params, view, K, False, unaligned)
 
 
 def test_error_reporting(sim_backend):
