@@ -244,6 +244,17 @@ def test_fused_backward_adam_equals_backward_then_adam(sim_backend, oracle, K, u
     fused_equals_backward_then_adam(sim_backend, params, view, K, False, unaligned)
 
 
+@pytest.mark.parametrize('n,w,h,focal', [(20_000, 320, 180, 237.0), (60_001, 640, 360, 473.0)])
+def test_garden_like_mid_size_scenes(sim_backend, oracle, n, w, h, focal):
+    """The bench's scene generator at sizes where every kernel runs many workgroups (multi-block sort passes, several buckets per tile, tiles
+    with hundreds of instances): forward intermediates and image bit-exact against the oracle, gradients to 1e-5."""
+    from harness.scenes import make_garden_like, orbit_views
+    params = make_garden_like(n)
+    params['scales'] = params['scales'] + (1.0 if n < 50_000 else 0.7)        # footprints as large, in tiles, as the 1080p scenes' (cf. test_gpu_parity)
+    res, f = _run(sim_backend, oracle, params, orbit_views(8, width=w, height=h, focal=focal)[1])
+    assert f['V'] > n // 3 and f['B'] > f['ranges'].shape[0] // 2
+
+
 def test_error_reporting(sim_backend):
     params, view = make_s0(n=8)
     _, RS = helpers.settings_pair(view)
