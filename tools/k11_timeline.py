@@ -6,7 +6,7 @@ shift = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 import bench
 from FasterGSCudaBackend._backend import default_backend
 from harness import trainer as T
-sys.argv = ['bench.py']
+sys.argv = ['bench.py'] + (['--ply', os.environ['FGS_PLY']] if os.environ.get('FGS_PLY') else [])     # FGS_PLY: a trained scene instead of S2
 params, views, _ = bench.build_scene(bench.parse())
 params['opacities'] = params['opacities'] + shift
 dev = torch.device('cuda:0'); be = default_backend()
@@ -46,3 +46,6 @@ print('  start of item #k at (share of span): k=0 %.3f, 10%% %.3f, 25%% %.3f, 50
 print('  items per XCD:', np.bincount(xcc, minlength=8).tolist(), ' end of the last item per XCD (share of span):', [round(float((end[xcc == x].max() - t0) / span), 2) for x in range(8) if (xcc == x).any()])
 early = dur[(start - t0) < 0.3 * span]; late = dur[(start - t0) > 0.7 * span]
 print(f'  item duration us, started in the first 30 % of the span: median {np.median(early) / 100:.1f}; in the last 30 %: median {np.median(late) / 100 if len(late) else float("nan"):.1f}')
+n_px = steps - 63
+hist = np.bincount(np.clip(n_px // 24, 0, 8), minlength=9)
+print('  live pixels per item (bins of 24, last = 192):', hist.tolist(), ' share of all steps spent on fill / drain (63 of n_px + 63):', round(float(63 * len(steps) / steps.sum()), 3))
