@@ -51,10 +51,7 @@ def _run_sharded_by_hand(be, params, views, grad_images, n_shards, dens=None, de
     return rendered, table, grads
 
 
-@pytest.mark.parametrize('n_shards', [1, 2, 3])
-def test_cut_pipeline_equals_whole_pipeline(n_shards):
-    params, settings, _ = _scene()
-    s = settings[0]
+def _cut_equals_whole(params, s, n_shards):
     be = helpers.poisoned(helpers.sim_backend())      # scratch buffers start as NaN / 0xFF garbage
     whole = be.forward(*(params[k] for k in ORDER), s)
     torch.manual_seed(3)
@@ -74,6 +71,21 @@ def test_cut_pipeline_equals_whole_pipeline(n_shards):
             assert torch.isfinite(g).all(), k
             assert torch.allclose(g, r[sh::n_shards], rtol=1e-4, atol=1e-7), (k, (g - r[sh::n_shards]).abs().max())
         assert torch.allclose(dens[sh], info_ref[:, sh::n_shards], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('n_shards', [1, 2, 3])
+def test_cut_pipeline_equals_whole_pipeline(n_shards):
+    params, settings, _ = _scene()
+    _cut_equals_whole(params, settings[0], n_shards)
+
+
+@pytest.mark.parametrize('seed', [1, 4, 6, 9, 13, 22])
+def test_cut_pipeline_equals_whole_pipeline_on_fuzz_configurations(seed):
+    """The seeded configurations of the fuzz tests (helpers.fuzz_configuration: 2 Gaussians -- an empty shard --, counts around the wavefront
+    size, 3000 Gaussians, odd image sizes, near / far planes, both antialiasing modes, culled / degenerate / screen-filling Gaussians) cut
+    into three shards: records out, rendered from records, accumulators back, gradients on the owners == the undivided pipeline."""
+    p, view, K, aa, label = helpers.fuzz_configuration(seed)
+    _cut_equals_whole(p, helpers.settings_pair(view, K, aa)[1], 3)
 
 
 @pytest.mark.parametrize('n_views', [2, 9])
