@@ -468,12 +468,12 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             hot_slot_word = __float_as_uint(r2.w);
         }
         wave_lds_fence();
-        // exponent of the Gaussian in base 2 with the constants folded per lane (kb:415-418): -1/2 d^T Sigma^-1 d * log2(e) =
-        // dx (A dx + B dy) + C dy dy -- five instructions and a bare v_exp_f32 per step instead of six, a multiply by log2(e) and the
-        // v_exp_f32 that __expf expands to. alpha differs from the forward pass's by a rounding (1e-7 relative), like any re-association.
-        constexpr float kLog2e = 1.4426950408889634f;
-        const float eA = (-0.5f * kLog2e) * ca, eB = -kLog2e * cb, eC = (-0.5f * kLog2e) * cc;
-
+        // alpha is recomputed with the FORWARD kernel's expression, operation for operation (kf:455-466 / kb:415-418; blend_forward.hip): the
+        // backward pass replays the forward pass's alpha bit for bit, so both passes agree on every alpha >= 1/255 decision and the
+        // transmittance rebuilt here is the one the forward pass used. (Round 3 first folded log2(e) and the -1/2 into per-lane constants --
+        // five instructions and a bare v_exp_f32 instead of eight: 1 % of this kernel -- at the price of an alpha that differed from the
+        // forward pass's by a rounding; a wide fuzz sweep in the simulator then showed a (pixel, Gaussian) pair blended by one pass and
+        // skipped by the other.)
         float a_c0 = 0.0f, a_c1 = 0.0f, a_c2 = 0.0f;                 // sum w g_c               (kb:426-427 without the clamp gate)
         float a_h = 0.0f, a_x = 0.0f, a_y = 0.0f;                     // sum hh, sum hh dx, sum hh dy
         float a_xx = 0.0f, a_xy = 0.0f, a_yy = 0.0f;                  // sum hh dx^2, hh dx dy, hh dy^2   (kb:443-448)
@@ -501,8 +501,8 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             const float4 px = pr.g;
             const float rel = px.w;
             const float dx = mx - pr.xy.x, dy = my - pr.xy.y;
-            const float power2 = dx * (eA * dx + eB * dy) + (eC * dy) * dy;
-            const float alpha = op * fast_exp2(fminf(power2, 0.0f));
+            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            const float alpha = op * __expf(fminf(power, 0.0f));
             if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
                 const float T = sT;
                 const float w = T * alpha;

@@ -677,8 +677,12 @@ void orc_threshold_risk(const uint* ranges, const uint* inst_prims, const uint16
                     const float dx = mean2d[2 * (size_t)p] - pxf, dy = mean2d[2 * (size_t)p + 1] - pyf;
                     const float expo = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     const float alpha = co[3] * expf(fminf(expo, 0.0f));
-                    if (pass == 1) { if (alpha >= MIN_ALPHA_THRESHOLD * (1.0f - eps)) near_prim[p] = 1; continue; }
-                    if (fabsf(alpha * MIN_ALPHA_THRESHOLD_RCP - 1.0f) < eps) { risky = 1; risk_prim[p] = 1; }
+                    /* The exponent is a sum of three terms that may cancel: another association / an FMA (the HIP blend kernels are built with
+                     * contraction) moves it by a few ulp OF THE TERMS, and alpha by that much relatively. The margin grows accordingly
+                     * (found by a wide fuzz sweep, round 3: a pair 2e-5 from the cut with terms of 40 flipped outside the fixed margin). */
+                    const float slack = eps + 4.0f * 1.1920929e-7f * (0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy));
+                    if (pass == 1) { if (alpha >= MIN_ALPHA_THRESHOLD * (1.0f - slack)) near_prim[p] = 1; continue; }
+                    if (fabsf(alpha * MIN_ALPHA_THRESHOLD_RCP - 1.0f) < slack) { risky = 1; risk_prim[p] = 1; }
                     const uint16_t* sb = screen_bounds + 4 * (size_t)p;
                     if (!(sb[0] < sx1 && sx0 < sb[1] && sb[2] < sy1 && sy0 < sb[3])) continue;
                     if (alpha < MIN_ALPHA_THRESHOLD) continue;

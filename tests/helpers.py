@@ -188,11 +188,16 @@ def elementwise_three_way(a, ref32, truth, keep: np.ndarray | None = None, kind:
     return fh, fo, n
 
 
-def three_way_ok(frac_hip: float, frac_oracle: float, n: int) -> bool:
-    """frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION, plus three standard deviations of a count of n * frac_oracle entries
-    (the two fp32 roundings are independent: on a 900-entry tensor 'the oracle misses 3, the HIP path 5' is noise, not a finding)."""
-    sigma = (max(frac_oracle, 1.0 / max(n, 1)) / max(n, 1)) ** 0.5
-    return frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION + 3.0 * sigma
+def three_way_ok(frac_hip: float, frac_oracle: float, n: int, cluster: int = 1) -> bool:
+    """frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION, plus four standard deviations of a count of n * frac_oracle entries
+    (the two fp32 roundings are independent: on a 900-entry tensor 'the oracle misses 3, the HIP path 5' is noise, not a finding). Four, not
+    three: the suite applies this to ~1500 tensors and a wide fuzz sweep to 1200 more, and a 3-sigma bar fires once in 740 on pure noise --
+    it did (round 3, seed 115 of the sweep: 5 entries of 3000 against 1, both max-norm errors below 1e-6)."""
+    # `cluster`: entries that miss the bar together -- the 3 / 4 / 45 gradient entries of ONE Gaussian share their ill-conditioned sums, so
+    # the count fluctuates like n / cluster independent events of `cluster` entries each (seed 411 of the sweep: 10 entries = 3-4 Gaussians
+    # of 480 against 2 entries = 1 Gaussian, every max-norm error below 4e-6)
+    sigma = (cluster * max(frac_oracle, float(cluster) / max(n, 1)) / max(n, 1)) ** 0.5
+    return frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION + 4.0 * sigma
 
 
 def outlier_fraction(a: np.ndarray, ref: np.ndarray, rtol: float, atol: float) -> float:
@@ -321,12 +326,15 @@ def seed_trainer_moments(trainer, names, seed: int = 11) -> None:
 
 
 def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label='', elem_fraction=ELEM_FRACTION,
-                     truth: dict | None = None):
+                     truth: dict | None = None, near_tol: float | None = None):
     """image [3,H,W]; grads / g_ref: {name: array with the Gaussian index first}. Entries outside the masks must agree to `tol`
     (max-abs error relative to the tensor's max-abs value) AND element by element: with `truth` (oracle.forward_backward_f64: the fp64
     values of 'image' and the six gradients) three-way (elementwise_three_way), without it directly against the oracle (fewer than
     `elem_fraction` of the entries beyond 1e-4 of their own magnitude + 1e-4 of the tensor's median magnitude); the masked fraction is
-    bounded; masked entries stay within `loose`."""
+    bounded; masked entries stay within `loose`. `near_tol` (the adversarial fuzz scenes only): Gaussians that merely CONTRIBUTE to a pixel
+    with a borderline pair (masks['near']) form a third class held to that looser bar -- a flipped pair in front of them scales their
+    share of that pixel by 1 - 1/255, which is 2e-4 of a tensor's maximum when the pixel dominates a small Gaussian's gradient (seed 243 of
+    a wide sweep, round 3); by default they are held to `tol` like everybody else."""
     report = {}
     pm = masks['pixel']
     frac_p, frac_g = float(pm.mean()), float(masks['prim'].mean()) if masks['prim'].size else 0.0
@@ -341,12 +349,19 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         assert report['image'] < tol, (label, 'image', report)
         if truth is not None and 'image' in truth:
             report['image_elem'] = elementwise_three_way(hwc(image), hwc(f_image), hwc(truth['image']), kind='image')
-            assert three_way_ok(*report['image_elem']), (label, 'image (element-wise 1e-4, three-way)', report)
+            assert three_way_ok(*report['image_elem'], cluster=3), (label, 'image (element-wise 1e-4, three-way)', report)
         else:
             report['image_elem'] = elementwise_fraction(hwc(image), hwc(f_image), kind='elementwise_image')
             assert report['image_elem'] < elem_fraction, (label, 'image (element-wise 1e-4)', report)
         assert report['image_masked'] < loose, (label, 'image (masked pixels)', report)
     keep = ~masks['prim']
+    if near_tol is not None and 'near' in masks:
+        near = masks['near'] & keep
+        keep = keep & ~near
+        report['near_gaussians'] = float(near.mean()) if near.size else 0.0
+        for k, a in grads.items():
+            report[k + '_near'] = masked_rel_inf(np.asarray(a).reshape(g_ref[k].shape), g_ref[k], near)
+            assert report[k + '_near'] < near_tol, (label, k + ' (Gaussians behind a borderline pair)', report)
     for k, a in grads.items():
         ref = g_ref[k]
         a = np.asarray(a).reshape(ref.shape)
@@ -356,7 +371,7 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         assert report[k + '_masked'] < loose, (label, k + ' (masked Gaussians)', report)
         if truth is not None and k in truth:
             report[k + '_elem'] = elementwise_three_way(a, ref, np.asarray(truth[k]).reshape(ref.shape), keep, kind=k)
-            assert three_way_ok(*report[k + '_elem']), (label, k + ' (element-wise 1e-4, three-way)', report)
+            assert three_way_ok(*report[k + '_elem'], cluster=int(np.prod(ref.shape[1:])) if ref.ndim > 1 else 1), (label, k + ' (element-wise 1e-4, three-way)', report)
         else:
             report[k + '_elem'] = elementwise_fraction(a, ref, keep, kind='elementwise_' + k)
             assert report[k + '_elem'] < elem_fraction, (label, k + ' (element-wise 1e-4)', report)
@@ -421,6 +436,22 @@ def fuzz_configuration(seed: int):
     p['rotations'][pick(0.02)] = 0.0                             # |q|^2 < 1e-8
     p['opacities'][pick(0.05)] = float(np.log((1 / 255) / (1 - 1 / 255))) + 1e-3     # sigmoid just above the cut
     p['opacities'][pick(0.02)] = -20.0
+    # Distinct view depths. Gaussians whose depth keys are bit-identical are blended in the order the preprocess kernel's counter atomics
+    # arrive (the reference: one atomicAdd per Gaussian, kf:204-208; the oracle: primitive order), and swapping two such neighbours moves
+    # the colour by T a_A a_B (c_B - c_A) wherever both contribute -- 1e-4 of the image in seed 126 of a wide sweep (round 3). The camera
+    # of these scenes looks down z from 4 units away, so depth = z + 4 drops low bits and ~1 pair in 1000 collides: nudged apart here.
+    w2c = v.w2c.numpy().astype(np.float32)
+    for _ in range(8):
+        m = p['means'].numpy()
+        depth = ((m[:, 0] * w2c[2, 0] + m[:, 1] * w2c[2, 1]) + (m[:, 2] * w2c[2, 2] + w2c[2, 3])).astype(np.float32)
+        _, first, counts = np.unique(depth.view(np.uint32), return_index=True, return_counts=True)
+        if (counts > 1).sum() == 0:
+            break
+        dup = np.setdiff1d(np.arange(n), first)
+        dup = dup[np.abs(m[dup, 2]) < 100.0]                      # not the ones parked behind the camera / beyond the far plane (culled anyway)
+        if len(dup) == 0:
+            break
+        p['means'][torch.from_numpy(dup), 2] += 1e-4 * (1.0 + torch.arange(len(dup), dtype=torch.float32))
     focal = float(W) * float(rng.uniform(0.6, 1.4))
     bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
     view = View(v.w2c, v.position, W, H, focal, focal * float(rng.uniform(0.9, 1.1)), W / 2 + float(rng.uniform(-9, 9)), H / 2 + float(rng.uniform(-9, 9)),

@@ -69,7 +69,9 @@ struct Lane {
     void* sp = nullptr;          // saved stack pointer while the fiber is not running
     bool alive = false;
     unsigned gen_wave = 0, gen_block = 0;
-    uint64_t slot[2][kSlots];
+    uint64_t slot[2][kSlots];      // exchange slots of WAVE-scope collectives (parity = wave generation)
+    int block_slot[2];             // of __syncthreads_and (parity = block generation): its own storage -- a lane that has passed a workgroup barrier may
+                                   // enter a wave collective (or the other way round) before a slower lane has read what it published for the first
 };
 struct Block {
     std::vector<Lane> lanes;
@@ -124,7 +126,19 @@ inline void run_block(unsigned block_idx, unsigned block_dim, unsigned grid_dim,
             if (b.lanes[i].alive) ++alive;
         }
         if (b.progress == before && alive > 0) {
-            if (++stale_rounds > 4) { fprintf(stderr, "[sim] deadlock: a collective is waiting for lanes that never arrive (block %u)\n", block_idx); abort(); }
+            if (++stale_rounds > 4) {
+                fprintf(stderr, "[sim] deadlock: a collective is waiting for lanes that never arrive (block %u); per wave: alive lanes, min..max wave / block generation\n", block_idx);
+                for (int w0 = 0; w0 < b.n; w0 += 64) {
+                    unsigned lo_w = ~0u, hi_w = 0, lo_b = ~0u, hi_b = 0; int live = 0;
+                    for (int i = w0; i < std::min(w0 + 64, b.n); ++i) {
+                        if (!b.lanes[i].alive) continue;
+                        ++live; lo_w = std::min(lo_w, b.lanes[i].gen_wave); hi_w = std::max(hi_w, b.lanes[i].gen_wave);
+                        lo_b = std::min(lo_b, b.lanes[i].gen_block); hi_b = std::max(hi_b, b.lanes[i].gen_block);
+                    }
+                    fprintf(stderr, "[sim]   wave %d: %d alive, wave generation %u..%u, block generation %u..%u\n", w0 / 64, live, lo_w, hi_w, lo_b, hi_b);
+                }
+                abort();
+            }
         } else stale_rounds = 0;
     }
 }
@@ -177,11 +191,11 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStrea
 inline void __syncthreads() { sim::sync_scope(false); }
 inline int __syncthreads_and(int p) {
     const int par = sim::next_parity(false);
-    sim::me().slot[par][0] = p ? 1 : 0;
+    sim::me().block_slot[par] = p ? 1 : 0;
     const unsigned g = sim::sync_scope(false);
     sim::Block& b = sim::blk();
     int r = 1;
-    for (int i = 0; i < b.n; ++i) if (b.lanes[i].gen_block >= g && !b.lanes[i].slot[par][0]) r = 0;
+    for (int i = 0; i < b.n; ++i) if (b.lanes[i].gen_block >= g && !b.lanes[i].block_slot[par]) r = 0;
     return r;
 }
 

@@ -41,7 +41,7 @@ def _grads_close(grads, g, tol=1e-4, truth=None, free_rows=2):
         assert e < tol, (k, e)
         if truth is not None:
             fh, fo, cnt = helpers.elementwise_three_way(a, g[k], np.asarray(truth[k]).reshape(g[k].shape), kind=k, free_rows=free_rows)
-            assert helpers.three_way_ok(fh, fo, cnt), (k, 'element-wise 1e-4 (HIP vs fp64, oracle32 vs fp64, entries)', fh, fo, cnt)
+            assert helpers.three_way_ok(fh, fo, cnt, cluster=int(np.prod(g[k].shape[1:])) if g[k].ndim > 1 else 1), (k, 'element-wise 1e-4 (HIP vs fp64, oracle32 vs fp64, entries)', fh, fo, cnt)
 
 
 def test_wave_primitives_selftest(hip_backend):
@@ -338,7 +338,7 @@ def test_empty_scene(hip_backend):
     assert torch.allclose(res.image.cpu(), torch.tensor([0.1, 0.2, 0.3])[:, None, None].expand(3, 128, 128))
 
 
-def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, K=16, aa=False, max_masked=1e-3):
+def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, K=16, aa=False, max_masked=1e-3, near_tol=None):
     """Forward + backward (+ FusedAdam-style steps with the same gradients) against the oracle; entries on a hard threshold are
     counted and excluded (helpers.check_flip_aware), everything else is held to 1e-4 -- image, six gradients, densification_info,
     and after `adam_steps` Adam steps the parameters and both moments."""
@@ -361,7 +361,7 @@ def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_
     ref = {k: g[k] for k in helpers.GRAD_KEYS}
     ref['densification_info'] = dens_o.T
     truth = oracle.forward_backward_f64(f, S, gi)              # the same formulas in double: the element-wise bar is applied three-way
-    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, max_masked=max_masked, label=label, truth=truth)
+    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, max_masked=max_masked, label=label, truth=truth, near_tol=near_tol)
     # integer intermediates away from the thresholds: the pixel's last contributor
     npr = helpers.tiles_to_image(dec['n_processed_tiles'], view.width, view.height)
     if dec['I'] == f['I']:

@@ -2,13 +2,18 @@
 antialiasing modes, screen-filling / sub-pixel / culled / degenerate Gaussians, opacities on the 1/255 cut) through the product sources in the
 fiber simulator against the oracle: every forward intermediate and the image BIT-EXACT (the simulator shares libm with the oracle and keeps
 the reference's operation order), the gradients to 1e-5 (summation order)."""
+import os
+
 import pytest
 
 import helpers
 from test_sim_parity import _run, fused_equals_backward_then_adam
 
 
-@pytest.mark.parametrize('seed', range(32))
+_SEEDS = range(*(int(x) for x in os.environ['FGS_FUZZ_SEEDS'].split('-'))) if os.environ.get('FGS_FUZZ_SEEDS') else range(32)
+
+
+@pytest.mark.parametrize('seed', _SEEDS)
 def test_random_configuration_in_the_simulator(sim_backend, oracle, seed):
     p, view, K, aa, label = helpers.fuzz_configuration(seed)
     _run(sim_backend, oracle, p, view, K, aa)
