@@ -13,6 +13,9 @@ CSRC = REPO / 'faster-gaussian-splatting_amd' / 'csrc'
 OUT = SIM / '_build' / 'libfgs_sim.so'
 FLAGS = ['-std=c++17', '-O2', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas', '-Wno-sign-compare',
          '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-Wno-attributes', f'-I{SIM / "include"}', f'-I{CSRC}', f'-I{REPO / "include"}']
+# FGS_SIM_SANITIZE=undefined: an occasional deep check -- the kernels' integer / shift / alignment / bounds-of-static-array behaviour under UBSan
+# (reports go to stderr, the run continues); rebuild with `python tests/sim/build_sim.py` afterwards to get the plain library back
+SAN = [f'-fsanitize={os.environ["FGS_SIM_SANITIZE"]}', '-fsanitize-recover=all', '-g'] if os.environ.get('FGS_SIM_SANITIZE') else []
 
 
 def build(force: bool = False) -> Path:
@@ -24,13 +27,13 @@ def build(force: bool = False) -> Path:
     def compile_one(src: Path) -> Path:
         obj = OUT.parent / (src.stem + '.o')
         if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, newest_header):
-            subprocess.run(['g++', *FLAGS, '-c', '-x', 'c++', str(src), '-o', str(obj)], check=True)
+            subprocess.run(['g++', *FLAGS, *SAN, '-c', '-x', 'c++', str(src), '-o', str(obj)], check=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, srcs))
     if force or not OUT.exists() or any(OUT.stat().st_mtime < o.stat().st_mtime for o in objs):
-        subprocess.run(['g++', '-shared', '-fPIC', '-o', str(OUT), *[str(o) for o in objs]], check=True)
+        subprocess.run(['g++', '-shared', '-fPIC', *SAN, '-o', str(OUT), *[str(o) for o in objs]], check=True)
     return OUT
 
 
