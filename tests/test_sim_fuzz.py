@@ -16,11 +16,11 @@ _SEEDS = range(*(int(x) for x in os.environ['FGS_FUZZ_SEEDS'].split('-'))) if os
 @pytest.mark.parametrize('seed', _SEEDS)
 def test_random_configuration_in_the_simulator(sim_backend, oracle, seed):
     p, view, K, aa, label = helpers.fuzz_configuration(seed)
-    _run(sim_backend, oracle, p, view, K, aa)
+    _run(helpers.poisoned(sim_backend), oracle, p, view, K, aa)        # scratch buffers arrive as 0xFF bytes: nothing may depend on their contents
 
 
 @pytest.mark.parametrize('seed', range(0, 32, 5))
 def test_random_configuration_fused_equals_unfused_in_the_simulator(sim_backend, seed):
     """The same configurations: fgs_backward_adam_fused == fgs_backward -> fgs_adam_step_multi, two steps, bit for bit."""
     p, view, K, aa, label = helpers.fuzz_configuration(seed)
-    fused_equals_backward_then_adam(sim_backend, p, view, K, aa)
+    fused_equals_backward_then_adam(helpers.poisoned(sim_backend), p, view, K, aa)
