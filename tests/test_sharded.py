@@ -243,6 +243,49 @@ def test_sharded_world4_gloo_equals_local_group(tmp_path):
         assert torch.equal(got[k], ref[k]), k
 
 
+def _fuzz_step_inputs(seed, world):
+    import helpers as h
+    p, view, K, aa, label = h.fuzz_configuration(seed)
+    s = h.settings_pair(view, K, aa)[1]
+    gen = torch.Generator().manual_seed(seed)
+    targets = [torch.rand(3, view.height, view.width, generator=gen) for _ in range(world)]
+    return p, [s] * world, targets
+
+
+def _worker_fuzz(rank, world, port, out_dir, seed):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _setup_paths()
+        import helpers as h
+        from harness.sharded import ShardedTrainer, shard_of
+        params, settings, targets = _fuzz_step_inputs(seed, world)
+        tr = ShardedTrainer(h.sim_backend(), shard_of(params, rank, world), LRS)
+        for _ in range(2):
+            tr.step(settings, targets[rank])
+        full = tr.gather_parameters()
+        if rank == 0:
+            torch.save(full, Path(out_dir) / 'full.pt')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('seed', [6, 22])
+def test_sharded_world3_gloo_on_fuzz_configurations(tmp_path, seed):
+    """Three processes over gloo on two of the fuzz configurations (127 and 64 Gaussians: shards of 43 / 42 / 42 and 22 / 21 / 21, narrow odd-sized
+    images, 1 and 9 active SH bases): uneven all-to-all splits in both directions == the three owners stepped in one process."""
+    from harness.sharded import LocalShardGroup
+    mp.spawn(_worker_fuzz, args=(3, 35500 + (os.getpid() % 2000) + seed, str(tmp_path), seed), nprocs=3, join=True)
+    got = torch.load(tmp_path / 'full.pt')
+    params, settings, targets = _fuzz_step_inputs(seed, 3)
+    grp = LocalShardGroup(helpers.sim_backend(), params, LRS, 3)
+    for _ in range(2):
+        grp.step(settings, targets)
+    ref = grp.gather_parameters()
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+
+
 @pytest.mark.parametrize('sh_bases', [1, 4])
 def test_sharded_step_with_fewer_sh_bands(sh_bases):
     """SH degree 0 / 1 models through the sharded path (generic-R kernels, empty sh_rest): fused and unfused phase C agree."""
