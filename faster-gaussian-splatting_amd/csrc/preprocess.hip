@@ -2,7 +2,7 @@
 // count, SH colour, compaction of the visible list. Semantics: reference kernels_forward.cuh:14-209 (training) and
 // kernels_inference.cuh:14-207 (colour clamped at store, n_touched not cleared).
 //
-// CDNA4 shape: 512-thread workgroups (8 wave64). The exact tile count for large footprints is done by the whole
+// CDNA4 shape: 256-thread workgroups (4 wave64; fgs_config.h: the compaction barrier couples fewer waves than at 512). The exact tile count for large footprints is done by the whole
 // wave, 64 candidate tiles per step, with the owning lane's parameters broadcast through v_readlane (SGPRs, no LDS);
 // compaction uses ONE packed 64-bit atomic per workgroup (ballot + mbcnt prefix inside, LDS across waves) instead of two
 // atomics per visible Gaussian: measured on MI355X, per-wave atomics on the two counters alone cost 0.6 ms at 3 M Gaussians.
@@ -232,7 +232,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     FGS_K1_MARK(4);                                             // hot slots, SH colour, record write (waves that were not culled whole)
     if (gid < a.n) a.n_touched[idx] = visible ? cnt : 0u;      // kf:59,193; also the scan input of K4 and the skip test of K12
 
-    // ---- compaction (kf:204-208): ONE 64-bit atomic per 512-thread workgroup. Both counters share one word
+    // ---- compaction (kf:204-208): ONE 64-bit atomic per workgroup (256 threads). Both counters share one word
     // (low = n_visible, high = n_instances): a same-address atomic retires at ~88/us on this chip, so one per Gaussian
     // (reference) or even one per wave would serialise the whole kernel behind the counter. ----
     __shared__ unsigned s_vis[kPreprocessBlock / kWave], s_inst[kPreprocessBlock / kWave];
@@ -263,10 +263,11 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
     FGS_K1_FLUSH;
 }
 
-// The register budget is capped for FGS_K1_WAVES waves per SIMD. Uncapped the kernel takes 116 VGPRs = 4 waves = TWO 512-thread workgroups per
-// CU, and it is latency-bound (35 % of the HBM rate, 40 % of the issue slots, round 2). Measured on one box (profiles/r03_ab_k1_occupancy.txt,
-// S2): uncapped 0.216 ms; 6 waves (80 VGPRs, 43 registers spilled to scratch: THREE workgroups per CU) 0.196 ms; 5 waves (no more workgroups)
-// 0.215; 8 waves (64 VGPRs, 66 spilled, four workgroups) 0.222 -- the spills eat it. 0 = no cap.
+// The register budget is capped for FGS_K1_WAVES waves per SIMD. History: with packed fp32 instructions and 512-thread workgroups the uncapped
+// kernel took 116 VGPRs (two workgroups per CU) and was latency-bound: 0.216 ms uncapped, 0.196 at 6 waves (80 VGPRs, 43 spilled), 0.215 at 5,
+// 0.222 at 8 (profiles/r03_ab_k1_occupancy.txt). Built without packed fp32 (Makefile) it needs 63 VGPRs and no scratch at any cap, and its
+// time does not depend on the instruction count; MORE than 6 waves per SIMD measures slower (0.226 vs 0.213 ms, r03_ab_nopk.txt: the lanes'
+// 180-byte-stride coefficient reads thrash the 32 KB L1 sooner), so the cap stays. 0 = no cap.
 #ifndef FGS_K1_WAVES
 #define FGS_K1_WAVES 6
 #endif
