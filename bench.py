@@ -96,7 +96,8 @@ def live_pmc(args) -> dict:
     out: dict = {}
     tmp = tempfile.mkdtemp(prefix='fgs_pmc_', dir='/tmp')
     child = [sys.executable, str(Path(__file__).resolve()), '--scene', args.scene, '--steps', '3', '--warmup', '1', '--no-extras', '--blocks', '1',
-             '--no-cpu-baseline', '--no-pmc', '--pmc-child'] + (['--n-gaussians', str(args.n_gaussians)] if args.n_gaussians else [])
+             '--no-cpu-baseline', '--no-pmc', '--pmc-child'] + (['--n-gaussians', str(args.n_gaussians)] if args.n_gaussians else []) \
+        + (['--ply', args.ply] if args.ply else [])
     try:
         for tag, counters in (('fetch', ['FETCH_SIZE', 'SQ_INSTS_VALU']), ('write', ['WRITE_SIZE', 'SQ_WAVES'])):
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', *counters, '-d', f'{tmp}/{tag}', '-o', 'b', '--'] + child

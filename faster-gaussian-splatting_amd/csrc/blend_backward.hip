@@ -362,6 +362,12 @@ __global__ void __launch_bounds__(kTileScanThreads) plan_blend_backward_kernel(c
 constexpr unsigned kK11TimelineItems = 1u << 18;
 __device__ unsigned long long g_k11_timeline[kK11TimelineItems * 4];
 #endif
+// Debug-only pair statistics (tools/pair_stats.sh builds a separate library with -DFGS_PAIR_STATS; the product build has none of it): how many
+// of the (pixel, Gaussian) lane-steps K11 issues pass the alpha test -- [0] work items, [1] pipeline steps, [2] steps whose contribution block ran
+// (at least one lane passed), [3] lane-steps with a real pixel in front of its last contributor, [4] lane-steps that passed the alpha test.
+#ifdef FGS_PAIR_STATS
+__device__ unsigned long long g_k11_pair_stats[8];
+#endif
 #ifndef FGS_K11_WAVES_PER_GROUP
 #define FGS_K11_WAVES_PER_GROUP 1
 #endif
@@ -495,6 +501,9 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             ring_at = (ring_at + 8u) & (kXyBytes - 1u);
             return r;
         };
+#ifdef FGS_PAIR_STATS
+        unsigned st_steps = 0, st_body = 0, st_elig = 0, st_pass = 0;
+#endif
         auto step = [&](const float2 inj, const PixRead pr) {
             sT = wave_shift_up1_zero(sT) + inj.x;                                               // kb:383-410
             sS = wave_shift_up1_zero(sS) + inj.y;
@@ -503,6 +512,13 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             const float dx = mx - pr.xy.x, dy = my - pr.xy.y;
             const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
             const float alpha = op * __expf(fminf(power, 0.0f));
+#ifdef FGS_PAIR_STATS
+            {
+                const uint64_t me_ = wave_ballot(lane_f < rel), mp_ = wave_ballot(lane_f < rel && alpha >= kMinAlphaThreshold);
+                st_steps += 1u; st_body += mp_ != 0 ? 1u : 0u;
+                st_elig += static_cast<unsigned>(__popcll(me_)); st_pass += static_cast<unsigned>(__popcll(mp_));
+            }
+#endif
             if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
                 const float T = sT;
                 const float w = T * alpha;
@@ -551,6 +567,13 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             unsafeAtomicAdd(dst + 7 * plane, a_c1 * f1);
             unsafeAtomicAdd(dst + 8 * plane, a_c2 * f2);
         }
+#ifdef FGS_PAIR_STATS
+        if (lane == 0) {
+            atomicAdd(&g_k11_pair_stats[0], 1ull); atomicAdd(&g_k11_pair_stats[1], static_cast<unsigned long long>(st_steps));
+            atomicAdd(&g_k11_pair_stats[2], static_cast<unsigned long long>(st_body)); atomicAdd(&g_k11_pair_stats[3], static_cast<unsigned long long>(st_elig));
+            atomicAdd(&g_k11_pair_stats[4], static_cast<unsigned long long>(st_pass));
+        }
+#endif
 #ifdef FGS_K11_TIMELINE
         if (lane == 0 && item < kK11TimelineItems) {
             g_k11_timeline[item * 4u] = t_start_;
@@ -573,6 +596,19 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_timeline(uns
         void* dev = nullptr;
         if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k11_timeline)) != hipSuccess
             || hipMemset(dev, 0, sizeof(unsigned long long) * 4 * fgs::kK11TimelineItems) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace fgs {
+#endif
+
+#ifdef FGS_PAIR_STATS
+}  // namespace fgs
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_pair_stats(unsigned long long* out, int reset) {
+    if (out != nullptr && hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k11_pair_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k11_pair_stats)) != hipSuccess || hipMemset(dev, 0, sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -105,6 +105,12 @@ constexpr unsigned kK10TimelineTiles = 1u << 17;
 __device__ unsigned long long g_k10_timeline[kK10TimelineTiles * 4];
 #endif
 
+// Debug-only pair statistics (tools/pair_stats.sh, -DFGS_PAIR_STATS; the product build has none of it): [0] tiles, [1] instances staged, [2] (Gaussian,
+// 16x4 strip) pairs walked (the union of the two sub-tile masks), [3] lanes of walked pairs whose own 8x4 sub-tile is hit and whose pixel is not finished,
+// [4] lanes that blended (alpha test passed), [5] (Gaussian, strip) slots offered to the cull = 64-Gaussian chunks x 64 seen by a wave that still had a live pixel.
+#ifdef FGS_PAIR_STATS
+__device__ unsigned long long g_k10_pair_stats[8];
+#endif
 template <bool TRAINING>
 __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
     const unsigned tile = tile_of_workgroup(blockIdx.x, a.grid_w, a.n_tiles, a.row_group, a.tile_plan, a.grid_h);
@@ -138,6 +144,9 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
     float4* const s_c = s_rec + 2 * kBlendBlock;                      // b bounds_x bounds_y -
     __shared__ unsigned s_max[kBlendBlock / kWave];
 
+#ifdef FGS_PAIR_STATS
+    unsigned st_staged = 0, st_pairs = 0, st_mine = 0, st_pass = 0, st_offered = 0;
+#endif
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;
     float gate = inside ? kMinAlphaThreshold : __builtin_inff();       // the alpha a pair has to reach to be blended (see the walk below)
     unsigned n_used = 0;
@@ -181,6 +190,10 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
             const uint64_t mine = inside ? (half ? mask_r : mask_l) : 0ull;            // pixels outside the image never blend
             uint64_t pending = mask_l | mask_r;
             if (wave_ballot(!done) == 0) pending = 0;
+#ifdef FGS_PAIR_STATS
+            if (wave == 0) st_staged += min(static_cast<unsigned>(kBucket), batch - chunk);
+            if (wave_ballot(!done) != 0) st_offered += min(static_cast<unsigned>(kBucket), batch - chunk);
+#endif
             // The walk over the set bits saturates the scalar unit (ONE per CU for four SIMDs; rocprofv3 on the layered scene, round 2:
             // SQ_INSTS_SALU = SQ_INSTS_VALU = 457 M per launch), so every test of a (pixel, Gaussian) pair is ONE vector compare:
             //  * the 64-bit list is walked as two bit-reversed 32-bit words from the top (count-leading-zeros / clear on single registers);
@@ -205,6 +218,11 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
                     const float gauss = __expf(fminf(power, 0.0f));
                     const float alpha = gb.y * gauss;
                     const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha));
+#ifdef FGS_PAIR_STATS
+                    st_pairs += 1u;
+                    st_mine += static_cast<unsigned>(__popcll(wave_ballot(((not_mine << k) & 0x80000000u) == 0u && gate < 1.0f)));
+                    st_pass += static_cast<unsigned>(__popcll(wave_ballot(tested >= gate)));
+#endif
                     if (tested >= gate) {
                         const float w = T * alpha;
                         cr += w * gb.z; cg += w * gb.w; cb += w * entry[2 * kBlendBlock].x;
@@ -239,6 +257,13 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
         __syncthreads();
         if (tid == 0) a.max_n_processed[tile] = max(s_max[0], max(s_max[1], s_max[2]));   // kf:493-497
     }
+#ifdef FGS_PAIR_STATS
+    if (TRAINING && lane == 0) {
+        if (wave == 0) { atomicAdd(&g_k10_pair_stats[0], 1ull); atomicAdd(&g_k10_pair_stats[1], static_cast<unsigned long long>(st_staged)); }
+        atomicAdd(&g_k10_pair_stats[2], static_cast<unsigned long long>(st_pairs)); atomicAdd(&g_k10_pair_stats[3], static_cast<unsigned long long>(st_mine));
+        atomicAdd(&g_k10_pair_stats[4], static_cast<unsigned long long>(st_pass)); atomicAdd(&g_k10_pair_stats[5], static_cast<unsigned long long>(st_offered));
+    }
+#endif
 #ifdef FGS_K10_TIMELINE
     if (tid == 0 && tile < kK10TimelineTiles) {
         g_k10_timeline[tile * 4u] = t_start_;
@@ -258,6 +283,19 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k10_timeline(uns
         void* dev = nullptr;
         if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k10_timeline)) != hipSuccess
             || hipMemset(dev, 0, sizeof(unsigned long long) * 4 * fgs::kK10TimelineTiles) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace fgs {
+#endif
+
+#ifdef FGS_PAIR_STATS
+}  // namespace fgs
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k10_pair_stats(unsigned long long* out, int reset) {
+    if (out != nullptr && hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k10_pair_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k10_pair_stats)) != hipSuccess || hipMemset(dev, 0, sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     }
     return 0;
 }
