@@ -50,6 +50,10 @@ def parse():
     ap.add_argument('--watchdog', type=int, default=900, help='seconds after which a hung rank dumps its stacks and exits (0 = off)')
     ap.add_argument('--pmc-child', action='store_true', help='internal: the short child run of the rocprofv3 counter passes (training + fused steps only)')
     ap.add_argument('--force-dp', action='store_true', help='world size 1: run the multi-GPU step (exchange = local copy) instead of the single-GPU iteration (profiling)')
+    ap.add_argument('--sim', action='store_true',
+                    help='TEST INFRASTRUCTURE, not a measurement: run this script\'s multi-rank control flow on CPU -- the tests/sim build of the same HIP '
+                         'sources as backend, CPU tensors, gloo instead of RCCL -- so that the N > 1 branch is executed before an 8-GPU node ever runs it '
+                         '(tests/test_bench_multirank.py). The line it prints says so in `data`; its numbers mean nothing.')
     ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'zero1', 'allreduce'],
                     help="N > 1: 'sharded' = every rank owns N/G Gaussians, 56-B records / 36-B accumulators cross xGMI (harness/sharded.py); "
                          "'zero1' / 'allreduce' = replicated parameters, 236-B gradients cross xGMI (harness/distributed.py)")
@@ -69,12 +73,16 @@ def build_scene(args):
                               tuple(float(x) for x in c), 1920, 1080, 1420.0) for k in range(8)]
         return params, views, f'PLY {Path(args.ply).name}: {params["means"].shape[0]} Gaussians, 1920x1080, 8 orbit views at radius {r:.2f} around the median'
     if args.scene == 'S0':
-        params, view = make_s0()
-        return params, [view], 'S0: 1k Gaussians, 128x128'
+        params, view = make_s0(n=args.n_gaussians or 1000)
+        return params, [view], f'S0: {args.n_gaussians or 1000} Gaussians, 128x128'
     n = args.n_gaussians or SCENE_SIZES[args.scene]
     params = make_garden_like(n)
     return params, orbit_views(8), f'{args.scene}: {n} garden-like Gaussians (SH degree 3), 1920x1080, 8 orbit views'
 
+
+# stages of the built-in HIP-event profiler that have an algorithmic byte count (main(): stage_bytes) -- the candidates for the dominant kernel
+STAGE_KEYS = ('preprocess', 'depth_sort', 'offsets_scan', 'create_instances', 'tile_sort', 'extract_ranges', 'bucket_scan', 'blend_forward', 'stage_pixels',
+              'blend_backward', 'preprocess_backward', 'sh_rest_backward', 'fused_backward_adam', 'adam', 'l1_dssim_loss')
 
 PMC_KERNELS = {       # stage -> substring of the kernel name in the rocprofv3 trace
     'adam': 'fgs::adam_kernel', 'blend_backward': 'blend_backward_compact_kernel', 'blend_forward': 'blend_kernel<true>',
@@ -221,15 +229,28 @@ def main():
     from FasterGSCudaBackend._backend import default_backend
     from harness import trainer as T
 
-    if not torch.cuda.is_available():
+    sim = args.sim
+    if not torch.cuda.is_available() and not sim:
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device('cpu') if sim else torch.device('cuda', local_rank)
+    if not sim:
+        torch.cuda.set_device(device)
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         import datetime
-        dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=max(args.watchdog, 120) if args.watchdog else 1800))
+        limit = datetime.timedelta(seconds=max(args.watchdog, 120) if args.watchdog else 1800)
+        if sim:
+            dist.init_process_group('gloo', timeout=limit)
+        else:
+            dist.init_process_group('nccl', device_id=device, timeout=limit)
         assert dist.get_world_size() == world and dist.get_rank() == rank, (dist.get_world_size(), world, dist.get_rank(), rank)
-    be = default_backend()
+    if sim:      # the CPU build of the same kernel sources (tests/sim): exercises this script, measures nothing
+        sys.path.insert(0, str(REPO / 'tests'))
+        import helpers
+        be = helpers.sim_backend()
+        if os.environ.get('FGS_BENCH_SIM_FAIL_RANK') == str(rank):      # tests/test_bench_multirank.py: a rank that dies must take the job down loudly
+            raise RuntimeError(f'rank {rank}: failure injected by FGS_BENCH_SIM_FAIL_RANK')
+    else:
+        be = default_backend()
     import FasterGSCudaBackend as FGS
     # Default: fgs_forward with its ONE host read of the counts -- the depth sort is enqueued behind the copy, so the wait costs nothing at
     # this size (measured: 2.66 ms vs 2.70 ms per iteration for the synchronisation-free form, whose launches are sized by bounds).
@@ -269,7 +290,7 @@ def main():
     # rank) or one all-reduce. The rasterizer is called through the backend directly (no autograd copies of the 708 MB arena).
     # One GPU (however the process was launched): the reference's single-GPU iteration -- so the N = 1 point of a scaling curve
     # is the BENCH number. N > 1 (or --force-dp): the multi-GPU step.
-    use_dp = world > 1 or args.force_dp
+    use_dp = world > 1 or args.force_dp or sim          # (the single-GPU iteration goes through the autograd operators, which refuse CPU tensors)
     lr = T.GARDEN_LR
     lrs = {'means': lr['means_init'] * 5.0, **{k: lr[k] for k in T.PARAM_ORDER[1:]}}
 
@@ -305,11 +326,14 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not sim:
+            torch.cuda.synchronize(device)
 
     def peak_vram(reset: bool = False) -> dict:
         """Peak device memory of this process since the last reset: everything the path allocates goes through torch (parameters, moments,
         gradients, images, and the four scratch blobs the library sizes through the resize callback), so torch's allocator statistics cover it."""
+        if sim:
+            return {'peak_allocated_GB': None, 'peak_reserved_GB': None}
         out_ = {'peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 1e9, 'peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 1e9}
         if reset:
             torch.cuda.reset_peak_memory_stats(device)
@@ -333,7 +357,8 @@ def main():
     for i in range(len(my_views) if vp is None else 2):
         step(i)
     fence()
-    torch.cuda.reset_peak_memory_stats(device)
+    if not sim:
+        torch.cuda.reset_peak_memory_stats(device)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -349,7 +374,7 @@ def main():
     prof = be.profile_read()
     be.profile_enable(False)
     n_prof = PROFILE_STEPS
-    dom_stage = max((k for k, v_ in prof.items() if v_[1] > 0), key=lambda k: prof[k][0] / prof[k][1])
+    dom_stage = max((k for k, v_ in prof.items() if v_[1] > 0 and k in STAGE_KEYS), key=lambda k: prof[k][0] / prof[k][1])
     be.profile_enable(True, only=dom_stage)
     be.profile_read()
     fence()
@@ -384,8 +409,8 @@ def main():
     # who took part: every rank reports its device and the Gaussians it saw (proves N ranks ran)
     roster = None
     if dist.is_initialized():
-        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.get_device_name(device), 'n_gaussians_on_rank': int(getattr(vp, 'n', n)) if vp is not None else n,
-                'n_visible_view0': int(stats[id(my_views[0])]['V']), 'visible_devices': torch.cuda.device_count()}
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': 'cpu (simulation)' if sim else torch.cuda.get_device_name(device), 'n_gaussians_on_rank': int(getattr(vp, 'n', n)) if vp is not None else n,
+                'n_visible_view0': int(stats[id(my_views[0])]['V']), 'visible_devices': 0 if sim else torch.cuda.device_count()}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         roster = gathered
@@ -479,7 +504,7 @@ def main():
     bytes_iter = float(sum(stage_bytes[k] for k, v_ in prof.items() if v_[1] > 0 and k in stage_bytes))
     bytes_iter_survey = 1960.0 * n + (36 * K_ + 312.0) * V + 158.0 * I + 6152.0 * B + 52.0 * P_ + 28.0 * T_
     # live counters (rank 0, one GPU): HBM traffic of the dominant kernel; VALU instruction counts for the secondary ceiling
-    pmc = live_pmc(args) if (rank == 0 and world == 1 and not args.no_pmc) else {'error': 'not collected (--no-pmc or N > 1)'}
+    pmc = live_pmc(args) if (rank == 0 and world == 1 and not args.no_pmc and not sim) else {'error': 'not collected (--no-pmc or N > 1)'}
     traffic, traffic_note = None, pmc.get('error', 'no counters for this kernel')
     if dom in pmc and 'FETCH_SIZE' in pmc[dom] and 'WRITE_SIZE' in pmc[dom]:
         # counters are KiB per dispatch; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read (MI355X_MICROARCH.md
@@ -496,11 +521,12 @@ def main():
             insts = pmc[st]['SQ_INSTS_VALU']
             secondary.append({'bound': 'valu', 'stage': st, 'kernel': kernel_of[st], 'insts': insts, 'avg_kernel_ms': per_launch[st],
                               'avg_kernel_ms_source': f'untimed {n_prof}-step stage-profile pass (HIP events around every stage), not the timed region',
-                              'cycles_per_inst': 2.9, 'frac': insts * 2.9 / (1024 * 2.4e9 * per_launch[st] * 1e-3)})
+                              'cycles_per_inst': 2.9, 'frac': insts * 2.9 / (1024 * 2.4e9 * max(per_launch[st], 1e-9) * 1e-3)})
     out = {
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic' if not sim else 'synthetic; SIMULATION on CPU (tests/sim build of the HIP sources, gloo): a test of this script, NOT a measurement',
         'config': {'workload': workload + '; full training iteration fwd+loss+bwd+Adam (BASELINE.json configs[2]), loss 0.8*L1+0.2*DSSIM, '
                                'densification_info updated', 'parallelism': f'view-parallel dp{world} ({args.dp_mode})' if vp is not None else 'single GPU',
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'instances_walked': Ip, 'buckets64_walked': Bp, 'active_sh_bases': K_,
@@ -510,9 +536,9 @@ def main():
                    # the gradient tensors untouched (bit-identical): how often that held / did not in this process
                    'live_block_handover': FGS.live_block_stats(),
                    'world': dist.get_world_size() if dist.is_initialized() else 1, 'ranks': roster,
-                   'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if dist.is_initialized() else None,
+                   'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if (dist.is_initialized() and not sim) else None,
                    'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
-                   'device': f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
+                   'device': 'cpu (simulation)' if sim else f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
                    'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0,
                    # sharded exchange on rank 0: time inside the step's three exchanges (counts all-gather, records all-to-all, accumulators
                    # all-to-all), averaged over all blocks incl. warm-up; nothing overlaps them (harness/sharded.py), so exposed = total
@@ -532,12 +558,12 @@ def main():
                          'note': 'torch allocator peaks over warm-up + stage profile + all timed blocks of the headline run'},
         'stage_ms_per_step': {k: v[0] / n_prof for k, v in prof.items() if v[1] > 0},
         'stage_profile_steps': n_prof,
-        'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes},
+        'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes and per_launch[k] > 0},
     }
 
     if other is not None:
         out['other_exchange'] = other
-    if rank == 0 and not args.no_extras and world == 1:
+    if rank == 0 and not args.no_extras and world == 1 and not sim:
         # BASELINE.json configs[1]: forward render only (the reference's render_image_benchmark path)
         v = my_views[0]
         for _ in range(3):
@@ -641,7 +667,7 @@ def main():
                                 'stage_ms_per_step': {k: v_[0] / PROFILE_STEPS for k, v_ in pr.items() if v_[1] > 0}}
         del g2, tg2, res
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sim:
         try:
             out['cpu_baseline'] = cpu_baseline(params, [v.to('cpu') for v in views], stats)
         except Exception as exc:   # the baseline must never take the GPU number down with it
