@@ -167,3 +167,72 @@ def initialize_from_point_cloud(positions: torch.Tensor, colors: torch.Tensor | 
         'sh_coefficients_0': sh0.contiguous(),
         'sh_coefficients_rest': torch.zeros((n, (max_sh_degree + 1) ** 2 - 1, 3), dtype=torch.float32, device=dev),
     }
+
+
+# ---- a structured ground truth for end-to-end training runs (tools/train_full.py) ------------------------------------------
+def make_surface_scene(n: int, seed: int = 4321, sh_bases: int = 16, morton: bool = True) -> dict:
+    """Gaussians lying ON surfaces, the way a trained 3DGS scene looks: a gently rolling textured ground over [-4, 4]^2 and a dozen
+    textured ellipsoids resting on it; every Gaussian is a thin, nearly opaque disk in the tangent plane of its surface point, coloured by
+    a procedural albedo (checker + stripes + a per-object tint) with no view dependence. Unlike `make_garden_like` (independent random
+    blobs filling a volume: every view looks like noise with parallax between the layers), renders of this scene are consistent across
+    views, so a model trained on some cameras can be judged on held-out ones. World is y-down (the ground is near y = +2)."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g)
+    nrm = lambda *s: torch.randn(*s, generator=g)
+    n_obj = 12
+    centers_xz = (u(n_obj, 2) * 2.0 - 1.0) * 3.0
+    radii = torch.stack([0.45 + 0.6 * u(n_obj), 0.35 + 0.8 * u(n_obj), 0.45 + 0.6 * u(n_obj)], dim=1)          # ellipsoid semi-axes (x, y, z)
+    ground_y = lambda x, z: 2.0 + 0.22 * torch.sin(0.9 * x) * torch.cos(0.7 * z)
+    centers = torch.stack([centers_xz[:, 0], ground_y(centers_xz[:, 0], centers_xz[:, 1]) - 0.9 * radii[:, 1], centers_xz[:, 1]], dim=1)
+    areas = torch.cat([torch.tensor([64.0]), 4.0 * math.pi * ((radii[:, 0] * radii[:, 1]) ** 1.6 + (radii[:, 0] * radii[:, 2]) ** 1.6
+                                                              + (radii[:, 1] * radii[:, 2]) ** 1.6).div(3.0).pow(1.0 / 1.6)])
+    counts = (areas / areas.sum() * n).long()
+    counts[0] += n - int(counts.sum())
+    pos, nor, tint = [], [], []
+    # ground
+    m = int(counts[0])
+    x, z = u(m) * 8.0 - 4.0, u(m) * 8.0 - 4.0
+    dydx, dydz = 0.22 * 0.9 * torch.cos(0.9 * x) * torch.cos(0.7 * z), -0.22 * 0.7 * torch.sin(0.9 * x) * torch.sin(0.7 * z)
+    pos.append(torch.stack([x, ground_y(x, z), z], dim=1))
+    nor.append(torch.nn.functional.normalize(torch.stack([dydx, -torch.ones(m), dydz], dim=1), dim=1))        # up = -y
+    tint.append(torch.tensor([0.55, 0.6, 0.45]).expand(m, 3))
+    for o in range(n_obj):
+        m = int(counts[1 + o])
+        d = torch.nn.functional.normalize(nrm(m, 3), dim=1)
+        pos.append(centers[o] + d * radii[o])
+        nor.append(torch.nn.functional.normalize(d / radii[o], dim=1))
+        hue = u(3) * 0.7 + 0.25
+        tint.append(hue.expand(m, 3))
+    pos, nor, tint = torch.cat(pos), torch.cat(nor), torch.cat(tint)
+    # procedural albedo: a 0.5 m checker, 8 cm stripes and a slow gradient, modulated per object
+    chk = ((torch.floor(pos[:, 0] * 2.0) + torch.floor(pos[:, 2] * 2.0) + torch.floor(pos[:, 1] * 2.0)) % 2.0) * 0.5 + 0.5
+    stripes = 0.5 + 0.5 * torch.sin(pos[:, 0] * 40.0 + 3.0 * torch.sin(pos[:, 2] * 2.0))
+    slow = 0.5 + 0.5 * torch.sin(pos * torch.tensor([0.8, 1.3, 1.1]) + torch.tensor([0.3, 1.1, 2.0]))
+    rgb = (tint * (0.35 + 0.65 * chk[:, None]) * (0.7 + 0.3 * stripes[:, None]) * (0.6 + 0.4 * slow)).clamp(0.02, 0.98)
+    # thin disks in the tangent plane: rotation takes the local z axis onto the normal
+    spacing = math.sqrt(float(areas.sum()) / n)
+    s_t = spacing * 1.3 * torch.exp(0.25 * nrm(n, 1)) * (0.8 + 0.4 * u(n, 2))
+    scales = torch.log(torch.cat([s_t, 0.12 * s_t.mean(dim=1, keepdim=True)], dim=1))
+    zaxis = torch.tensor([0.0, 0.0, 1.0]).expand(n, 3)
+    half = torch.nn.functional.normalize(zaxis + nor + 1e-6 * nrm(n, 3), dim=1)           # quaternion of the shortest arc z -> normal: (z . h, z x h)
+    w = (zaxis * half).sum(dim=1, keepdim=True)
+    xyz = torch.linalg.cross(zaxis, half, dim=1)
+    spin = u(n, 1) * 2.0 * math.pi                                                         # random in-plane spin (about local z), applied first
+    qs = torch.cat([torch.cos(spin / 2), torch.zeros(n, 2), torch.sin(spin / 2)], dim=1)
+    qa = torch.cat([w, xyz], dim=1)
+    rot = torch.stack([qa[:, 0] * qs[:, 0] - (qa[:, 1:] * qs[:, 1:]).sum(dim=1),
+                       qa[:, 0] * qs[:, 1] + qs[:, 0] * qa[:, 1] + qa[:, 2] * qs[:, 3] - qa[:, 3] * qs[:, 2],
+                       qa[:, 0] * qs[:, 2] + qs[:, 0] * qa[:, 2] + qa[:, 3] * qs[:, 1] - qa[:, 1] * qs[:, 3],
+                       qa[:, 0] * qs[:, 3] + qs[:, 0] * qa[:, 3] + qa[:, 1] * qs[:, 2] - qa[:, 2] * qs[:, 1]], dim=1)
+    params = {
+        'means': pos.contiguous(),
+        'scales': scales.contiguous(),
+        'rotations': rot.contiguous(),
+        'opacities': _logit((0.75 + 0.23 * u(n, 1)).clamp(0.02, 0.98)),
+        'sh_coefficients_0': rgb_to_sh0(rgb)[:, None, :].contiguous(),
+        'sh_coefficients_rest': torch.zeros(n, sh_bases - 1, 3),
+    }
+    if morton:
+        perm = morton_order(params['means'])
+        params = {k: v[perm].contiguous() for k, v in params.items()}
+    return params
