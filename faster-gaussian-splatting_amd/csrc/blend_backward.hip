@@ -602,6 +602,225 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_timeline(uns
 namespace fgs {
 #endif
 
+
+// ---- variant 4: lane = PIXEL, reduction over the pixels on the matrix cores ----------------------------------------------------------------
+// Measured in round 4 (tools/pair_stats.sh, profiles/r04_k11_pair_efficiency.txt): of the (pixel, Gaussian) lane-steps the systolic kernel above
+// issues, 33-41 % pass the alpha test (S2, the layered scene, a trained export alike); a quarter of its steps is pipeline fill, and it evaluates
+// every Gaussian of a bucket against all 192 pixels of the tile. The forward kernel's formulation -- lane = pixel, each wave walks only the
+// Gaussians whose bounding box reaches its 16x4 strip -- visits 0.65-0.72 as many lane-steps, needs no fill, no ring of per-pixel constants (they
+// sit in registers) and no shifted state (T and S belong to the lane). What it needs instead is a sum over the 64 pixels of a strip for each of
+// the nine per-Gaussian gradients, which as DPP reductions costs 54 cross-lane adds per (Gaussian, strip) pair (the strip variant 1: slower).
+// Here that sum is a matrix product. All nine sums are linear in two per-pair values, w = T alpha and hh = -alpha/2 dL/dalpha:
+//     dL/dcolour_c = sum_p w g_c(p),      sum_p hh { 1, x', y', x'^2, x'y', y'^2 }   (x', y' = pixel centre relative to the TILE centre: exact
+// small half-integers), from which the sums over dx = Dx - x', dy = Dy - y' (Dx, Dy = mean2d relative to the tile centre) follow per Gaussian:
+//     sum hh dx = Dx Sh - Sx,  sum hh dx^2 = Dx (Dx Sh - 2 Sx) + Sxx,  sum hh dx dy = Dx Dy Sh - Dx Sy - Dy Sx + Sxy, ...
+// So each wave keeps, for up to 8 walked Gaussians, w and hh of its 64 pixels in 16 rows of a private LDS buffer (the transposition: lanes are
+// pixels when the rows are written and (k, column) pairs of the matrix instruction when they are read), and one pass of 16
+// v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain) multiplies the 9 x 64 feature matrix of the strip
+// [g_r, g_g, g_b, 1, x', y', x'^2, x'y', y'^2] with those rows: columns 0..7 = w of the 8 slots, 8..15 = hh. The matrix pipe runs beside the
+// vector pipe; the vector instructions per pair are the forward walk's plus the gradient arithmetic. The three waves of a tile add their
+// results into LDS accumulators of the bucket's 64 Gaussians; 64 threads convert and issue the nine global atomics as the other variants do.
+// alpha is the forward kernel's expression operation for operation (same dx, dy: pixel centre = px + 0.5), T and S restart from the bucket's
+// checkpoint exactly as in the systolic form.
+constexpr unsigned kPixSlots = 8;                        // walked Gaussians per matrix pass
+constexpr unsigned kPixRows = 2 * kPixSlots;             // w rows, then hh rows
+constexpr unsigned kPixStride = 68;                      // floats per row: 64 pixels + 4, so that the 16-byte reads of 16 columns hit 64 distinct banks
+#ifndef FGS_K11M_MAX_BLOCKS
+#define FGS_K11M_MAX_BLOCKS 32768
+#endif
+__global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const BlendBackwardArgs a) {
+    __shared__ float4 s_rec[3 * kBucket];                                      // mean.xy conic.ab | conic.c opacity r g (clamped) | b (clamped) bounds_x bounds_y flags
+    __shared__ uint2 s_meta[kBucket];                                          // primitive, hot-slot word
+    __shared__ float s_acc[9 * kBucket];                                       // planes Sh Sx Sy Sxx Sxy Syy c0 c1 c2 of the bucket's Gaussians
+    __shared__ __attribute__((aligned(16))) float s_v[kTilePixels / kWave][kPixRows * kPixStride];
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
+    float* const v_mine = s_v[wave];
+    const unsigned pos = (lane & 3u) * 16u + (lane >> 2);                      // pixel p = 4 s + q of matrix k-step s sits at q * 16 + s of its row
+    const unsigned col = lane & 15u, q = lane >> 4;                            // this lane's column / k index in the matrix instruction
+    const unsigned lx = half * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
+    const unsigned local = ly * kTileW + lx;
+    const unsigned n_live = *a.live_count;
+    for (unsigned item = blockIdx.x; item < n_live; item += gridDim.x) {      // workgroup-uniform
+        const uint2 work = a.work_list[item];
+        const unsigned tile = work.x, tb = work.y;
+        const uint2 range = a.ranges[tile];
+        const unsigned tile_n = range.y - range.x;
+        const unsigned bucket = (tile == 0 ? 0u : a.bucket_offsets[tile - 1]) + tb;
+        const unsigned first_gaussian = tb * kBucket;
+        const unsigned n_here = min(static_cast<unsigned>(kBucket), tile_n - first_gaussian);
+        const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+
+        if (tid < kBucket) {                                                   // the bucket's records (kb:297-319)
+            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+            uint32_t prim = 0, flags = 0;
+            if (tid < n_here) {
+                prim = a.inst_prims[range.x + first_gaussian + tid];
+                const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+                r0 = r[0]; r1 = r[1]; r2 = r[2];
+                flags = (r1.z >= 0.0f ? 1u : 0u) | (r1.w >= 0.0f ? 2u : 0u) | (r2.x >= 0.0f ? 4u : 0u);      // kb:313-318
+            }
+            s_rec[tid] = r0;
+            s_rec[kBucket + tid] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
+            s_rec[2 * kBucket + tid] = make_float4(fmaxf(r2.x, 0.0f), r2.y, r2.z, __uint_as_float(flags));
+            s_meta[tid] = make_uint2(prim, __float_as_uint(r2.w));
+        }
+        for (unsigned e = tid; e < 9u * kBucket; e += kTilePixels) s_acc[e] = 0.0f;
+
+        // ---- this lane's pixel: constants and the state at the bucket's checkpoint (kb:349-380) ----
+        const float pxf = static_cast<float>(tile_x * kTileW + lx) + 0.5f, pyf = static_cast<float>(tile_y * kTileH + ly) + 0.5f;
+        const float4 g = a.pixrec[((size_t)tile * kTilePixels + local) * 2];
+        const float4 cst = a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1];
+        const float4 ck = a.ckpt[(size_t)bucket * kTilePixels + local];
+        const unsigned last = __float_as_uint(cst.w);                          // 0 outside the image
+        // a pixel that finished before this bucket never wrote its checkpoint (kf:436) and receives nothing here
+        const bool live = last > first_gaussian;
+        const unsigned rel = live ? last - first_gaussian : 0u;                // Gaussians of this bucket in front of the pixel's last contributor
+        float T = live ? ck.w : 0.0f;
+        float sS = live ? ((cst.x - ck.x) * g.x + (cst.y - ck.y) * g.y + (cst.z - ck.z) * g.z) - g.w : 0.0f;   // kb:371-377 projected on dL/dC
+        float gate = live ? kMinAlphaThreshold : __builtin_inff();            // as in the forward walk: +inf once the pixel takes nothing more
+
+        // ---- the strip's feature matrix as matrix operand A: row c of [g_r g_g g_b 1 x' y' x'^2 x'y' y'^2], 16 k-steps ----
+        float A[16];
+        {
+            const float xr = static_cast<float>(lx) - 7.5f, yr = static_cast<float>(ly) - 5.5f;
+            v_mine[0 * kPixStride + pos] = g.x; v_mine[1 * kPixStride + pos] = g.y; v_mine[2 * kPixStride + pos] = g.z;
+            v_mine[3 * kPixStride + pos] = 1.0f; v_mine[4 * kPixStride + pos] = xr; v_mine[5 * kPixStride + pos] = yr;
+            v_mine[6 * kPixStride + pos] = xr * xr; v_mine[7 * kPixStride + pos] = xr * yr; v_mine[8 * kPixStride + pos] = yr * yr;
+            wave_lds_fence();
+            const float4* ap = reinterpret_cast<const float4*>(v_mine + min(col, 8u) * kPixStride + q * 16u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 t = ap[i];
+                const bool used = col < 9u;
+                A[4 * i] = used ? t.x : 0.0f; A[4 * i + 1] = used ? t.y : 0.0f; A[4 * i + 2] = used ? t.z : 0.0f; A[4 * i + 3] = used ? t.w : 0.0f;
+            }
+            wave_lds_fence();                                                  // the rows are reused for w / hh below
+        }
+        __syncthreads();                                                       // records staged, accumulators cleared
+
+        // ---- cull the bucket against this wave's two 8x4 sub-tiles (kf:445-451) ----
+        const unsigned sub_y0 = tile_y * kTileH + wave * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
+        const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
+        bool in_l = false, in_r = false;
+        if (lane < n_here) {
+            const float4 gc = s_rec[2 * kBucket + lane];
+            const uint32_t bx = __float_as_uint(gc.y), by = __float_as_uint(gc.z);
+            const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
+            const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
+            in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
+            in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
+        }
+        const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
+        const uint64_t mine = half ? mask_r : mask_l;
+        const unsigned rel_max = wave_max(rel);                                // Gaussians at or behind every pixel's last contributor take nothing (kb:412)
+        uint64_t pending = (mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull));
+
+        unsigned n_slots = 0;                                                  // filled rows of the current matrix batch (wave-uniform)
+        unsigned slot_gaussian = 0;                                            // lane i < 8: bucket-relative index of the Gaussian in slot i
+        auto flush = [&](const unsigned n) {
+            wave_lds_fence();
+            const float4* bp = reinterpret_cast<const float4*>(v_mine + col * kPixStride + q * 16u);
+            const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+            fgs_acc4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains: a dependent matrix instruction waits 40 cycles, an independent one 32
+            wave_mfma_16x16x4(A[0], b0.x, d0); wave_mfma_16x16x4(A[1], b0.y, d1); wave_mfma_16x16x4(A[2], b0.z, d0); wave_mfma_16x16x4(A[3], b0.w, d1);
+            wave_mfma_16x16x4(A[4], b1.x, d0); wave_mfma_16x16x4(A[5], b1.y, d1); wave_mfma_16x16x4(A[6], b1.z, d0); wave_mfma_16x16x4(A[7], b1.w, d1);
+            wave_mfma_16x16x4(A[8], b2.x, d0); wave_mfma_16x16x4(A[9], b2.y, d1); wave_mfma_16x16x4(A[10], b2.z, d0); wave_mfma_16x16x4(A[11], b2.w, d1);
+            wave_mfma_16x16x4(A[12], b3.x, d0); wave_mfma_16x16x4(A[13], b3.y, d1); wave_mfma_16x16x4(A[14], b3.z, d0); wave_mfma_16x16x4(A[15], b3.w, d1);
+            // this lane holds D[row 4 q + r][col]: rows 0..2 = colour sums (columns 0..7, the w rows), rows 3..8 = moment sums (columns 8..15, the hh rows)
+            const unsigned slot = col & 7u;
+            const unsigned gi = wave_shuffle(slot_gaussian, slot);
+            const bool is_w = col < 8u;
+            if (slot < n) {
+                if (q == 0u) {
+                    if (is_w) {
+                        atomicAdd(&s_acc[6 * kBucket + gi], d0[0] + d1[0]); atomicAdd(&s_acc[7 * kBucket + gi], d0[1] + d1[1]);
+                        atomicAdd(&s_acc[8 * kBucket + gi], d0[2] + d1[2]);
+                    } else atomicAdd(&s_acc[gi], d0[3] + d1[3]);
+                } else if (!is_w) {
+                    if (q == 1u) {
+                        atomicAdd(&s_acc[1 * kBucket + gi], d0[0] + d1[0]); atomicAdd(&s_acc[2 * kBucket + gi], d0[1] + d1[1]);
+                        atomicAdd(&s_acc[3 * kBucket + gi], d0[2] + d1[2]); atomicAdd(&s_acc[4 * kBucket + gi], d0[3] + d1[3]);
+                    } else if (q == 2u) atomicAdd(&s_acc[5 * kBucket + gi], d0[0] + d1[0]);
+                }
+            }
+            wave_lds_fence();                                                  // the next batch overwrites the rows
+        };
+
+        if (rel_max == 0u) pending = 0;                                        // no live pixel in this strip
+#pragma unroll
+        for (unsigned word = 0; word < 2u; ++word) {                           // the forward kernel's walk (blend_forward.hip): bit-reversed 32-bit words
+            uint32_t pend = __brev(static_cast<uint32_t>(word ? pending >> 32 : pending));
+            const uint32_t not_mine = __brev(~static_cast<uint32_t>(word ? mine >> 32 : mine));
+            const unsigned j0 = 32u * word;
+            const unsigned row0 = in_vector_register(j0 * 16u);
+            while (pend != 0) {                                                // wave-uniform
+                const unsigned k = static_cast<unsigned>(__clz(static_cast<int>(pend)));
+                pend &= ~(0x80000000u >> k);
+                const float4* const entry = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k << 4)));
+                const float4 ga = entry[0], gb = entry[kBucket];
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
+                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                const float gauss = __expf(fminf(power, 0.0f));
+                const float alpha = gb.y * gauss;
+                const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha));
+                float w = 0.0f, hh = 0.0f;
+                if (tested >= gate) {                                          // kb:412,419-421
+                    const float colb = entry[2 * kBucket].x;
+                    w = T * alpha;
+                    const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
+                    sS -= w * cg;                                               // kb:429 projected on dL/dC
+                    const float oma = 1.0f - alpha;
+                    const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+                    const float dl_dalpha = T * cg - sS * oma_rcp;              // kb:434-436
+                    hh = (-0.5f * alpha) * dl_dalpha;
+                    T *= oma;
+                    gate = j0 + k + 1u >= rel ? __builtin_inff() : gate;        // that was this pixel's last contributor
+                }
+                v_mine[n_slots * kPixStride + pos] = w;
+                v_mine[(kPixSlots + n_slots) * kPixStride + pos] = hh;
+                slot_gaussian = wave_write_lane(slot_gaussian, j0 + k, n_slots);
+                if (++n_slots == kPixSlots) { flush(kPixSlots); n_slots = 0; }
+            }
+        }
+        if (n_slots != 0) flush(n_slots);
+        __syncthreads();
+
+        // ---- per Gaussian: moments about the tile centre -> the nine gradients, added to the planes (kb:459-470) ----
+        if (tid < n_here) {
+            const float Sh = s_acc[tid], Sx = s_acc[kBucket + tid], Sy = s_acc[2 * kBucket + tid];
+            const float Sxx = s_acc[3 * kBucket + tid], Sxy = s_acc[4 * kBucket + tid], Syy = s_acc[5 * kBucket + tid];
+            const float c0 = s_acc[6 * kBucket + tid], c1 = s_acc[7 * kBucket + tid], c2 = s_acc[8 * kBucket + tid];
+            const bool silent = Sh == 0.0f && Sx == 0.0f && Sy == 0.0f && Sxx == 0.0f && Sxy == 0.0f && Syy == 0.0f && c0 == 0.0f && c1 == 0.0f && c2 == 0.0f;
+            if (!silent && !(a.ablate & 1)) {
+                const float4 ga = s_rec[tid], gb = s_rec[kBucket + tid], gc = s_rec[2 * kBucket + tid];
+                const uint2 meta = s_meta[tid];
+                const float ca = ga.z, cb = ga.w, cc = gb.x, op = gb.y;
+                const float Dx = ga.x - (static_cast<float>(tile_x * kTileW) + 8.0f), Dy = ga.y - (static_cast<float>(tile_y * kTileH) + 6.0f);
+                const float a_x = Dx * Sh - Sx, a_y = Dy * Sh - Sy;
+                const float a_xx = Dx * (Dx * Sh - 2.0f * Sx) + Sxx, a_yy = Dy * (Dy * Sh - 2.0f * Sy) + Syy;
+                const float a_xy = Dx * (Dy * Sh - Sy) - Dy * Sx + Sxy;
+                const unsigned flags = __float_as_uint(gc.w);
+                unsigned tx0, tx1, ty0, ty1;
+                tile_rect(__float_as_uint(gc.y), __float_as_uint(gc.z), tx0, tx1, ty0, ty1);
+                const unsigned footprint = (tx1 - tx0) * (ty1 - ty0);
+                const uint32_t hot_word = footprint > kHotFootprint ? meta.y : 0u;
+                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + meta.x;
+                const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
+                unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
+                unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
+                unsafeAtomicAdd(dst + 2 * plane, a_xx);
+                unsafeAtomicAdd(dst + 3 * plane, a_xy);
+                unsafeAtomicAdd(dst + 4 * plane, a_yy);
+                unsafeAtomicAdd(dst + 5 * plane, a.proper_aa ? -2.0f * Sh / op : -2.0f * Sh * (1.0f - op));
+                unsafeAtomicAdd(dst + 6 * plane, (flags & 1u) ? c0 : 0.0f);
+                unsafeAtomicAdd(dst + 7 * plane, (flags & 2u) ? c1 : 0.0f);
+                unsafeAtomicAdd(dst + 8 * plane, (flags & 4u) ? c2 : 0.0f);
+            }
+        }
+        __syncthreads();                                                       // the next item restages the records and clears the accumulators
+    }
+}
+
 #ifdef FGS_PAIR_STATS
 }  // namespace fgs
 extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_pair_stats(unsigned long long* out, int reset) {
@@ -634,7 +853,7 @@ std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted 
 
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
     BlendBackwardArgs a = a_in;
-    if (g_backward_variant == 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(kTileScanThreads), 0, s, a);
+    if (g_backward_variant >= 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(kTileScanThreads), 0, s, a);
     else a.live_offsets = nullptr;                            // the other variants walk all buckets: no list
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
     return hipGetLastError();
@@ -643,6 +862,14 @@ hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
 hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
     const BlendBackwardArgs& a = a_in;
     if (a.n_buckets_cap == 0) return hipSuccess;
+    if (g_backward_variant == 4) {
+        BlendBackwardArgs a = a_in;
+        a.ablate = g_backward_ablate;
+        const unsigned blocks = a.n_buckets_cap < FGS_K11M_MAX_BLOCKS ? a.n_buckets_cap : FGS_K11M_MAX_BLOCKS;
+        hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(blocks), dim3(kTilePixels), 0, s, a);
+        hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (g_backward_variant == 3) {
         BlendBackwardArgs a = a_in;
         a.ablate = g_backward_ablate;

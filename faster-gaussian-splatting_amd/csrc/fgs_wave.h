@@ -103,6 +103,22 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ unsigned in_vector_register(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); } // v_exp_f32, 1 ulp (__expf = this after a multiply by log2 e)
 
+// Matrix core, fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32, 32 cycles on the SIMD's matrix pipe, beside the vector pipe):
+// D[i][j] += sum_k A[i][k] B[k][j] for a 16 x 4 A and a 4 x 16 B. Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds
+// D[4 (l >> 4) + r][l & 15] in acc[r], r = 0..3. Bitwise a k-ordered fmaf chain (no wider internal accumulation). Full EXEC required.
+typedef float fgs_acc4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wave_mfma_16x16x4(const float a, const float b, fgs_acc4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+// v (wave-uniform) into lane `lane` (wave-uniform) of `old`, the other lanes keep theirs (this compiler has no v_writelane builtin: a compare + select)
+__device__ __forceinline__ unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) {
+    return lane_id() == lane ? v : old;
+}
+// every lane reads `v` of an arbitrary lane (ds_bpermute_b32: the LDS crossbar, no memory)
+__device__ __forceinline__ unsigned wave_shuffle(const unsigned v, const unsigned src_lane) {
+    return static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src_lane << 2), static_cast<int>(v)));
+}
+
 // One step of the backward pixel pipeline for NV per-pixel values:
 //   feed[]  rotates down by one lane (lane l takes lane l+1, lane 63 takes lane 0)      -- DPP wave_rol:1
 //   state[] shifts up by one lane (lane l takes lane l-1) and lane 0 takes its own feed[] -- DPP wave_shr:1 with

@@ -170,12 +170,14 @@ def initialize_from_point_cloud(positions: torch.Tensor, colors: torch.Tensor | 
 
 
 # ---- a structured ground truth for end-to-end training runs (tools/train_full.py) ------------------------------------------
-def make_surface_scene(n: int, seed: int = 4321, sh_bases: int = 16, morton: bool = True) -> dict:
+def make_surface_scene(n: int, seed: int = 4321, sh_bases: int = 16, morton: bool = True, disk_scale: float = 1.3, jitter: float = 0.24) -> dict:
     """Gaussians lying ON surfaces, the way a trained 3DGS scene looks: a gently rolling textured ground over [-4, 4]^2 and a dozen
     textured ellipsoids resting on it; every Gaussian is a thin, nearly opaque disk in the tangent plane of its surface point, coloured by
-    a procedural albedo (checker + stripes + a per-object tint) with no view dependence. Unlike `make_garden_like` (independent random
+    a procedural albedo (checker + stripes at 16 cm and 2.5 cm + a per-disk jitter + a per-object tint) with no view dependence. Unlike `make_garden_like` (independent random
     blobs filling a volume: every view looks like noise with parallax between the layers), renders of this scene are consistent across
-    views, so a model trained on some cameras can be judged on held-out ones. World is y-down (the ground is near y = +2)."""
+    views, so a model trained on some cameras can be judged on held-out ones. World is y-down (the ground is near y = +2).
+    `disk_scale` = disk sigma / disk spacing (1.3: neighbours blend into a smooth albedo; ~0.6: every disk stays a distinct cell), `jitter` = range
+    of the per-disk albedo variation (large values + small disks give a mosaic whose detail a model can only reach by growing)."""
     g = torch.Generator().manual_seed(seed)
     u = lambda *s: torch.rand(*s, generator=g)
     nrm = lambda *s: torch.randn(*s, generator=g)
@@ -208,10 +210,12 @@ def make_surface_scene(n: int, seed: int = 4321, sh_bases: int = 16, morton: boo
     chk = ((torch.floor(pos[:, 0] * 2.0) + torch.floor(pos[:, 2] * 2.0) + torch.floor(pos[:, 1] * 2.0)) % 2.0) * 0.5 + 0.5
     stripes = 0.5 + 0.5 * torch.sin(pos[:, 0] * 40.0 + 3.0 * torch.sin(pos[:, 2] * 2.0))
     slow = 0.5 + 0.5 * torch.sin(pos * torch.tensor([0.8, 1.3, 1.1]) + torch.tensor([0.3, 1.1, 2.0]))
-    rgb = (tint * (0.35 + 0.65 * chk[:, None]) * (0.7 + 0.3 * stripes[:, None]) * (0.6 + 0.4 * slow)).clamp(0.02, 0.98)
+    fine = 0.5 + 0.5 * torch.sin(250.0 * (0.6 * pos[:, 0] + 0.8 * pos[:, 2]) + 60.0 * pos[:, 1])        # 2.5 cm period: ~6 pixels from the training cameras
+    jitter = jitter * (u(n, 3) - 0.5)                                                                         # per-disk albedo variation (disk spacing ~7 mm)
+    rgb = (tint * (0.35 + 0.65 * chk[:, None]) * (0.7 + 0.3 * stripes[:, None]) * (0.6 + 0.4 * slow) * (0.7 + 0.3 * fine[:, None]) + jitter).clamp(0.02, 0.98)
     # thin disks in the tangent plane: rotation takes the local z axis onto the normal
     spacing = math.sqrt(float(areas.sum()) / n)
-    s_t = spacing * 1.3 * torch.exp(0.25 * nrm(n, 1)) * (0.8 + 0.4 * u(n, 2))
+    s_t = spacing * disk_scale * torch.exp(0.25 * nrm(n, 1)) * (0.8 + 0.4 * u(n, 2))
     scales = torch.log(torch.cat([s_t, 0.12 * s_t.mean(dim=1, keepdim=True)], dim=1))
     zaxis = torch.tensor([0.0, 0.0, 1.0]).expand(n, 3)
     half = torch.nn.functional.normalize(zaxis + nor + 1e-6 * nrm(n, 3), dim=1)           # quaternion of the shortest arc z -> normal: (z . h, z x h)

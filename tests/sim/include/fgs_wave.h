@@ -89,6 +89,32 @@ inline unsigned in_vector_register(unsigned x) { return x; }
 inline float4 load_float4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
 inline void store_float4_nt(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// v_mfma_f32_16x16x4_f32 on the fiber scheduler: a k-ordered fmaf chain, which is what the hardware computes bit for bit
+// (cdna_hip_programming.md, "FP32-input MFMA"). Lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15], holds D[4 (l >> 4) + r][l & 15].
+struct fgs_acc4 { float v[4]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+inline void wave_mfma_16x16x4(const float a, const float b, fgs_acc4& acc) {
+    const int par = sim::next_parity(true);
+    sim::Lane& L = sim::me();
+    L.slot[par][0] = __float_as_uint(a); L.slot[par][1] = __float_as_uint(b);
+    const unsigned g = sim::sync_scope(true);
+    sim::Block& blk = sim::blk();
+    const int first = (blk.cur / 64) * 64, lane = blk.cur - first;
+    const int col = lane & 15, rowg = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rowg + r;
+        float d = acc[r];
+        for (int k = 0; k < 4; ++k) {
+            const sim::Lane& la = blk.lanes[first + row + 16 * k];      // A[row][k]
+            const sim::Lane& lb = blk.lanes[first + 16 * k + col];      // B[k][col]
+            if (la.gen_wave < g || lb.gen_wave < g) { fprintf(stderr, "[sim] wave_mfma_16x16x4 needs all 64 lanes\n"); abort(); }
+            d = fmaf(__uint_as_float(static_cast<unsigned>(la.slot[par][0])), __uint_as_float(static_cast<unsigned>(lb.slot[par][1])), d);
+        }
+        acc[r] = d;
+    }
+}
+inline unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) { return lane_id() == lane ? v : old; }
+inline unsigned wave_shuffle(const unsigned v, const unsigned src_lane) { return static_cast<unsigned>(sim_exchange(v, static_cast<int>(src_lane & 63u))); }
+
 template <int NV>
 inline void pipeline_advance(float (&state)[NV], float (&feed)[NV]) {
     static_assert(2 * NV <= sim::kSlots, "slot overflow");

@@ -2,8 +2,8 @@
 end on this backend -- random initialisation, growth by adaptive density control, opacity resets, Morton re-ordering, the SH schedule -- and
 not only its kernels.
 
-* ground truth: a STRUCTURED scene (harness.scenes.make_surface_scene, default 2 M Gaussians: textured ground + ellipsoids, every Gaussian a thin
-  opaque disk on its surface -- consistent across views, so held-out cameras mean something; `--gt-scene garden` = the benchmark's random-blob
+* ground truth: a STRUCTURED scene (harness.scenes.make_surface_scene, default 300 k Gaussians: textured ground + ellipsoids, every Gaussian a thin
+  opaque disk on its surface, a mosaic of distinct randomly tinted cells ~2 cm across -- consistent across views, so held-out cameras mean something; `--gt-scene garden` = the benchmark's random-blob
   volume S2, whose views look like noise with parallax: a model fits its training views and does not grow, profiles/r04_train_full_garden_gt.json)
   rendered at 1920x1080 from 64 training cameras (4 rings of 16 on a hemisphere shell) and 8 HELD-OUT cameras (between the rings, other azimuths);
 * model: RANDOM_INITIALIZATION of fastergs_garden.yaml -- N_POINTS = 100 000 uniform samples of the scene's bounding box, carved to the points
@@ -15,7 +15,7 @@ not only its kernels.
 * report (one JSON line): Gaussian-count curve, train / held-out PSNR at 7 000 / 15 000 / 30 000, iterations/s including the callbacks, seconds
   inside them, peak VRAM, async-forward / live-block statistics, non-finite losses.
 
-usage: python tools/train_full.py [--gt-scene surface|garden] [--gt 2000000] [--iters 30000] [--points 100000] [--max-gaussians 0] [--max-seconds 0] [--save-ply out.ply]
+usage: python tools/train_full.py [--gt-scene surface|garden] [--gt 300000] [--iters 30000] [--points 100000] [--max-gaussians 0] [--max-seconds 0] [--save-ply out.ply]
        --max-gaussians: density control stops ADDING above this count (0 = no cap, as the reference); --max-seconds: wall-clock guard of the loop.
 """
 import argparse, json, math, os, sys, time
@@ -27,7 +27,9 @@ from harness import trainer as T
 from harness.scenes import initialize_from_point_cloud, look_at_view, make_garden_like, make_surface_scene
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--gt-scene', default='surface', choices=['surface', 'garden']); ap.add_argument('--gt', type=int, default=2_000_000); ap.add_argument('--iters', type=int, default=30_000)
+ap.add_argument('--gt-scene', default='surface', choices=['surface', 'garden']); ap.add_argument('--gt', type=int, default=300_000);
+ap.add_argument('--disk-scale', type=float, default=0.65); ap.add_argument('--jitter', type=float, default=0.9)     # surface scene: a mosaic of distinct cells
+ap.add_argument('--iters', type=int, default=30_000)
 ap.add_argument('--points', type=int, default=100_000); ap.add_argument('--max-gaussians', type=int, default=0)
 ap.add_argument('--max-seconds', type=float, default=0.0); ap.add_argument('--save-ply', default=''); ap.add_argument('--seed', type=int, default=7)
 ap.add_argument('--eval-at', default='7000,15000,30000'); ap.add_argument('--async-forward', action='store_true')
@@ -50,7 +52,7 @@ held_views = ring(4, 6.4, 1.8, 0.3) + ring(4, 6.8, 3.4, 0.8)
 train_views, held_views = [v.to(dev) for v in train_views], [v.to(dev) for v in held_views]
 
 t_setup = time.perf_counter()
-gt_params = make_surface_scene(a.gt) if a.gt_scene == 'surface' else make_garden_like(a.gt)
+gt_params = make_surface_scene(a.gt, disk_scale=a.disk_scale, jitter=a.jitter) if a.gt_scene == 'surface' else make_garden_like(a.gt)
 gt = T.Gaussians(gt_params, dev)
 targets = [T.render_image_benchmark(gt, v).clone() for v in train_views]
 held_targets = [T.render_image_benchmark(gt, v).clone() for v in held_views]
@@ -136,7 +138,7 @@ if a.save_ply:
 final = evals[str(done)]
 print(json.dumps({
     'what': 'from-scratch full-schedule training run (tools/train_full.py): random initialisation + carving, fastergs_garden.yaml schedule uncompressed',
-    'ground_truth': f'{a.gt_scene} scene, {a.gt} Gaussians, {W}x{H}, {len(train_views)} training + {len(held_views)} held-out cameras', 'extent': extent,
+    'ground_truth': f'{a.gt_scene} scene (disk scale {a.disk_scale}, jitter {a.jitter}), {a.gt} Gaussians, {W}x{H}, {len(train_views)} training + {len(held_views)} held-out cameras', 'extent': extent,
     'init_points': a.points, 'gaussians_after_carving': curve[0][1], 'iterations_done': done, 'iterations_planned': a.iters,
     'gaussians_end': g.means.shape[0], 'gaussians_max': max(c[1] for c in curve), 'count_curve_every_10th_call': curve[::10] + [curve[-1]],
     'psnr': evals, 'held_out_minus_train_db': final['held_out_psnr_db'] - final['train_psnr_db'],
