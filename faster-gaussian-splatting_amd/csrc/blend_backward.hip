@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const
     __shared__ uint2 s_meta[kBucket];                                          // primitive, hot-slot word
     __shared__ float s_acc[9 * kBucket];                                       // planes Sh Sx Sy Sxx Sxy Syy c0 c1 c2 of the bucket's Gaussians
     __shared__ __attribute__((aligned(16))) float s_v[kTilePixels / kWave][kPixRows * kPixStride];
+    __shared__ uint8_t s_order[kTilePixels / kWave][kBucket + kPixSlots + 4];     // per wave: bucket-relative index of the i-th Gaussian it walks
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
     float* const v_mine = s_v[wave];
     const unsigned pos = (lane & 3u) * 16u + (lane >> 2);                      // pixel p = 4 s + q of matrix k-step s sits at q * 16 + s of its row
@@ -712,23 +713,27 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const
         }
         const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
         const uint64_t mine = half ? mask_r : mask_l;
-        const unsigned rel_max = wave_max(rel);                                // Gaussians at or behind every pixel's last contributor take nothing (kb:412)
-        uint64_t pending = (mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull));
+        // Gaussians at or behind every pixel's last contributor take nothing (kb:412). The maximum is wave-uniform; the compiler only knows that
+        // of a value read through v_readfirstlane, and a list it believes divergent turns the whole walk below into an EXEC-masked vector loop
+        const unsigned rel_max = wave_uniform(wave_max(rel));
+        const uint64_t pending = rel_max == 0u ? 0ull : (mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull));
+        // slot -> Gaussian of the matrix batches: the walk visits the set bits of `pending` in order, so its i-th pair is the i-th set bit
+        // (every lane stores -- the lanes outside the list into a spare element -- so that no divergent branch sits between the list and the walk)
+        s_order[wave][((pending >> lane) & 1ull) ? lanes_below(pending) : kBucket + kPixSlots] = static_cast<uint8_t>(lane);
 
-        unsigned n_slots = 0;                                                  // filled rows of the current matrix batch (wave-uniform)
-        unsigned slot_gaussian = 0;                                            // lane i < 8: bucket-relative index of the Gaussian in slot i
+        unsigned n_slots = 0, n_flushed = 0;                                   // filled rows of the current matrix batch, pairs of earlier batches (wave-uniform)
         auto flush = [&](const unsigned n) {
             wave_lds_fence();
             const float4* bp = reinterpret_cast<const float4*>(v_mine + col * kPixStride + q * 16u);
             const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+            const unsigned slot = col & 7u;
+            const unsigned gi = s_order[wave][n_flushed + slot];
             fgs_acc4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains: a dependent matrix instruction waits 40 cycles, an independent one 32
             wave_mfma_16x16x4(A[0], b0.x, d0); wave_mfma_16x16x4(A[1], b0.y, d1); wave_mfma_16x16x4(A[2], b0.z, d0); wave_mfma_16x16x4(A[3], b0.w, d1);
             wave_mfma_16x16x4(A[4], b1.x, d0); wave_mfma_16x16x4(A[5], b1.y, d1); wave_mfma_16x16x4(A[6], b1.z, d0); wave_mfma_16x16x4(A[7], b1.w, d1);
             wave_mfma_16x16x4(A[8], b2.x, d0); wave_mfma_16x16x4(A[9], b2.y, d1); wave_mfma_16x16x4(A[10], b2.z, d0); wave_mfma_16x16x4(A[11], b2.w, d1);
             wave_mfma_16x16x4(A[12], b3.x, d0); wave_mfma_16x16x4(A[13], b3.y, d1); wave_mfma_16x16x4(A[14], b3.z, d0); wave_mfma_16x16x4(A[15], b3.w, d1);
             // this lane holds D[row 4 q + r][col]: rows 0..2 = colour sums (columns 0..7, the w rows), rows 3..8 = moment sums (columns 8..15, the hh rows)
-            const unsigned slot = col & 7u;
-            const unsigned gi = wave_shuffle(slot_gaussian, slot);
             const bool is_w = col < 8u;
             if (slot < n) {
                 if (q == 0u) {
@@ -743,43 +748,47 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const
                     } else if (q == 2u) atomicAdd(&s_acc[5 * kBucket + gi], d0[0] + d1[0]);
                 }
             }
+            n_flushed += n;
             wave_lds_fence();                                                  // the next batch overwrites the rows
         };
 
-        if (rel_max == 0u) pending = 0;                                        // no live pixel in this strip
+        float* v_row = v_mine + pos;                                           // this lane's element of the row of the current slot
 #pragma unroll
         for (unsigned word = 0; word < 2u; ++word) {                           // the forward kernel's walk (blend_forward.hip): bit-reversed 32-bit words
-            uint32_t pend = __brev(static_cast<uint32_t>(word ? pending >> 32 : pending));
+            uint32_t pend = wave_uniform(__brev(static_cast<uint32_t>(word ? pending >> 32 : pending)));      // (re-stated uniform: see rel_max)
             const uint32_t not_mine = __brev(~static_cast<uint32_t>(word ? mine >> 32 : mine));
             const unsigned j0 = 32u * word;
             const unsigned row0 = in_vector_register(j0 * 16u);
-            while (pend != 0) {                                                // wave-uniform
+            while (pend != 0) {                                                // wave-uniform scalar loop
                 const unsigned k = static_cast<unsigned>(__clz(static_cast<int>(pend)));
                 pend &= ~(0x80000000u >> k);
                 const float4* const entry = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k << 4)));
                 const float4 ga = entry[0], gb = entry[kBucket];
+                const float colb = entry[2 * kBucket].x;
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
                 const float gauss = __expf(fminf(power, 0.0f));
-                const float alpha = gb.y * gauss;
-                const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha));
-                float w = 0.0f, hh = 0.0f;
-                if (tested >= gate) {                                          // kb:412,419-421
-                    const float colb = entry[2 * kBucket].x;
-                    w = T * alpha;
-                    const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
-                    sS -= w * cg;                                               // kb:429 projected on dL/dC
-                    const float oma = 1.0f - alpha;
-                    const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
-                    const float dl_dalpha = T * cg - sS * oma_rcp;              // kb:434-436
-                    hh = (-0.5f * alpha) * dl_dalpha;
-                    T *= oma;
-                    gate = j0 + k + 1u >= rel ? __builtin_inff() : gate;        // that was this pixel's last contributor
-                }
-                v_mine[n_slots * kPixStride + pos] = w;
-                v_mine[(kPixSlots + n_slots) * kPixStride + pos] = hh;
-                slot_gaussian = wave_write_lane(slot_gaussian, j0 + k, n_slots);
-                if (++n_slots == kPixSlots) { flush(kPixSlots); n_slots = 0; }
+                const float alpha_raw = gb.y * gauss;
+                const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha_raw));
+                // Branch-free: a pair that does not contribute (kb:412,419-421) runs the same instructions with alpha = 0, which leaves T and S as they
+                // are and gives w = hh = 0 -- the contribution block would run anyway in 92-96 % of the pairs (profiles/r04_k11_pair_efficiency.txt:
+                // some lane passes), and without it there is no EXEC bookkeeping and no zero-fill of the two values that go to the matrix rows.
+                const float alpha = tested >= gate ? alpha_raw : 0.0f;
+                const float w = T * alpha;
+                const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
+                sS -= w * cg;                                                   // kb:429 projected on dL/dC
+                const float oma = 1.0f - alpha;
+                const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+                const float dl_dalpha = T * cg - sS * oma_rcp;                  // kb:434-436
+                const float hh = (-0.5f * alpha) * dl_dalpha;
+                T *= oma;
+                // index rel - 1 is this pixel's last contributor: from there on it takes nothing (for smaller indices the test is false, for larger ones
+                // the gate is closed already)
+                gate = j0 + k + 1u >= rel ? __builtin_inff() : gate;
+                v_row[0] = w;
+                v_row[kPixSlots * kPixStride] = hh;
+                v_row += kPixStride;
+                if (++n_slots == kPixSlots) { flush(kPixSlots); n_slots = 0; v_row = v_mine + pos; }
             }
         }
         if (n_slots != 0) flush(n_slots);

@@ -110,6 +110,8 @@ typedef float fgs_acc4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wave_mfma_16x16x4(const float a, const float b, fgs_acc4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
+// tells the compiler that v is the same in every lane (v_readfirstlane_b32 -> a scalar register): loops and branches on it stay scalar
+__device__ __forceinline__ unsigned wave_uniform(const unsigned v) { return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 // v (wave-uniform) into lane `lane` (wave-uniform) of `old`, the other lanes keep theirs (this compiler has no v_writelane builtin: a compare + select)
 __device__ __forceinline__ unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) {
     return lane_id() == lane ? v : old;

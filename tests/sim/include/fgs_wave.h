@@ -112,6 +112,7 @@ inline void wave_mfma_16x16x4(const float a, const float b, fgs_acc4& acc) {
         acc[r] = d;
     }
 }
+inline unsigned wave_uniform(const unsigned v) { return v; }
 inline unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) { return lane_id() == lane ? v : old; }
 inline unsigned wave_shuffle(const unsigned v, const unsigned src_lane) { return static_cast<unsigned>(sim_exchange(v, static_cast<int>(src_lane & 63u))); }
 
