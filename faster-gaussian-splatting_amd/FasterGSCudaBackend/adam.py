@@ -15,7 +15,7 @@ from typing import Iterator, NamedTuple
 import torch
 
 from ._backend import default_backend
-from .rasterization import clear_live_blocks, match_live_blocks
+from .rasterization import clear_live_blocks, match_live_blocks, take_async_overflow
 
 _GROUPS_PER_LAUNCH = 8          # AdamArgs::g[8] in csrc/fgs_kernels.h
 
@@ -58,6 +58,11 @@ class FusedAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self) -> None:
+        if take_async_overflow():
+            # the rasterizer's backward pass returned zeros because its (asynchronously sized) forward pass was truncated: stepping on them would
+            # decay the moments, advance the step counts and move every parameter on momentum for a loss that was never evaluated
+            clear_live_blocks()
+            return
         launches: dict[tuple, list[_Update]] = {}
         for key, update in self._pending():
             launches.setdefault(key, []).append(update)

@@ -26,13 +26,20 @@ def set_gradient_buffers(provider) -> None:
 # The reference blocks the host three times per forward pass (forward.cu:100,102,234) to size its buffers; fgs_forward once. With
 # `set_async_forward(True)` the training path sizes the instance stages from what an earlier pass OF THE SAME VIEW needed -- that view's
 # instances-per-Gaussian ratio x the current Gaussian count x `headroom` -- and reads the counts back asynchronously; they are looked at in
-# `backward` (by then the copy has long completed). A view that has not been seen yet (keyed by the address of its w2c tensor and the image
-# size), and any pass that does not need gradients (torch.no_grad(), detached inputs: nobody would ever look at the counts), takes the
-# synchronous path -- a ratio borrowed from other views overflows in the first epoch (round-2 advisor finding). If a pass still needs more
-# than its capacity (the instance count of one view jumped by more than the headroom between two of its visits), its image and therefore the
-# loss gradient were incomplete: backward reports it (RuntimeWarning), refreshes the view's ratio and returns ZERO gradients (and leaves
-# densification_info alone) -- mixing a re-rendered image with the gradient of a truncated one would be an inconsistent step.
-_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0, 'per_view': {}}
+# `backward` (by then the copy has long completed). A view that has not been seen yet, and any pass that does not need gradients
+# (torch.no_grad(), detached inputs: nobody would ever look at the counts), takes the synchronous path -- a ratio borrowed from other views
+# overflows in the first epoch (round-2 advisor finding). A view is recognised by the IDENTITY of its w2c tensor (address + a weak reference to
+# the tensor object + its version counter, plus image size and intrinsics): an address the caching allocator hands to another tensor, or a w2c
+# edited in place, is a new view, never a cache hit (round-3 advisor finding); a training loop that builds a fresh w2c every iteration therefore
+# stays synchronous -- correct, only without the saving. The table is bounded (least recently used views are dropped).
+# If a pass still needs more than its capacity (the instance count of one view jumped by more than the headroom between two of its visits), its
+# image and therefore the loss gradient were incomplete: backward reports it (RuntimeWarning), refreshes the view's ratio, returns ZERO gradients
+# (written into the caller's gradient buffers when a provider is set; densification_info is left alone) and marks the step invalid:
+# `FusedAdam.step` consumes that mark and skips the step -- no moment decay, no step count, no parameter motion on momentum (any other optimizer
+# can ask `take_async_overflow()`). A pass that asked for gradients but whose backward never runs (an evaluation loop without no_grad) is checked
+# lazily by the next forward pass, which warns if that image was truncated.
+_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0, 'per_view': {}, 'pending': {}, 'step_invalid': False, 'ticket': 0}
+_ASYNC_MAX_VIEWS = 1024
 
 # ---- live-block hand-over from this backward pass to FusedAdam.step ------------------------------------------------------------------
 # One third of the Gaussians is invisible in a view; their gradients are zeros that the backward pass writes (the gradient tensors are dense and
@@ -103,17 +110,67 @@ def match_live_blocks(gradients) -> 'torch.Tensor | None':
 def set_async_forward(enabled: bool, headroom: float = 1.25) -> None:
     _ASYNC.update(enabled=bool(enabled), headroom=float(headroom))
     if not enabled:
-        _ASYNC.update(ratio=0.0, per_view={})
+        _ASYNC.update(ratio=0.0, per_view={}, pending={}, step_invalid=False)
 
 
 def async_forward_stats() -> dict:
     """'ratio': the largest instances-per-Gaussian ratio of any view so far (informational); 'views': views with a recorded ratio."""
     return {'enabled': _ASYNC['enabled'], 'headroom': _ASYNC['headroom'], 'ratio': _ASYNC['ratio'], 'overflows': _ASYNC['overflows'],
-            'views': len(_ASYNC['per_view'])}
+            'views': len(_ASYNC['per_view']), 'unchecked_passes': len(_ASYNC['pending'])}
+
+
+def take_async_overflow() -> bool:
+    """True once after a backward pass had to return zero gradients because its forward pass overflowed its capacity: the optimizer step that
+    would consume them must be skipped (FusedAdam.step does)."""
+    flag = _ASYNC['step_invalid']
+    _ASYNC['step_invalid'] = False
+    return flag
 
 
 def _view_key(settings: RasterizerSettings):
-    return (settings.w2c.data_ptr(), int(settings.width), int(settings.height))
+    return (settings.w2c.data_ptr(), int(settings.width), int(settings.height), float(settings.focal_x), float(settings.focal_y),
+            float(settings.center_x), float(settings.center_y))
+
+
+def _view_ratio(key, w2c: torch.Tensor) -> float:
+    """The recorded instances-per-Gaussian ratio of this view, or 0.0 if `w2c` is not the very tensor (object and content version) it was recorded for."""
+    entry = _ASYNC['per_view'].get(key)
+    if entry is None:
+        return 0.0
+    ratio, ref, version = entry
+    if ref() is not w2c or w2c._version != version:
+        del _ASYNC['per_view'][key]
+        return 0.0
+    _ASYNC['per_view'][key] = _ASYNC['per_view'].pop(key)          # most recently used last
+    return ratio
+
+
+def _record_ratio(key, w2c: torch.Tensor, ratio: float) -> None:
+    import weakref
+    table = _ASYNC['per_view']
+    table.pop(key, None)
+    table[key] = (ratio, weakref.ref(w2c), w2c._version)
+    while len(table) > _ASYNC_MAX_VIEWS:
+        del table[next(iter(table))]
+    _ASYNC['ratio'] = max(_ASYNC['ratio'], ratio)
+
+
+def _check_abandoned_passes() -> None:
+    """Asynchronous passes whose backward never ran: look at their counts now (their copies completed long ago) and say so if an image was truncated."""
+    pending = _ASYNC['pending']
+    for ticket in list(pending):
+        host, event, capacity = pending[ticket]
+        if event is not None and not event.query():
+            continue
+        del pending[ticket]
+        if int(host[2]) != 0:
+            import warnings
+            _ASYNC['overflows'] += 1
+            warnings.warn(f'FasterGS async forward: an earlier pass whose backward never ran needed {int(host[1])} instances but had capacity {capacity}: '
+                          f'the image it returned was incomplete (render evaluation views under torch.no_grad(): those passes are sized synchronously)',
+                          RuntimeWarning)
+    while len(pending) > 64:                      # never unbounded: drop the oldest tickets unchecked
+        del pending[next(iter(pending))]
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -132,19 +189,23 @@ class _Rasterize(torch.autograd.Function):
         be, n = default_backend(), means.shape[0]
         capacity, key = None, None
         if _ASYNC['enabled'] and n > 0:
+            if _ASYNC['pending']:
+                _check_abandoned_passes()
             key = _view_key(rasterizer_settings)
-            ratio = _ASYNC['per_view'].get(key, 0.0)
+            ratio = _view_ratio(key, rasterizer_settings.w2c)
             # only a pass whose backward will run ever looks at the asynchronous counts; everything else is checked now (synchronously)
             if ratio > 0.0 and any(ctx.needs_input_grad[:6]):
                 capacity = int(ratio * n * _ASYNC['headroom']) + 4096
         res = be.forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings, capacity)
         if capacity is None:
             if key is not None:
-                _ASYNC['per_view'][key] = res.state[1] / n
-                _ASYNC['ratio'] = max(_ASYNC['ratio'], res.state[1] / n)
+                _record_ratio(key, rasterizer_settings.w2c, res.state[1] / n)
             ctx.async_check = None
         else:
-            ctx.async_check = be.forward_counts(res, n) + (key,)
+            host, event = be.forward_counts(res, n)
+            _ASYNC['ticket'] += 1
+            _ASYNC['pending'][_ASYNC['ticket']] = (host, event, capacity)      # consumed by backward; looked at by a later forward otherwise
+            ctx.async_check = (host, event, key, _ASYNC['ticket'])
         ctx.rasterizer_settings = rasterizer_settings
         ctx.buffer_state = res.state
         ctx.save_for_backward(res.image, means, scales, rotations, opacities, sh_coefficients_rest, *res.buffers)
@@ -158,22 +219,28 @@ class _Rasterize(torch.autograd.Function):
         image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
         state = ctx.buffer_state
         if ctx.async_check is not None:
-            host, event, key = ctx.async_check
+            host, event, key, ticket = ctx.async_check
+            _ASYNC['pending'].pop(ticket, None)
             if event is not None:
                 event.synchronize()
             n = means.shape[0]
-            _ASYNC['per_view'][key] = int(host[1]) / max(n, 1)
-            _ASYNC['ratio'] = max(_ASYNC['ratio'], int(host[1]) / max(n, 1))
+            _record_ratio(key, ctx.rasterizer_settings.w2c, int(host[1]) / max(n, 1))
             if int(host[2]) != 0:          # the capacity was too small: the image (and the loss gradient) missed the instances beyond it
                 import warnings
                 _ASYNC['overflows'] += 1
                 warnings.warn(f'FasterGS async forward: {int(host[1])} instances exceeded the capacity {state[1]} of this pass: its image was '
-                              f'incomplete, so this backward pass returns zero gradients (the view is rendered with the right capacity next time)',
-                              RuntimeWarning)
+                              f'incomplete, so this backward pass returns zero gradients and FusedAdam.step skips the step (the view is rendered with the '
+                              f'right capacity next time)', RuntimeWarning)
                 clear_live_blocks()
-                total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
-                zeros = tuple(torch.zeros(sh, dtype=torch.float32, device=means.device)
-                              for sh in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3)))
+                _ASYNC['step_invalid'] = True
+                if _GRAD_OUT is not None:          # a consumer that reads the provider's arena directly must not see the previous step's gradients
+                    zeros = tuple(_GRAD_OUT())
+                    for z in zeros:
+                        z.zero_()
+                else:
+                    total_rest = sh_rest.shape[1] if sh_rest.dim() == 3 else 0
+                    zeros = tuple(torch.zeros(sh, dtype=torch.float32, device=means.device)
+                                  for sh in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 1, 3), (n, total_rest, 3)))
                 return (*zeros, None, None)
         n = means.shape[0]
         if _LIVE['enabled'] and _GRAD_OUT is None and n > 0:

@@ -1055,6 +1055,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 2: fgs::g_adam_nontemporal = value ? 1 : 0; return FGS_OK;
         case 3: g_fused_single_kernel = value ? 1 : 0; return FGS_OK;
         case 7: fgs::g_backward_ablate = value & 15; return FGS_OK;
+        case 13: if (value < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "K11 variant 4 needs at least one workgroup"); fgs::g_k11m_max_blocks = value; return FGS_OK;
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;

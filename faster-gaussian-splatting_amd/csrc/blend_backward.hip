@@ -14,6 +14,8 @@
 //  * per-pixel constants (dL/dC, C_final - T_final*bg, T_final*-(dL/dC . bg), last contributor) are staged ONCE per
 //    backward pass into a tile-major 32-byte record, so each bucket reads 48 B per pixel with three coalesced 16-byte
 //    loads instead of gathering 9 scalars from image-linear arrays per bucket.
+#include <type_traits>
+
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 #include "fgs_tile_scan.h"
@@ -618,191 +620,258 @@ namespace fgs {
 // pixels when the rows are written and (k, column) pairs of the matrix instruction when they are read), and one pass of 16
 // v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain) multiplies the 9 x 64 feature matrix of the strip
 // [g_r, g_g, g_b, 1, x', y', x'^2, x'y', y'^2] with those rows: columns 0..7 = w of the 8 slots, 8..15 = hh. The matrix pipe runs beside the
-// vector pipe; the vector instructions per pair are the forward walk's plus the gradient arithmetic. The three waves of a tile add their
-// results into LDS accumulators of the bucket's 64 Gaussians; 64 threads convert and issue the nine global atomics as the other variants do.
+// vector pipe; the vector instructions per pair are the forward walk's plus the gradient arithmetic. The results of the tile's three strips
+// add up in LDS accumulators of the bucket's 64 Gaussians; then lane = Gaussian converts and issues the nine global atomics as the other variants do.
 // alpha is the forward kernel's expression operation for operation (same dx, dy: pixel centre = px + 0.5), T and S restart from the bucket's
 // checkpoint exactly as in the systolic form.
 constexpr unsigned kPixSlots = 8;                        // walked Gaussians per matrix pass
 constexpr unsigned kPixRows = 2 * kPixSlots;             // w rows, then hh rows
 constexpr unsigned kPixStride = 68;                      // floats per row: 64 pixels + 4, so that the 16-byte reads of 16 columns hit 64 distinct banks
 #ifndef FGS_K11M_MAX_BLOCKS
-#define FGS_K11M_MAX_BLOCKS 32768
+#define FGS_K11M_MAX_BLOCKS 65536
 #endif
-__global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const BlendBackwardArgs a) {
+// Debug-only phase timer (tools/k11m_phases.sh, -DFGS_K11M_PHASES; the product build has none of it): shader cycles per wave summed over the launch --
+// [0] items, [1] staging of the records, [2] per strip: pixel loads, feature operand, cull + order table, [3] the walk without its matrix passes,
+// [4] the matrix passes, [5] tail (conversion, atomics), [6] pairs walked, [7] matrix passes.
+#ifdef FGS_K11M_PHASES
+__device__ unsigned long long g_k11m_phases[8];
+#define FGS_PH(i) ph_[i] += __builtin_readcyclecounter() - pt_, pt_ = __builtin_readcyclecounter()
+#else
+#define FGS_PH(i)
+#endif
+__global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const BlendBackwardArgs a) {
+    // ONE wave per work item (tile, bucket), as in the systolic form: it walks the tile's three 16x4 strips one after the other, so there is no
+    // workgroup barrier (the first version gave each strip its own wave: the two waves with the shorter lists waited at the barrier for the
+    // third, and eight 3-wave workgroups per CU did not cover the four dependent loads at the head of every item).
     __shared__ float4 s_rec[3 * kBucket];                                      // mean.xy conic.ab | conic.c opacity r g (clamped) | b (clamped) bounds_x bounds_y flags
-    __shared__ uint2 s_meta[kBucket];                                          // primitive, hot-slot word
     __shared__ float s_acc[9 * kBucket];                                       // planes Sh Sx Sy Sxx Sxy Syy c0 c1 c2 of the bucket's Gaussians
-    __shared__ __attribute__((aligned(16))) float s_v[kTilePixels / kWave][kPixRows * kPixStride];
-    __shared__ uint8_t s_order[kTilePixels / kWave][kBucket + kPixSlots + 4];     // per wave: bucket-relative index of the i-th Gaussian it walks
-    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, half = lane >> 5;
-    float* const v_mine = s_v[wave];
+    __shared__ __attribute__((aligned(16))) float s_v[kPixRows * kPixStride];
+    __shared__ uint8_t s_order[kBucket + kPixSlots + 4];                       // bucket-relative index of the i-th Gaussian the current strip walks
+    const unsigned lane = threadIdx.x, half = lane >> 5;
+    float* const v_mine = s_v;
     const unsigned pos = (lane & 3u) * 16u + (lane >> 2);                      // pixel p = 4 s + q of matrix k-step s sits at q * 16 + s of its row
     const unsigned col = lane & 15u, q = lane >> 4;                            // this lane's column / k index in the matrix instruction
-    const unsigned lx = half * kSubtileW + (lane & 7u), ly = wave * kSubtileH + ((lane >> 3) & 3u);
-    const unsigned local = ly * kTileW + lx;
+    const unsigned lx = half * kSubtileW + (lane & 7u), ly_in_strip = (lane >> 3) & 3u;
     const unsigned n_live = *a.live_count;
-    for (unsigned item = blockIdx.x; item < n_live; item += gridDim.x) {      // workgroup-uniform
-        const uint2 work = a.work_list[item];
+#ifdef FGS_K11M_PHASES
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_readcyclecounter();
+#endif
+    // The head of an item is a chain of dependent loads (list entry -> tile range / bucket base -> primitive index -> record), and each strip
+    // had two more (pixel record -> checkpoint). With four waves per SIMD that latency was two thirds of a wave's time (tools/k11m_phases.sh). So:
+    // the scalar part of the chain is fetched one item AHEAD (the wave keeps the next item's list entry, range and bucket base in scalar
+    // registers), and everything per pixel -- the three strips' records and checkpoints -- is requested in one go at the top of the item, next
+    // to the primitive indices: two exposed round trips per item instead of ten.
+    unsigned item = blockIdx.x;
+    uint2 work = make_uint2(0u, 0u), range = make_uint2(0u, 0u);
+    unsigned bucket_base = 0;
+    if (item < n_live) {
+        work = a.work_list[item];
+        range = a.ranges[work.x];
+        bucket_base = work.x == 0 ? 0u : a.bucket_offsets[work.x - 1];
+    }
+    for (; item < n_live; item += gridDim.x) {                                 // wave-uniform
+#ifdef FGS_K11M_PHASES
+        ph_[0] += 1; pt_ = __builtin_readcyclecounter();
+#endif
         const unsigned tile = work.x, tb = work.y;
-        const uint2 range = a.ranges[tile];
         const unsigned tile_n = range.y - range.x;
-        const unsigned bucket = (tile == 0 ? 0u : a.bucket_offsets[tile - 1]) + tb;
+        const unsigned bucket = bucket_base + tb;
         const unsigned first_gaussian = tb * kBucket;
         const unsigned n_here = min(static_cast<unsigned>(kBucket), tile_n - first_gaussian);
         const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+        const unsigned range_x = range.x;
 
-        if (tid < kBucket) {                                                   // the bucket's records (kb:297-319)
+        // ---- requests of this item: primitive index, the three strips' pixel records and checkpoints ----
+        uint32_t prim = 0, hot_slot_word = 0;
+        if (lane < n_here) prim = a.inst_prims[range_x + first_gaussian + lane];
+        float4 cst_[3], g_[3], ck_[3];
+#pragma unroll
+        for (unsigned st = 0; st < 3u; ++st) {
+            const unsigned local = (st * kSubtileH + ly_in_strip) * kTileW + lx;
+            cst_[st] = a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1];
+            g_[st] = a.pixrec[((size_t)tile * kTilePixels + local) * 2];
+            ck_[st] = a.ckpt[(size_t)bucket * kTilePixels + local];
+        }
+        // ---- the scalar head of the NEXT item ----
+        {
+            const unsigned next = item + gridDim.x;
+            if (next < n_live) {
+                work = a.work_list[next];
+                range = a.ranges[work.x];
+                bucket_base = work.x == 0 ? 0u : a.bucket_offsets[work.x - 1];
+            }
+        }
+        {                                                                      // the bucket's records (kb:297-319), lane = Gaussian
             float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-            uint32_t prim = 0, flags = 0;
-            if (tid < n_here) {
-                prim = a.inst_prims[range.x + first_gaussian + tid];
+            uint32_t flags = 0;
+            if (lane < n_here) {
                 const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
                 r0 = r[0]; r1 = r[1]; r2 = r[2];
                 flags = (r1.z >= 0.0f ? 1u : 0u) | (r1.w >= 0.0f ? 2u : 0u) | (r2.x >= 0.0f ? 4u : 0u);      // kb:313-318
+                hot_slot_word = __float_as_uint(r2.w);
             }
-            s_rec[tid] = r0;
-            s_rec[kBucket + tid] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
-            s_rec[2 * kBucket + tid] = make_float4(fmaxf(r2.x, 0.0f), r2.y, r2.z, __uint_as_float(flags));
-            s_meta[tid] = make_uint2(prim, __float_as_uint(r2.w));
-        }
-        for (unsigned e = tid; e < 9u * kBucket; e += kTilePixels) s_acc[e] = 0.0f;
-
-        // ---- this lane's pixel: constants and the state at the bucket's checkpoint (kb:349-380) ----
-        const float pxf = static_cast<float>(tile_x * kTileW + lx) + 0.5f, pyf = static_cast<float>(tile_y * kTileH + ly) + 0.5f;
-        const float4 g = a.pixrec[((size_t)tile * kTilePixels + local) * 2];
-        const float4 cst = a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1];
-        const float4 ck = a.ckpt[(size_t)bucket * kTilePixels + local];
-        const unsigned last = __float_as_uint(cst.w);                          // 0 outside the image
-        // a pixel that finished before this bucket never wrote its checkpoint (kf:436) and receives nothing here
-        const bool live = last > first_gaussian;
-        const unsigned rel = live ? last - first_gaussian : 0u;                // Gaussians of this bucket in front of the pixel's last contributor
-        float T = live ? ck.w : 0.0f;
-        float sS = live ? ((cst.x - ck.x) * g.x + (cst.y - ck.y) * g.y + (cst.z - ck.z) * g.z) - g.w : 0.0f;   // kb:371-377 projected on dL/dC
-        float gate = live ? kMinAlphaThreshold : __builtin_inff();            // as in the forward walk: +inf once the pixel takes nothing more
-
-        // ---- the strip's feature matrix as matrix operand A: row c of [g_r g_g g_b 1 x' y' x'^2 x'y' y'^2], 16 k-steps ----
-        float A[16];
-        {
-            const float xr = static_cast<float>(lx) - 7.5f, yr = static_cast<float>(ly) - 5.5f;
-            v_mine[0 * kPixStride + pos] = g.x; v_mine[1 * kPixStride + pos] = g.y; v_mine[2 * kPixStride + pos] = g.z;
-            v_mine[3 * kPixStride + pos] = 1.0f; v_mine[4 * kPixStride + pos] = xr; v_mine[5 * kPixStride + pos] = yr;
-            v_mine[6 * kPixStride + pos] = xr * xr; v_mine[7 * kPixStride + pos] = xr * yr; v_mine[8 * kPixStride + pos] = yr * yr;
-            wave_lds_fence();
-            const float4* ap = reinterpret_cast<const float4*>(v_mine + min(col, 8u) * kPixStride + q * 16u);
+            s_rec[lane] = r0;
+            s_rec[kBucket + lane] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
+            s_rec[2 * kBucket + lane] = make_float4(fmaxf(r2.x, 0.0f), r2.y, r2.z, __uint_as_float(flags));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 t = ap[i];
-                const bool used = col < 9u;
-                A[4 * i] = used ? t.x : 0.0f; A[4 * i + 1] = used ? t.y : 0.0f; A[4 * i + 2] = used ? t.z : 0.0f; A[4 * i + 3] = used ? t.w : 0.0f;
-            }
-            wave_lds_fence();                                                  // the rows are reused for w / hh below
+            for (unsigned e = 0; e < 9u; ++e) s_acc[e * kBucket + lane] = 0.0f;
         }
-        __syncthreads();                                                       // records staged, accumulators cleared
-
-        // ---- cull the bucket against this wave's two 8x4 sub-tiles (kf:445-451) ----
-        const unsigned sub_y0 = tile_y * kTileH + wave * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
-        const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
-        bool in_l = false, in_r = false;
-        if (lane < n_here) {
-            const float4 gc = s_rec[2 * kBucket + lane];
-            const uint32_t bx = __float_as_uint(gc.y), by = __float_as_uint(gc.z);
-            const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
-            const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
-            in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
-            in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
+        // ---- the pixels' state at the bucket's checkpoint (kb:349-380): six values per strip stay in registers ----
+        float gx_[3], gy_[3], gz_[3], T_[3], S_[3];
+        unsigned rel_[3];
+#pragma unroll
+        for (unsigned st = 0; st < 3u; ++st) {
+            const unsigned last = __float_as_uint(cst_[st].w);                // 0 outside the image
+            // a pixel that finished before this bucket never wrote its checkpoint (kf:436) and receives nothing here
+            const bool live = last > first_gaussian;
+            rel_[st] = live ? last - first_gaussian : 0u;                      // Gaussians of this bucket in front of the pixel's last contributor
+            gx_[st] = g_[st].x; gy_[st] = g_[st].y; gz_[st] = g_[st].z;
+            T_[st] = live ? ck_[st].w : 0.0f;
+            S_[st] = live ? ((cst_[st].x - ck_[st].x) * g_[st].x + (cst_[st].y - ck_[st].y) * g_[st].y + (cst_[st].z - ck_[st].z) * g_[st].z) - g_[st].w : 0.0f;   // kb:371-377 projected on dL/dC
         }
-        const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
-        const uint64_t mine = half ? mask_r : mask_l;
-        // Gaussians at or behind every pixel's last contributor take nothing (kb:412). The maximum is wave-uniform; the compiler only knows that
-        // of a value read through v_readfirstlane, and a list it believes divergent turns the whole walk below into an EXEC-masked vector loop
-        const unsigned rel_max = wave_uniform(wave_max(rel));
-        const uint64_t pending = rel_max == 0u ? 0ull : (mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull));
-        // slot -> Gaussian of the matrix batches: the walk visits the set bits of `pending` in order, so its i-th pair is the i-th set bit
-        // (every lane stores -- the lanes outside the list into a spare element -- so that no divergent branch sits between the list and the walk)
-        s_order[wave][((pending >> lane) & 1ull) ? lanes_below(pending) : kBucket + kPixSlots] = static_cast<uint8_t>(lane);
+        wave_lds_fence();
+        FGS_PH(1);
 
-        unsigned n_slots = 0, n_flushed = 0;                                   // filled rows of the current matrix batch, pairs of earlier batches (wave-uniform)
-        auto flush = [&](const unsigned n) {
-            wave_lds_fence();
-            const float4* bp = reinterpret_cast<const float4*>(v_mine + col * kPixStride + q * 16u);
-            const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-            const unsigned slot = col & 7u;
-            const unsigned gi = s_order[wave][n_flushed + slot];
-            fgs_acc4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains: a dependent matrix instruction waits 40 cycles, an independent one 32
-            wave_mfma_16x16x4(A[0], b0.x, d0); wave_mfma_16x16x4(A[1], b0.y, d1); wave_mfma_16x16x4(A[2], b0.z, d0); wave_mfma_16x16x4(A[3], b0.w, d1);
-            wave_mfma_16x16x4(A[4], b1.x, d0); wave_mfma_16x16x4(A[5], b1.y, d1); wave_mfma_16x16x4(A[6], b1.z, d0); wave_mfma_16x16x4(A[7], b1.w, d1);
-            wave_mfma_16x16x4(A[8], b2.x, d0); wave_mfma_16x16x4(A[9], b2.y, d1); wave_mfma_16x16x4(A[10], b2.z, d0); wave_mfma_16x16x4(A[11], b2.w, d1);
-            wave_mfma_16x16x4(A[12], b3.x, d0); wave_mfma_16x16x4(A[13], b3.y, d1); wave_mfma_16x16x4(A[14], b3.z, d0); wave_mfma_16x16x4(A[15], b3.w, d1);
-            // this lane holds D[row 4 q + r][col]: rows 0..2 = colour sums (columns 0..7, the w rows), rows 3..8 = moment sums (columns 8..15, the hh rows)
-            const bool is_w = col < 8u;
-            if (slot < n) {
-                if (q == 0u) {
-                    if (is_w) {
-                        atomicAdd(&s_acc[6 * kBucket + gi], d0[0] + d1[0]); atomicAdd(&s_acc[7 * kBucket + gi], d0[1] + d1[1]);
-                        atomicAdd(&s_acc[8 * kBucket + gi], d0[2] + d1[2]);
-                    } else atomicAdd(&s_acc[gi], d0[3] + d1[3]);
-                } else if (!is_w) {
-                    if (q == 1u) {
-                        atomicAdd(&s_acc[1 * kBucket + gi], d0[0] + d1[0]); atomicAdd(&s_acc[2 * kBucket + gi], d0[1] + d1[1]);
-                        atomicAdd(&s_acc[3 * kBucket + gi], d0[2] + d1[2]); atomicAdd(&s_acc[4 * kBucket + gi], d0[3] + d1[3]);
-                    } else if (q == 2u) atomicAdd(&s_acc[5 * kBucket + gi], d0[0] + d1[0]);
+#pragma unroll 1
+        for (unsigned strip = 0; strip < static_cast<unsigned>(kTilePixels / kWave); ++strip) {
+            const unsigned ly = strip * kSubtileH + ly_in_strip;
+            const float pxf = static_cast<float>(tile_x * kTileW + lx) + 0.5f, pyf = static_cast<float>(tile_y * kTileH + ly) + 0.5f;
+            // (the strip loop stays rolled -- the walk below is long -- so the strip's six values are picked by selects, not by indexing register arrays)
+            const unsigned rel = strip == 0u ? rel_[0] : strip == 1u ? rel_[1] : rel_[2];
+            // Gaussians at or behind every pixel's last contributor take nothing (kb:412). (The maximum is wave-uniform; the compiler only knows that of
+            // a value read through v_readfirstlane, and a list it believes divergent turns the walk below into an EXEC-masked vector loop.)
+            const unsigned rel_max = wave_uniform(wave_max(rel));
+            if (rel_max == 0u) continue;                                       // no live pixel in this strip
+            const float4 g = make_float4(strip == 0u ? gx_[0] : strip == 1u ? gx_[1] : gx_[2], strip == 0u ? gy_[0] : strip == 1u ? gy_[1] : gy_[2],
+                                         strip == 0u ? gz_[0] : strip == 1u ? gz_[1] : gz_[2], 0.0f);
+            float T = strip == 0u ? T_[0] : strip == 1u ? T_[1] : T_[2], sS = strip == 0u ? S_[0] : strip == 1u ? S_[1] : S_[2];
+
+            // ---- the strip's feature matrix as matrix operand A: row c of [g_r g_g g_b 1 x' y' x'^2 x'y' y'^2], 16 k-steps ----
+            float A[16];
+            {
+                const float xr = static_cast<float>(lx) - 7.5f, yr = static_cast<float>(ly) - 5.5f;
+                v_mine[0 * kPixStride + pos] = g.x; v_mine[1 * kPixStride + pos] = g.y; v_mine[2 * kPixStride + pos] = g.z;
+                v_mine[3 * kPixStride + pos] = 1.0f; v_mine[4 * kPixStride + pos] = xr; v_mine[5 * kPixStride + pos] = yr;
+                v_mine[6 * kPixStride + pos] = xr * xr; v_mine[7 * kPixStride + pos] = xr * yr; v_mine[8 * kPixStride + pos] = yr * yr;
+                wave_lds_fence();
+                const float4* ap = reinterpret_cast<const float4*>(v_mine + min(col, 8u) * kPixStride + q * 16u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t = ap[i];
+                    const bool used = col < 9u;
+                    A[4 * i] = used ? t.x : 0.0f; A[4 * i + 1] = used ? t.y : 0.0f; A[4 * i + 2] = used ? t.z : 0.0f; A[4 * i + 3] = used ? t.w : 0.0f;
                 }
+                wave_lds_fence();                                              // the rows are reused for w / hh below
             }
-            n_flushed += n;
-            wave_lds_fence();                                                  // the next batch overwrites the rows
-        };
 
-        float* v_row = v_mine + pos;                                           // this lane's element of the row of the current slot
-#pragma unroll
-        for (unsigned word = 0; word < 2u; ++word) {                           // the forward kernel's walk (blend_forward.hip): bit-reversed 32-bit words
-            uint32_t pend = wave_uniform(__brev(static_cast<uint32_t>(word ? pending >> 32 : pending)));      // (re-stated uniform: see rel_max)
-            const uint32_t not_mine = __brev(~static_cast<uint32_t>(word ? mine >> 32 : mine));
-            const unsigned j0 = 32u * word;
-            const unsigned row0 = in_vector_register(j0 * 16u);
-            while (pend != 0) {                                                // wave-uniform scalar loop
-                const unsigned k = static_cast<unsigned>(__clz(static_cast<int>(pend)));
-                pend &= ~(0x80000000u >> k);
-                const float4* const entry = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k << 4)));
-                const float4 ga = entry[0], gb = entry[kBucket];
-                const float colb = entry[2 * kBucket].x;
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
-                const float gauss = __expf(fminf(power, 0.0f));
-                const float alpha_raw = gb.y * gauss;
-                const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha_raw));
-                // Branch-free: a pair that does not contribute (kb:412,419-421) runs the same instructions with alpha = 0, which leaves T and S as they
-                // are and gives w = hh = 0 -- the contribution block would run anyway in 92-96 % of the pairs (profiles/r04_k11_pair_efficiency.txt:
-                // some lane passes), and without it there is no EXEC bookkeeping and no zero-fill of the two values that go to the matrix rows.
-                const float alpha = tested >= gate ? alpha_raw : 0.0f;
-                const float w = T * alpha;
-                const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
-                sS -= w * cg;                                                   // kb:429 projected on dL/dC
-                const float oma = 1.0f - alpha;
-                const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
-                const float dl_dalpha = T * cg - sS * oma_rcp;                  // kb:434-436
-                const float hh = (-0.5f * alpha) * dl_dalpha;
-                T *= oma;
-                // index rel - 1 is this pixel's last contributor: from there on it takes nothing (for smaller indices the test is false, for larger ones
-                // the gate is closed already)
-                gate = j0 + k + 1u >= rel ? __builtin_inff() : gate;
-                v_row[0] = w;
-                v_row[kPixSlots * kPixStride] = hh;
+            // ---- cull the bucket against this strip's two 8x4 sub-tiles (kf:445-451) ----
+            const unsigned sub_y0 = tile_y * kTileH + strip * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
+            const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
+            bool in_l = false, in_r = false;
+            if (lane < n_here) {
+                const float4 gc = s_rec[2 * kBucket + lane];
+                const uint32_t bx = __float_as_uint(gc.y), by = __float_as_uint(gc.z);
+                const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
+                const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
+                in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
+                in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
+            }
+            const uint64_t mask_l = wave_ballot(in_l), mask_r = wave_ballot(in_r);
+            const uint64_t pending = (mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull));
+            // slot -> Gaussian of the matrix batches: the walk visits the set bits of `pending` in order, so its i-th pair is the i-th set bit
+            // (every lane stores -- the lanes outside the list into a spare element -- so that no divergent branch sits between the list and the walk)
+            s_order[((pending >> lane) & 1ull) ? lanes_below(pending) : kBucket + kPixSlots] = static_cast<uint8_t>(lane);
+            FGS_PH(2);
+
+            // ---- the walk: eight pairs into the rows, then one matrix pass. (Two other schedules were built and measured slower on the layered scene,
+            // profiles/r04_k11m_closeout.txt: the matrix instructions of batch n issued between the pairs of batch n + 1 -- 1.69 ms against 1.58 --
+            // and groups of four pairs as straight-line code for instruction-level parallelism -- 132 registers, three waves per SIMD, 1.83 ms.)
+            unsigned n_slots = 0, n_flushed = 0;                               // filled rows of the current matrix batch, pairs of earlier batches (wave-uniform)
+            auto flush = [&](const unsigned n) {
+                FGS_PH(3);
+                wave_lds_fence();
+                const float4* bp = reinterpret_cast<const float4*>(v_mine + col * kPixStride + q * 16u);
+                const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+                const unsigned slot = col & 7u;
+                const unsigned gi = s_order[n_flushed + slot];
+                fgs_acc4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains: a dependent matrix instruction waits 40 cycles, an independent one 32
+                if (!(a.ablate & 4)) {
+                    wave_mfma_16x16x4(A[0], b0.x, d0); wave_mfma_16x16x4(A[1], b0.y, d1); wave_mfma_16x16x4(A[2], b0.z, d0); wave_mfma_16x16x4(A[3], b0.w, d1);
+                    wave_mfma_16x16x4(A[4], b1.x, d0); wave_mfma_16x16x4(A[5], b1.y, d1); wave_mfma_16x16x4(A[6], b1.z, d0); wave_mfma_16x16x4(A[7], b1.w, d1);
+                    wave_mfma_16x16x4(A[8], b2.x, d0); wave_mfma_16x16x4(A[9], b2.y, d1); wave_mfma_16x16x4(A[10], b2.z, d0); wave_mfma_16x16x4(A[11], b2.w, d1);
+                    wave_mfma_16x16x4(A[12], b3.x, d0); wave_mfma_16x16x4(A[13], b3.y, d1); wave_mfma_16x16x4(A[14], b3.z, d0); wave_mfma_16x16x4(A[15], b3.w, d1);
+                }
+                // this lane holds D[row 4 q + r][col]: rows 0..2 = colour sums (columns 0..7, the w rows), rows 3..8 = moment sums (columns 8..15, the hh rows).
+                // One wave owns the accumulators, and a Gaussian sits in one slot of one pass per strip: plain read-modify-write, in program order.
+                const bool is_w = col < 8u;
+                if (slot < n && !(a.ablate & 4)) {
+                    if (q == 0u) {
+                        if (is_w) {
+                            s_acc[6 * kBucket + gi] += d0[0] + d1[0]; s_acc[7 * kBucket + gi] += d0[1] + d1[1]; s_acc[8 * kBucket + gi] += d0[2] + d1[2];
+                        } else s_acc[gi] += d0[3] + d1[3];
+                    } else if (!is_w) {
+                        if (q == 1u) {
+                            s_acc[1 * kBucket + gi] += d0[0] + d1[0]; s_acc[2 * kBucket + gi] += d0[1] + d1[1];
+                            s_acc[3 * kBucket + gi] += d0[2] + d1[2]; s_acc[4 * kBucket + gi] += d0[3] + d1[3];
+                        } else if (q == 2u) s_acc[5 * kBucket + gi] += d0[0] + d1[0];
+                    }
+                }
+                n_flushed += n;
+                wave_lds_fence();                                              // the next batch overwrites the rows
+#ifdef FGS_K11M_PHASES
+                ph_[7] += 1; ph_[6] += n;
+#endif
+                FGS_PH(4);
+            };
+
+            float* v_row = v_mine + pos;                                       // this lane's element of the row of the current slot
+            uint64_t pend = wave_uniform(pending);                             // (re-stated uniform: see rel_max)
+            while (pend != 0ull) {                                             // wave-uniform scalar loop
+                const unsigned j = static_cast<unsigned>(__ffsll(static_cast<unsigned long long>(pend))) - 1u;
+                pend &= pend - 1ull;
+                if (!(a.ablate & 8)) {
+                    const float4* const entry = s_rec + j;
+                    const float4 ga = entry[0], gb = entry[kBucket];
+                    const float colb = entry[2 * kBucket].x;
+                    const float dx = ga.x - pxf, dy = ga.y - pyf;
+                    const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                    const float gauss = __expf(fminf(power, 0.0f));
+                    const float alpha_raw = gb.y * gauss;
+                    // Contributes (kb:412,419-421; kf:445-467): alpha >= 1/255, the Gaussian in front of this pixel's last contributor, and its box on this
+                    // lane's 8x4 sub-tile -- the last one is the same for the 32 lanes of a half, so it is a scalar mask. Branch-free: a pair that does not
+                    // contribute runs the same instructions with alpha = 0, which leaves T and S as they are and gives w = hh = 0 -- the contribution block
+                    // would run anyway in 92-96 % of the pairs (profiles/r04_k11_pair_efficiency.txt: some lane passes), and there is no EXEC bookkeeping
+                    // and no zero-fill of the two values that go to the matrix rows.
+                    const uint64_t not_mine = (((mask_l >> j) & 1ull) ? 0ull : 0x00000000ffffffffull) | (((mask_r >> j) & 1ull) ? 0ull : 0xffffffff00000000ull);
+                    const uint64_t pass = wave_ballot(alpha_raw >= kMinAlphaThreshold && j < rel) & ~not_mine;
+                    const float alpha = lane_select(pass, 0.0f, alpha_raw);
+                    const float w = T * alpha;
+                    const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
+                    sS -= w * cg;                                               // kb:429 projected on dL/dC
+                    const float oma = 1.0f - alpha;
+                    const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+                    const float dl_dalpha = T * cg - sS * oma_rcp;              // kb:434-436
+                    const float hh = (-0.5f * alpha) * dl_dalpha;
+                    T *= oma;
+                    v_row[0] = w;
+                    v_row[kPixSlots * kPixStride] = hh;
+                }
                 v_row += kPixStride;
                 if (++n_slots == kPixSlots) { flush(kPixSlots); n_slots = 0; v_row = v_mine + pos; }
             }
+            if (n_slots != 0) flush(n_slots);
+            FGS_PH(3);
         }
-        if (n_slots != 0) flush(n_slots);
-        __syncthreads();
+        wave_lds_fence();
 
-        // ---- per Gaussian: moments about the tile centre -> the nine gradients, added to the planes (kb:459-470) ----
-        if (tid < n_here) {
-            const float Sh = s_acc[tid], Sx = s_acc[kBucket + tid], Sy = s_acc[2 * kBucket + tid];
-            const float Sxx = s_acc[3 * kBucket + tid], Sxy = s_acc[4 * kBucket + tid], Syy = s_acc[5 * kBucket + tid];
-            const float c0 = s_acc[6 * kBucket + tid], c1 = s_acc[7 * kBucket + tid], c2 = s_acc[8 * kBucket + tid];
+        // ---- per Gaussian (lane = Gaussian again): moments about the tile centre -> the nine gradients, added to the planes (kb:459-470) ----
+        if (lane < n_here) {
+            const float Sh = s_acc[lane], Sx = s_acc[kBucket + lane], Sy = s_acc[2 * kBucket + lane];
+            const float Sxx = s_acc[3 * kBucket + lane], Sxy = s_acc[4 * kBucket + lane], Syy = s_acc[5 * kBucket + lane];
+            const float c0 = s_acc[6 * kBucket + lane], c1 = s_acc[7 * kBucket + lane], c2 = s_acc[8 * kBucket + lane];
             const bool silent = Sh == 0.0f && Sx == 0.0f && Sy == 0.0f && Sxx == 0.0f && Sxy == 0.0f && Syy == 0.0f && c0 == 0.0f && c1 == 0.0f && c2 == 0.0f;
             if (!silent && !(a.ablate & 1)) {
-                const float4 ga = s_rec[tid], gb = s_rec[kBucket + tid], gc = s_rec[2 * kBucket + tid];
-                const uint2 meta = s_meta[tid];
+                const float4 ga = s_rec[lane], gb = s_rec[kBucket + lane], gc = s_rec[2 * kBucket + lane];
                 const float ca = ga.z, cb = ga.w, cc = gb.x, op = gb.y;
                 const float Dx = ga.x - (static_cast<float>(tile_x * kTileW) + 8.0f), Dy = ga.y - (static_cast<float>(tile_y * kTileH) + 6.0f);
                 const float a_x = Dx * Sh - Sx, a_y = Dy * Sh - Sy;
@@ -812,8 +881,8 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const
                 unsigned tx0, tx1, ty0, ty1;
                 tile_rect(__float_as_uint(gc.y), __float_as_uint(gc.z), tx0, tx1, ty0, ty1);
                 const unsigned footprint = (tx1 - tx0) * (ty1 - ty0);
-                const uint32_t hot_word = footprint > kHotFootprint ? meta.y : 0u;
-                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + meta.x;
+                const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
+                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + prim;
                 const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
                 unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
                 unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
@@ -826,9 +895,25 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_pixel_kernel(const
                 unsafeAtomicAdd(dst + 8 * plane, (flags & 4u) ? c2 : 0.0f);
             }
         }
-        __syncthreads();                                                       // the next item restages the records and clears the accumulators
+        wave_lds_fence();                                                      // the next item restages the records and clears the accumulators
+        FGS_PH(5);
     }
+#ifdef FGS_K11M_PHASES
+    if (lane == 0) for (int i = 0; i < 8; ++i) if (ph_[i] != 0) atomicAdd(&g_k11m_phases[i], ph_[i]);
+#endif
 }
+#ifdef FGS_K11M_PHASES
+}  // namespace fgs
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k11m_phases(unsigned long long* out, int reset) {
+    if (out != nullptr && hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k11m_phases), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* dev = nullptr;
+        if (hipGetSymbolAddress(&dev, HIP_SYMBOL(fgs::g_k11m_phases)) != hipSuccess || hipMemset(dev, 0, sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace fgs {
+#endif
 
 #ifdef FGS_PAIR_STATS
 }  // namespace fgs
@@ -855,6 +940,7 @@ __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendB
     if (sum != 0.0f) a.acc[(size_t)k * a.n + a.hot_list[slot]] += sum;      // one slot per primitive: no other writer at this point
 }
 
+std::atomic<int> g_k11m_max_blocks{FGS_K11M_MAX_BLOCKS};   // variant 4: upper bound of its grid (fgs_debug_set_option(13, n)); items beyond it are walked grid-stride
 std::atomic<int> g_backward_ablate{0};    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
 std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
                               // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
@@ -874,8 +960,9 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
     if (g_backward_variant == 4) {
         BlendBackwardArgs a = a_in;
         a.ablate = g_backward_ablate;
-        const unsigned blocks = a.n_buckets_cap < FGS_K11M_MAX_BLOCKS ? a.n_buckets_cap : FGS_K11M_MAX_BLOCKS;
-        hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(blocks), dim3(kTilePixels), 0, s, a);
+        const unsigned cap_blocks = static_cast<unsigned>(g_k11m_max_blocks.load());
+        const unsigned blocks = a.n_buckets_cap < cap_blocks ? a.n_buckets_cap : cap_blocks;
+        hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(blocks), dim3(kWave), 0, s, a);
         hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
         return hipGetLastError();
     }

@@ -227,6 +227,7 @@ extern std::atomic<int> g_adam_reverse;
 extern std::atomic<int> g_adam_nontemporal;                                  // 0 | 1
 extern std::atomic<int> g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
 extern std::atomic<int> g_backward_ablate;
+extern std::atomic<int> g_k11m_max_blocks;
 extern std::atomic<int> g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 

@@ -10,7 +10,9 @@ __device__ __forceinline__ unsigned lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+// (the builtin, not HIP's __ballot: that one materialises the predicate as 0 / 1 in a vector register and compares it again -- two vector
+// instructions per ballot in loops that are bound by vector issue)
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // number of set bits of m strictly below this lane
 __device__ __forceinline__ unsigned lanes_below(uint64_t m) {
@@ -46,10 +48,16 @@ __device__ __forceinline__ unsigned wave_exclusive_sum(unsigned v) { return wave
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum(v)), 63));
 }
+// maximum over the wave in every lane: the inclusive-scan idiom of wave_inclusive_sum with max (0 fills lanes without a source: the identity of an
+// unsigned maximum), then a broadcast of lane 63. (Until round 4: six ds_bpermute round trips through the LDS crossbar.)
 __device__ __forceinline__ unsigned wave_max(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
+    v = max(v, dpp_read_u<0x111 /*row_shr:1*/, 0xf>(v));
+    v = max(v, dpp_read_u<0x112 /*row_shr:2*/, 0xf>(v));
+    v = max(v, dpp_read_u<0x114 /*row_shr:4*/, 0xf>(v));
+    v = max(v, dpp_read_u<0x118 /*row_shr:8*/, 0xf>(v));
+    v = max(v, dpp_read_u<0x142 /*row_bcast:15*/, 0xa>(v));
+    v = max(v, dpp_read_u<0x143 /*row_bcast:31*/, 0xc>(v));
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
 // Sum over the 64 lanes, result valid in lane 63 only: 4 row_shr scan steps inside each 16-lane row, then row_bcast:15 /
@@ -112,6 +120,16 @@ __device__ __forceinline__ void wave_mfma_16x16x4(const float a, const float b, 
 }
 // tells the compiler that v is the same in every lane (v_readfirstlane_b32 -> a scalar register): loops and branches on it stay scalar
 __device__ __forceinline__ unsigned wave_uniform(const unsigned v) { return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ uint64_t wave_uniform(const uint64_t v) {
+    return (static_cast<uint64_t>(wave_uniform(static_cast<unsigned>(v >> 32))) << 32) | wave_uniform(static_cast<unsigned>(v));
+}
+// per lane: bit `lane` of the wave-uniform mask set ? b : a -- ONE v_cndmask_b32 with the mask as its scalar condition (what a ballot produces and
+// scalar instructions combine); written out because the compiler would shift the 64-bit mask by the lane id instead
+__device__ __forceinline__ float lane_select(const uint64_t mask, const float a, const float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
 // v (wave-uniform) into lane `lane` (wave-uniform) of `old`, the other lanes keep theirs (this compiler has no v_writelane builtin: a compare + select)
 __device__ __forceinline__ unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) {
     return lane_id() == lane ? v : old;

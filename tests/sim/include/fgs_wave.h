@@ -113,6 +113,8 @@ inline void wave_mfma_16x16x4(const float a, const float b, fgs_acc4& acc) {
     }
 }
 inline unsigned wave_uniform(const unsigned v) { return v; }
+inline uint64_t wave_uniform(const uint64_t v) { return v; }
+inline float lane_select(const uint64_t mask, const float a, const float b) { return ((mask >> lane_id()) & 1ull) ? b : a; }
 inline unsigned wave_write_lane(const unsigned old, const unsigned v, const unsigned lane) { return lane_id() == lane ? v : old; }
 inline unsigned wave_shuffle(const unsigned v, const unsigned src_lane) { return static_cast<unsigned>(sim_exchange(v, static_cast<int>(src_lane & 63u))); }
 

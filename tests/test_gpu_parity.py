@@ -128,7 +128,7 @@ def test_partial_tiles_sh_degrees_antialiasing(hip_backend, oracle, w, h, K, aa)
     assert helpers.rel_inf(dens.cpu().numpy(), dens_o) < 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant):
     """Both formulations of K11 (0 systolic lane=Gaussian, 1 strip lane=pixel) against the oracle on a deep scene."""
     p, v = make_s0(seed=11, n=1500)
@@ -156,7 +156,7 @@ def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
     gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32)
     g = oracle.backward(f, S, gi)
     truth = oracle.forward_backward_f64(f, S, gi)
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             grads = be.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
@@ -504,9 +504,36 @@ def test_async_forward_through_the_public_operators(hip_backend, oracle):
             _, grads = step()
         assert any('exceeded the capacity' in str(x.message) for x in w) and async_forward_stats()['overflows'] == 1
         assert all(float(t.abs().max()) == 0.0 for t in grads)
+        # ... and the optimizer step that would consume those zeros is SKIPPED: no step count, no motion on momentum (round-3 advisor finding)
+        from FasterGSCudaBackend import FusedAdam, take_async_overflow
+        q = torch.nn.Parameter(torch.ones(64, 3, device=DEV))
+        opt = FusedAdam([{'params': [q], 'lr': 1e-2}], lr=0.0, eps=1e-15)
+        q.grad = torch.ones_like(q)
+        opt.step()                                                               # consumes the mark: nothing happens
+        assert float((q.detach() - 1.0).abs().max()) == 0.0 and not opt.state[q] and not take_async_overflow()
+        opt.step()                                                               # the next step is an ordinary one
+        assert float((q.detach() - 1.0).abs().max()) > 0.0 and opt.state[q]['step'] == 1
         set_async_forward(True)                  # default headroom again: the refreshed ratio renders the view completely
         image, grads = step()
         assert torch.equal(image, ref_image)
+        _grads_close(grads, g)
+        # a pass that asks for gradients but never runs backward (an evaluation loop without no_grad) is checked by the next forward pass
+        set_async_forward(True, headroom=0.4)
+        P = [torch.nn.Parameter(params[k].to(DEV)) for k in helpers.NAMES]
+        truncated = diff_rasterize(*P, torch.empty(0, device=DEV), RS)
+        assert not torch.equal(truncated, ref_image) and async_forward_stats()['unchecked_passes'] == 1
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            with torch.no_grad():
+                diff_rasterize(*[params[k].to(DEV) for k in helpers.NAMES], torch.empty(0, device=DEV), RS)
+        assert any('backward never ran' in str(x.message) for x in w) and async_forward_stats()['unchecked_passes'] == 0
+        set_async_forward(True)
+        # a w2c edited in place is a NEW view (version counter), as is another tensor at a recycled address: both start synchronously
+        RS.w2c.mul_(1.0)
+        before = async_forward_stats()['views']
+        image, grads = step()
+        assert torch.equal(image, ref_image) and async_forward_stats()['views'] == before
         _grads_close(grads, g)
         # another view (another w2c tensor) starts with its own synchronous pass
         RS2 = RS._replace(w2c=RS.w2c.clone())

@@ -126,9 +126,11 @@ def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     assert (f['ranges'][:, 1] - f['ranges'][:, 0]).max() > 400
 
 
-def test_strip_backward_variant(sim_backend, oracle):
-    """The default is the systolic formulation; the strip one stays selectable and must give the same gradients."""
-    sim_backend.lib.fgs_debug_set_backward_variant(1)
+@pytest.mark.parametrize('variant', [1, 4])
+def test_strip_backward_variant(sim_backend, oracle, variant):
+    """The default is the systolic formulation; the lane = pixel ones (1: DPP reductions, 4: matrix-core reduction through an LDS transposition, the
+    matrix instruction emulated as the fmaf chain it is) stay selectable and must give the same gradients."""
+    sim_backend.lib.fgs_debug_set_backward_variant(variant)
     try:
         p, v = make_s0(seed=11, n=600)
         p['means'][:, :2] *= 0.3
@@ -145,7 +147,7 @@ def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
     p['opacities'] -= 2.5
     p['means'][:50, 2] = -10.0                      # invisible primitives: their records stay poisoned
     be = helpers.poisoned(sim_backend)
-    for variant in (2, 3):                          # the default and round 1's main form (0 / 1: on hardware, test_gpu_parity.py)
+    for variant in (2, 3, 4):                       # the default, round 1's main form and the matrix-core form (0 / 1: on hardware, test_gpu_parity.py)
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             _run(be, oracle, p, v)

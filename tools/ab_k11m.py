@@ -9,6 +9,10 @@ from harness import trainer as T
 from FasterGSCudaBackend._backend import default_backend
 be = default_backend(); dev = torch.device('cuda:0')
 variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '3,4').split(',')]
+if os.environ.get('FGS_ABLATE'):
+    assert be.lib.fgs_debug_set_option(7, int(os.environ['FGS_ABLATE'])) == 0
+if os.environ.get('FGS_K11M_BLOCKS'):
+    assert be.lib.fgs_debug_set_option(13, int(os.environ['FGS_K11M_BLOCKS'])) == 0
 
 
 def run(tag, params, views):
@@ -31,6 +35,11 @@ def run(tag, params, views):
                 be.backward(*args)
             torch.cuda.synchronize(); pr = be.profile_read(); be.profile_enable(False)
             res[var].append(pr['blend_backward'][0] / pr['blend_backward'][1])
+        if rnd == 0:       # what two runs of the SAME variant differ by (float atomics arrive in another order): the floor for the comparison below
+            be.lib.fgs_debug_set_backward_variant(variants[0])
+            again = [t.clone() for t in be.backward(torch.empty(0, device=dev), gi, fw.image, g.means, g.scales, g.rotations, g.opacities, g.sh_coefficients_rest, fw.buffers, S, fw.state)]
+            for name, a, b in zip(('means', 'scales', 'rotations', 'opacities', 'sh0', 'sh_rest'), grads[variants[0]], again):
+                worst[(f'{variants[0]} (second run)', name)] = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
         if rnd < 2 and len(variants) > 1:
             for var in variants[1:]:
                 for name, a, b in zip(('means', 'scales', 'rotations', 'opacities', 'sh0', 'sh_rest'), grads[variants[0]], grads[var]):
