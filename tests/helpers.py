@@ -169,7 +169,12 @@ def elementwise_fraction(a: np.ndarray, ref: np.ndarray, keep: np.ndarray | None
     return value
 
 
-THREE_WAY_FACTOR = 1.25     # the HIP path may miss the element-wise bar (against the fp64 evaluation) at most this often relative to the fp32 oracle; measured on MI355X: 0.98-1.03 at every site (profiles/r03_gpu_tolerance_slack.txt)
+# The HIP path may miss the element-wise bar (against the fp64 evaluation) at most this often relative to the fp32 oracle. Measured on MI355X:
+# 0.98-1.03 at every site with >= 60 k Gaussians (profiles/r03_gpu_tolerance_slack.txt), so those are held to 1.10 (round 4); the small scenes, where the
+# counts are a handful of entries, keep 1.25 beside their 4-sigma term.
+THREE_WAY_FACTOR = 1.25
+THREE_WAY_FACTOR_LARGE = 1.10
+LARGE_SCENE_ROWS = 60_000
 
 
 def elementwise_three_way(a, ref32, truth, keep: np.ndarray | None = None, kind: str = '', free_rows: int = 0):
@@ -189,6 +194,7 @@ def elementwise_three_way(a, ref32, truth, keep: np.ndarray | None = None, kind:
 
 
 def three_way_ok(frac_hip: float, frac_oracle: float, n: int, cluster: int = 1) -> bool:
+    # n / cluster = rows (Gaussians, or pixels for an image) of the compared tensor: LARGE_SCENE_ROWS and more -> the tighter factor
     """frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION, plus four standard deviations of a count of n * frac_oracle entries
     (the two fp32 roundings are independent: on a 900-entry tensor 'the oracle misses 3, the HIP path 5' is noise, not a finding). Four, not
     three: the suite applies this to ~1500 tensors and a wide fuzz sweep to 1200 more, and a 3-sigma bar fires once in 740 on pure noise --
@@ -197,7 +203,9 @@ def three_way_ok(frac_hip: float, frac_oracle: float, n: int, cluster: int = 1) 
     # the count fluctuates like n / cluster independent events of `cluster` entries each (seed 411 of the sweep: 10 entries = 3-4 Gaussians
     # of 480 against 2 entries = 1 Gaussian, every max-norm error below 4e-6)
     sigma = (cluster * max(frac_oracle, float(cluster) / max(n, 1)) / max(n, 1)) ** 0.5
-    return frac_hip <= THREE_WAY_FACTOR * frac_oracle + ELEM_FRACTION + 4.0 * sigma
+    factor = THREE_WAY_FACTOR_LARGE if n // max(cluster, 1) >= LARGE_SCENE_ROWS else THREE_WAY_FACTOR
+    log_note('three_way_ratio', f'{(frac_hip / frac_oracle if frac_oracle > 0 else 0.0):.3f}', factor=factor, rows=n // max(cluster, 1), frac_hip=f'{frac_hip:.3e}', frac_oracle=f'{frac_oracle:.3e}')
+    return frac_hip <= factor * frac_oracle + ELEM_FRACTION + 4.0 * sigma
 
 
 def outlier_fraction(a: np.ndarray, ref: np.ndarray, rtol: float, atol: float) -> float:
@@ -339,6 +347,8 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
     pm = masks['pixel']
     frac_p, frac_g = float(pm.mean()), float(masks['prim'].mean()) if masks['prim'].size else 0.0
     report['masked_pixels'], report['masked_gaussians'] = frac_p, frac_g
+    log_note('masked_fraction', f'{max(frac_p, frac_g):.3e}', label=label.replace(' ', '_'), pixels=f'{frac_p:.3e}', gaussians=f'{frac_g:.3e}', bound=max_masked,
+             near=f'{float(masks["near"].mean()) if "near" in masks and masks["near"].size else 0.0:.3e}')
     assert frac_p < max_masked and frac_g < max_masked, (label, 'masked fraction', frac_p, frac_g)
     if image is not None:
         err = np.abs(np.asarray(image, np.float64) - f_image).max(axis=0)

@@ -34,7 +34,9 @@ def _to(params, dev=None):
 def _grads_close(grads, g, tol=1e-4, truth=None, free_rows=2):
     """Max-norm 1e-4 per tensor; with `truth` (oracle.forward_backward_f64 of the same scene) also the element-wise 1e-4 bar, three-way
     (helpers.elementwise_three_way). These scenes are compared without the oracle's threshold-risk mask, so up to `free_rows` Gaussians
-    (one alpha-test flip) may exceed the element-wise bar."""
+    (one alpha-test flip) may exceed the element-wise bar -- on the small scenes only: from 60 k Gaussians on nothing is free (round 4)."""
+    if g[helpers.GRAD_KEYS[0]].shape[0] >= helpers.LARGE_SCENE_ROWS:
+        free_rows = 0
     for k, t in zip(helpers.GRAD_KEYS, grads):
         a = t.detach().cpu().numpy().reshape(g[k].shape)
         e = helpers.rel_inf(a, g[k])

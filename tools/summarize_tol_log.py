@@ -11,11 +11,21 @@ path = sys.argv[1]
 maxnorm = collections.defaultdict(lambda: [0, 0.0, 0.0])
 elem = collections.defaultdict(lambda: collections.defaultdict(list))
 notes = collections.Counter()
+masked, ratios = [], {}
 for line in open(path):
     m = re.match(r'(\S+) (\S+) (\w+)=(\S+)(.*)', line)
     if not m:
         continue
     site, fn, kind, val, rest = m.groups()
+    if kind == 'masked_fraction':
+        masked.append((fn, val, rest.strip()))
+        continue
+    if kind == 'three_way_ratio':
+        rows = re.search(r"'rows': (\d+)", rest); fac = re.search(r"'factor': ([\d.]+)", rest); fo = re.search(r"'frac_oracle': '([^']+)'", rest)
+        if rows and fac and fo and float(fo.group(1)) > 1e-3:
+            key = (fn, 'rows >= 60 k (factor 1.10)' if int(rows.group(1)) >= 60000 else 'smaller scenes (factor 1.25)')
+            ratios[key] = max(ratios.get(key, 0.0), float(val))
+        continue
     if kind == 'int_mismatch_primitives':
         notes[(site, fn, 'budget branch taken' if int(val) else 'no integer mismatch')] += 1
         continue
@@ -49,7 +59,7 @@ print(f'# sites above 1e-4: {above} of {len(maxnorm)}')
 print()
 print('# (2) element-wise: fraction of entries with |a - x| > 1e-4 |x| + 1e-4 median|x| (helpers.elementwise_fraction), outside the oracle\'s')
 print('#     threshold-risk masks. x = the fp64 evaluation of the same formulas (oracle.forward_backward_f64). The fp32 oracle itself misses this')
-print('#     bar wherever a gradient entry is an ill-conditioned sum; the assert is HIP <= 1.25 x oracle32 + 1e-4 (+ 3 sigma of the count).')
+print('#     bar wherever a gradient entry is an ill-conditioned sum; the assert is HIP <= f x oracle32 + 1e-4 (+ 4 sigma of the count), f = 1.10 from 60 k rows on, 1.25 below.')
 print(f'{"site":26s} {"tensor":20s} {"entries":>10s}  {"HIP vs fp64":>12s}  {"oracle32 vs fp64":>16s}  {"ratio":>6s}  {"HIP vs oracle32":>15s}')
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0.0])
 for (site, fn, tensor, n), d in sorted(elem.items()):
@@ -72,3 +82,12 @@ print()
 print('# (3) integer intermediates of _forward_check (screen bounds / tile counts vs the oracle): how often the libm-ULP budget branch is taken')
 for (site, fn, what), c in sorted(notes.items()):
     print(f'{site:32s} {fn:40s} {what:24s} {c}')
+print()
+print('# (4) threshold-risk masks of the flip-aware comparisons: realised masked fraction per call (pixels / Gaussians excluded from the 1e-4 bars), its bound,')
+print('#     and the share of Gaussians in the looser "near" class (adversarial fuzz scenes only)')
+for fn, val, rest in masked:
+    print(f'{fn:48s} masked {val:>10s}   {rest}')
+print()
+print('# (5) worst HIP / oracle32 miss ratio of the three-way rule per test function (calls where the oracle misses more than 1e-3 of the entries)')
+for (fn, cls), r in sorted(ratios.items()):
+    print(f'{fn:48s} {cls:32s} {r:6.3f}')
