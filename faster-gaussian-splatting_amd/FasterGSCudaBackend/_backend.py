@@ -323,7 +323,9 @@ class Backend:
         return buffers[0]
 
     def forward_from_records(self, records: torch.Tensor, n_records: int, n_instances: int, settings: RasterizerSettings,
-                             total_sh_rest: int) -> ForwardResult:
+                             total_sh_rest: int, shard_counts: Sequence[int] | None = None) -> ForwardResult:
+        """`shard_counts`: the records are the concatenation of that many records per shard; the renderer then places them interleaved (Morton
+        neighbourhood of strided owners restored, include/fgs_hip.h). Pass the same counts to `backward_to_records`."""
         device = records.device
         if records.dtype != torch.uint8 or not records.is_contiguous() or records.numel() < n_records * _lib.SPLAT_RECORD_BYTES:
             raise RuntimeError('records must be a contiguous uint8 tensor of n_records * 56 bytes')
@@ -332,12 +334,13 @@ class Backend:
         image = torch.empty((3, settings.height, settings.width), dtype=torch.float32, device=device)
         buffers, cb = self._make_resizer(device, 4)
         st = _lib.ForwardState()
-        self._check(self.lib.fgs_forward_from_records(_ptr(records), int(n_records), int(n_instances), C.byref(S), image.data_ptr(), cb, None,
-                                                      C.byref(st), _stream_of(device)), 'fgs_forward_from_records')
+        counts = (C.c_int32 * len(shard_counts))(*[int(c) for c in shard_counts]) if shard_counts else None
+        self._check(self.lib.fgs_forward_from_shard_records(_ptr(records), int(n_records), int(n_instances), counts, len(shard_counts) if shard_counts else 0,
+                                                            C.byref(S), image.data_ptr(), cb, None, C.byref(st), _stream_of(device)), 'fgs_forward_from_shard_records')
         return ForwardResult(image, tuple(buffers), (st.n_visible, st.n_instances, st.n_buckets, st.selector))
 
     def backward_to_records(self, grad_image, image, buffers, settings: RasterizerSettings, state, total_sh_rest: int,
-                            out: torch.Tensor | None = None) -> torch.Tensor:
+                            out: torch.Tensor | None = None, shard_counts: Sequence[int] | None = None) -> torch.Tensor:
         """K11 of a view rendered by `forward_from_records` -> float32 [n_records, 9] accumulator records."""
         device = image.device
         n = int(state[0])
@@ -349,9 +352,10 @@ class Backend:
             raise RuntimeError('accumulator records must be contiguous float32 [n_records, 9]')
         scratch = self._scratch(n, settings, device)
         st = _lib.ForwardState(*state)
-        self._check(self.lib.fgs_backward_to_records(_ptr(grad_image), _ptr(image), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]),
-                                                     _ptr(buffers[3]), scratch.data_ptr(), _ptr(acc), n, C.byref(S), C.byref(st),
-                                                     _stream_of(device)), 'fgs_backward_to_records')
+        counts = (C.c_int32 * len(shard_counts))(*[int(c) for c in shard_counts]) if shard_counts else None
+        self._check(self.lib.fgs_backward_to_shard_records(_ptr(grad_image), _ptr(image), _ptr(buffers[0]), _ptr(buffers[1]), _ptr(buffers[2]),
+                                                           _ptr(buffers[3]), scratch.data_ptr(), _ptr(acc), n, counts, len(shard_counts) if shard_counts else 0,
+                                                           C.byref(S), C.byref(st), _stream_of(device)), 'fgs_backward_to_shard_records')
         return acc
 
     def shard_backward(self, acc_records: torch.Tensor, n_visible: Sequence[int], primitive_buffer: torch.Tensor, densification_info, means,

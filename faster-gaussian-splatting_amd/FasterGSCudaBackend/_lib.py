@@ -68,6 +68,8 @@ _SIGNATURES = {
     'fgs_shard_preprocess': (C.c_int32, [_P] * 6 + [_I32, _I32, C.POINTER(Settings), _P, _P, RESIZE_FN, _P, _P]),
     'fgs_forward_from_records': (C.c_int32, [_P, _I32, _I32, C.POINTER(Settings), _P, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
     'fgs_backward_to_records': (C.c_int32, [_P] * 2 + [_P] * 4 + [_P, _P, _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
+    'fgs_forward_from_shard_records': (C.c_int32, [_P, _I32, _I32, C.POINTER(_I32), _I32, C.POINTER(Settings), _P, RESIZE_FN, _P, C.POINTER(ForwardState), _P]),
+    'fgs_backward_to_shard_records': (C.c_int32, [_P] * 2 + [_P] * 4 + [_P, _P, _I32, C.POINTER(_I32), _I32, C.POINTER(Settings), C.POINTER(ForwardState), _P]),
     'fgs_shard_backward_scratch_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_shard_backward': (C.c_int32, [_P, C.POINTER(_I32), _P] + [_P] * 5 + [_P] * 6 + [_P, _P, _I32, _I32, C.POINTER(Settings), _P]),
     'fgs_shard_backward_adam_fused': (C.c_int32, [_P, C.POINTER(_I32), _P] + [C.POINTER(_P)] * 3 + [_P, _P, _I32, _I32, C.POINTER(Settings), _I32,

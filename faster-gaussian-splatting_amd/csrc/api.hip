@@ -638,9 +638,33 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
     return FGS_OK;
 }
 
+// records of the shards, concatenated -> ShardOrder (nullptr / fewer than two segments / more than kMaxBatchViews: the order as received)
+static int shard_order_of(ShardOrder& order, const int32_t* shard_counts, int32_t n_shards, int32_t n_records) {
+    order = ShardOrder{};
+    if (!shard_counts || n_shards <= 1) return FGS_OK;
+    int64_t total = 0;
+    for (int32_t k = 0; k < n_shards; ++k) {
+        if (shard_counts[k] < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "shard_counts[%d] = %d", k, shard_counts[k]);
+        total += shard_counts[k];
+    }
+    if (total != n_records) return fail(FGS_ERR_INVALID_ARGUMENT, "shard_counts sum to %lld, n_records = %d", static_cast<long long>(total), n_records);
+    if (n_shards > kMaxBatchViews) return FGS_OK;
+    order.n_shards = n_shards;
+    for (int32_t k = 0; k < n_shards; ++k) order.count[k] = static_cast<uint32_t>(shard_counts[k]);
+    return FGS_OK;
+}
+
 int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t n_instances, const fgs_settings* settings, float* image,
                                  fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream_) {
+    return fgs_forward_from_shard_records(records, n_records, n_instances, nullptr, 0, settings, image, resize, resize_user, state_out, stream_);
+}
+
+int32_t fgs_forward_from_shard_records(const void* records, int32_t n_records, int32_t n_instances, const int32_t* shard_counts, int32_t n_shards,
+                                       const fgs_settings* settings, float* image, fgs_resize_fn resize, void* resize_user,
+                                       fgs_forward_state* state_out, void* stream_) {
     if (int rc = check_settings(settings)) return rc;
+    ShardOrder order;
+    if (int rc = shard_order_of(order, shard_counts, n_shards, n_records)) return rc;
     if (n_records < 0 || n_instances < 0 || !image || !resize || !state_out || (n_records > 0 && !records))
         return fail(FGS_ERR_INVALID_ARGUMENT, "bad argument (n_records=%d, n_instances=%d)", n_records, n_instances);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -660,7 +684,7 @@ int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
     FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
-      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, stream)); }
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, order, stream)); }
     return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
@@ -668,6 +692,16 @@ int32_t fgs_backward_to_records(const float* grad_image, const float* image,
                                 void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
                                 void* scratch, float* acc_records_out, int32_t n_records,
                                 const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
+    return fgs_backward_to_shard_records(grad_image, image, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, acc_records_out,
+                                         n_records, nullptr, 0, settings, state, stream_);
+}
+
+int32_t fgs_backward_to_shard_records(const float* grad_image, const float* image,
+                                      void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                      void* scratch, float* acc_records_out, int32_t n_records, const int32_t* shard_counts, int32_t n_shards,
+                                      const fgs_settings* settings, const fgs_forward_state* state, void* stream_) {
+    ShardOrder order;
+    if (int rc = shard_order_of(order, shard_counts, n_shards, n_records)) return rc;
     BackwardPlan P;
     if (int rc = plan_backward(P, primitive_buffers, tile_buffers, instance_buffers, bucket_buffers, scratch, n_records, settings, state)) return rc;
     if (!grad_image || !image) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL image / grad_image");
@@ -675,7 +709,7 @@ int32_t fgs_backward_to_records(const float* grad_image, const float* image,
     if (!acc_records_out) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL acc_records_out");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream)) return rc;
-    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), acc_records_out, stream)); }
+    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), acc_records_out, order, stream)); }
     return FGS_OK;
 }
 

@@ -184,9 +184,12 @@ struct PackRecordsView { const PrimRec* rec; const uint32_t* n_touched; const ui
                          const uint32_t* counters; uint32_t* slot; uint32_t* out; uint32_t* counts_out; };
 struct PackRecordsBatch { int n_views; uint32_t capacity; PackRecordsView v[kMaxBatchViews]; };
 hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
+// how the renderer's record concatenation is made of the shards' segments (n_shards <= 1: the records keep their order)
+struct ShardOrder { int n_shards; uint32_t count[kMaxBatchViews]; };
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, hipStream_t s);
-hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s);
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
+                                       hipStream_t s);
+hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, const ShardOrder& order, hipStream_t s);
 
 // aux_ops.hip: the reference's remaining exported operators
 hipError_t launch_update_3d_filter(const float* positions, const float* w2c, float* filter_3d, uint8_t* visibility_mask, int n,

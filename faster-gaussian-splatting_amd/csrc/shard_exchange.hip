@@ -45,17 +45,76 @@ __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecor
     o[6] = make_uint2(w.depth_keys[j], w.n_touched[i]);
 }
 
+// Where does record j of the concatenation (all of shard 0, then shard 1, ...) go on the renderer? Owners hold the Gaussians r, r + G, r + 2 G ... of a
+// Morton-ordered scene, so the shard-major concatenation puts Morton neighbours -- Gaussians of the same tiles -- V / G records apart, and K11 on it
+// measured 0.508 ms against 0.433 in memory order (S2, G = 8, one GPU, profiles/r04_ab_sharded_order.txt). The renderer therefore INTERLEAVES the
+// shards again, inside the two passes it runs anyway (this unpack, and pack_acc on the way back): record with rank r in shard s goes to primitive
+// slot sum_s' min(count[s'], r + [s' < s]) -- r G + s when all shards sent the same number, and a bijection onto 0..n-1 for any counts.
+__device__ __forceinline__ uint32_t renderer_slot(const uint32_t j, const ShardOrder& o) {
+    if (o.n_shards <= 1) return j;
+    uint32_t s = 0, first = 0, end = 0;                                      // shard of record j = number of segments that end at or before j
+#pragma unroll
+    for (int k = 0; k < kMaxBatchViews; ++k) {
+        if (k < o.n_shards) {
+            end += o.count[k];
+            if (j >= end) { s = static_cast<uint32_t>(k) + 1u; first = end; }
+        }
+    }
+    const uint32_t r = j - first;
+    uint32_t dst = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBatchViews; ++k)
+        if (k < o.n_shards) dst += min(o.count[k], r + (static_cast<uint32_t>(k) < s ? 1u : 0u));
+    return dst;
+}
+
+// The inverse: which record of the concatenation becomes primitive slot d? Ranks below r fill f(r) = sum_s' min(count[s'], r) slots (monotone in r):
+// r = the largest rank with f(r) <= d (binary search, 8 terms per probe), and the shard is the (d - f(r))-th of those that have a record of rank r.
+// Both passes are written per SLOT (thread = slot: coalesced accesses to the renderer's arrays, and lanes 8 apart touch consecutive records of one
+// shard's segment): per record they measured 0.090 ms for the two passes against 0.040 as received -- more than K11 gained.
+__device__ __forceinline__ uint32_t record_of_slot(const uint32_t d, const ShardOrder& o) {
+    if (o.n_shards <= 1) return d;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBatchViews; ++k) if (k < o.n_shards) hi = max(hi, o.count[k]);
+    while (lo < hi) {                                                          // largest r in [0, max count] with f(r) <= d
+        const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+        uint32_t f = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxBatchViews; ++k) if (k < o.n_shards) f += min(o.count[k], mid);
+        if (f <= d) lo = mid; else hi = mid - 1u;
+    }
+    const uint32_t r = lo;
+    uint32_t f = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBatchViews; ++k) if (k < o.n_shards) f += min(o.count[k], r);
+    uint32_t left = d - f, first = 0, j = 0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < kMaxBatchViews; ++k) {
+        if (k < o.n_shards) {
+            if (!found && o.count[k] > r) {
+                if (left == 0u) { j = first + r; found = true; }
+                else --left;
+            }
+            first += o.count[k];
+        }
+    }
+    return j;
+}
+
 // Renderer side: the concatenated records of all shards become primitives 0..n-1 of a pipeline that starts at K2.
 // Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
 __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, PrimRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
                                                                    uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles,
-                                                                   uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t t = j; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
-    const bool in_range = j < n;
+                                                                   uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count, const ShardOrder order) {
+    const uint32_t dst = blockIdx.x * 256u + threadIdx.x;                     // thread = primitive slot; its record is gathered
+    for (uint32_t t = dst; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+    const bool in_range = dst < n;
     uint2 w0{}, w1{}, w2{}, w3{}, w4{}, w5{}, w6{};
     if (in_range) {
+        const uint32_t j = record_of_slot(dst, order);
         const uint2* m = reinterpret_cast<const uint2*>(records + (size_t)kSplatRecordWords * j);
         w0 = m[0]; w1 = m[1]; w2 = m[2]; w3 = m[3]; w4 = m[4]; w5 = m[5]; w6 = m[6];
     }
@@ -73,23 +132,25 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
         if (lane == static_cast<unsigned>(leader)) base = atomicAdd(hot_count, static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hot_mask))));
         base = wave_read(base, leader);
         const unsigned slot = base + lanes_below(hot_mask);
-        if (hot && slot < kMaxHot) { hot_list[slot] = j; slot_word = slot + 1u; }
+        if (hot && slot < kMaxHot) { hot_list[slot] = dst; slot_word = slot + 1u; }
     }
     if (!in_range) return;
-    uint4* r = reinterpret_cast<uint4*>(rec + j);
+    uint4* r = reinterpret_cast<uint4*>(rec + dst);
     r[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
     r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
     r[2] = make_uint4(w4.x, w4.y, w5.x, slot_word);
-    depth_keys[j] = w6.x; prim_idx[j] = j; n_touched[j] = w6.y;
+    depth_keys[dst] = w6.x; prim_idx[dst] = dst; n_touched[dst] = w6.y;   // the visible list in slot order: equal depth keys keep that order through the stable sort
 }
 
-// planar accumulators [9][n] (what K11 adds into) -> one 36-byte record per record j, ready to be cut into per-shard segments
-__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, float* __restrict__ out) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= n) return;
+// planar accumulators [9][n] (what K11 adds into, by primitive slot) -> one 36-byte record per record j of the concatenation, ready to be cut into
+// per-shard segments
+__global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, float* __restrict__ out, const ShardOrder order) {
+    const uint32_t src = blockIdx.x * 256u + threadIdx.x;                     // thread = primitive slot: coalesced plane reads, the record is scattered
+    if (src >= n) return;
+    const uint32_t j = record_of_slot(src, order);
     float v[kAccRecordWords];
 #pragma unroll
-    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n + j];
+    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n + src];
 #pragma unroll
     for (int k = 0; k < kAccRecordWords; ++k) out[(size_t)kAccRecordWords * j + k] = v[k];
 }
@@ -102,15 +163,16 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
 }
 
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, hipStream_t s) {
+                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
+                                       hipStream_t s) {
     const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count, order);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, hipStream_t s) {
+hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, const ShardOrder& order, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, n, out);
+    hipLaunchKernelGGL(pack_acc_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, acc, n, out, order);
     return hipGetLastError();
 }
 

@@ -34,6 +34,9 @@ from FasterGSCudaBackend._backend import Backend, RasterizerSettings
 from .distributed import SEGMENTS, _ALIGN, _BACKWARD_ORDER, l1_grad
 
 
+INTERLEAVE_SHARDS = True      # A/B switch (tools/ab_sharded_order.py, tests): False = the renderer keeps the records in the order they arrive
+
+
 def shard_of(params: dict, rank: int, world: int) -> dict:
     """Strided ownership: every shard sees the same spatial distribution, so the per-(shard, view) record counts -- the
     all-to-all message sizes -- are balanced whatever the memory order (Morton, Model.py:357-366) of the scene."""
@@ -158,11 +161,15 @@ class ShardedTrainer:
         tensors = (p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_0'], p['sh_coefficients_rest'])
         return self.be.shard_preprocess(*tensors, views, self.records, self.counts)
 
-    def render(self, records: torch.Tensor, n_instances: int, view: RasterizerSettings, target: torch.Tensor):
-        """Phase B (renderer of `view`): K2..K10, loss gradient, K11 -> (image, accumulator records [n_records, 9])."""
-        res = self.be.forward_from_records(records.view(-1), records.shape[0], n_instances, view, self.total_sh_rest)
+    def render(self, records: torch.Tensor, n_instances: int, view: RasterizerSettings, target: torch.Tensor, shard_counts: Sequence[int] | None = None):
+        """Phase B (renderer of `view`): K2..K10, loss gradient, K11 -> (image, accumulator records [n_records, 9]). `shard_counts`: how many of the
+        records each shard sent (in concatenation order): the renderer interleaves them, which gives K11 back the locality of the scene's Morton
+        order (profiles/r04_ab_sharded_order.txt); the accumulator records still come out in the order the records came in."""
+        if not INTERLEAVE_SHARDS:
+            shard_counts = None
+        res = self.be.forward_from_records(records.view(-1), records.shape[0], n_instances, view, self.total_sh_rest, shard_counts=shard_counts)
         grad_image = self.image_gradient(res.image, target)
-        acc = self.be.backward_to_records(grad_image, res.image, res.buffers, view, res.state, self.total_sh_rest)
+        acc = self.be.backward_to_records(grad_image, res.image, res.buffers, view, res.state, self.total_sh_rest, shard_counts=shard_counts)
         return res.image, acc
 
     def finish(self, views: Sequence[RasterizerSettings], prim: torch.Tensor, acc_back: torch.Tensor, sent: Sequence[int],
@@ -197,7 +204,7 @@ class ShardedTrainer:
         sent = [int(table[r, v, 0]) for v in range(G)]                      # my records per view
         got = [int(table[s, r, 0]) for s in range(G)]                       # records of my view per shard
         records = self._all_to_all([self.records[v, :sent[v]] for v in range(G)], got)
-        image, acc = self.render(records, int(table[:, r, 1].sum()), views[r], target)
+        image, acc = self.render(records, int(table[:, r, 1].sum()), views[r], target, shard_counts=got if self.strided else None)
         offs = [0]
         for c in got:
             offs.append(offs[-1] + c)
@@ -296,7 +303,8 @@ class LocalShardGroup:
         images, accs = [], []
         for v in range(G):
             records = torch.cat([self.ranks[s].records[v, :int(table[s, v, 0])] for s in range(G)], dim=0)
-            image, acc = self.ranks[v].render(records, int(table[:, v, 1].sum()), views[v], targets[v])
+            image, acc = self.ranks[v].render(records, int(table[:, v, 1].sum()), views[v], targets[v],
+                                              shard_counts=[int(table[s, v, 0]) for s in range(G)] if all(t.strided for t in self.ranks) else None)
             images.append(image)
             accs.append(acc)
         for s in range(G):

@@ -190,12 +190,26 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
 int32_t fgs_forward_from_records(const void* records, int32_t n_records, int32_t n_instances, const fgs_settings* settings,
                                  float* image, fgs_resize_fn resize, void* resize_user, fgs_forward_state* state_out, void* stream);
 
+/* The same for records that are the concatenation of n_shards segments (shard_counts[s] records of shard 0, 1, ...: [host] array): the renderer
+ * places them interleaved -- rank r of shard s becomes primitive sum_s' min(count[s'], r + [s' < s]) -- which restores the Morton neighbourhood of
+ * owners that hold every n_shards-th Gaussian (K11: 0.51 -> 0.43 ms at 3 M Gaussians, 8 shards). Results are those of fgs_forward_from_records up to
+ * the summation order of K11's atomics. More than 8 segments, or NULL: as received. Pair with fgs_backward_to_shard_records and the SAME counts. */
+int32_t fgs_forward_from_shard_records(const void* records, int32_t n_records, int32_t n_instances, const int32_t* shard_counts, int32_t n_shards,
+                                       const fgs_settings* settings, float* image, fgs_resize_fn resize, void* resize_user,
+                                       fgs_forward_state* state_out, void* stream);
+
 /* K11 over the buffers of fgs_forward_from_records; acc_records_out[n_records] (36 bytes each, record order).
  * scratch: fgs_backward_scratch_bytes(n_records, width, height). */
 int32_t fgs_backward_to_records(const float* grad_image, const float* image,
                                 void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
                                 void* scratch, float* acc_records_out, int32_t n_records,
                                 const fgs_settings* settings, const fgs_forward_state* state, void* stream);
+
+/* ... over the buffers of fgs_forward_from_shard_records (same shard_counts): the accumulator records come out in the order the records came in. */
+int32_t fgs_backward_to_shard_records(const float* grad_image, const float* image,
+                                      void* primitive_buffers, void* tile_buffers, void* instance_buffers, void* bucket_buffers,
+                                      void* scratch, float* acc_records_out, int32_t n_records, const int32_t* shard_counts, int32_t n_shards,
+                                      const fgs_settings* settings, const fgs_forward_state* state, void* stream);
 
 /* K12 on the shard for all views of the step: acc_records = the accumulator records returned for the records of
  * fgs_shard_preprocess, concatenated in view order (n_visible[v] records for view v, [host] array; same order as they
