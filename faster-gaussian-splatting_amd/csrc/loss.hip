@@ -82,9 +82,12 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
         const int item = threadIdx.x + it * 256;
         if (item < kItems) {
             const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
-            float p[14], q[14];
+            float p[14], q[14], p2[14], q2[14], pq[14];
 #pragma unroll
             for (int t = 0; t < 14; ++t) { p[t] = sxy[0][ry][cx + t]; q[t] = sxy[1][ry][cx + t]; }
+            // the three products once per staged value, not once per (output, tap): 42 multiplications instead of 132 per work item (round 4)
+#pragma unroll
+            for (int t = 0; t < 14; ++t) { p2[t] = p[t] * p[t]; q2[t] = q[t] * q[t]; pq[t] = p[t] * q[t]; }
             const int gy = y0 + ry - kHalo;
             const bool own_row = ry >= kHalo && ry < kHalo + kLossTileH && gy < a.height;
 #pragma unroll
@@ -92,8 +95,8 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
                 float m1 = 0.0f, m2 = 0.0f, m11 = 0.0f, m22 = 0.0f, m12 = 0.0f;
 #pragma unroll
                 for (int t = 0; t < kTaps; ++t) {
-                    const float w = gw.w[t], pp = p[o + t], qq = q[o + t];
-                    m1 += w * pp; m2 += w * qq; m11 += w * pp * pp; m22 += w * qq * qq; m12 += w * pp * qq;
+                    const float w = gw.w[t];
+                    m1 += w * p[o + t]; m2 += w * q[o + t]; m11 += w * p2[o + t]; m22 += w * q2[o + t]; m12 += w * pq[o + t];
                 }
                 hz4[0][ry][cx + o] = m1; hz4[1][ry][cx + o] = m2; hz4[2][ry][cx + o] = m11; hz4[3][ry][cx + o] = m22;
                 keep[it][o] = m12;
@@ -170,25 +173,43 @@ __global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, cons
     }
 }
 
+// The backward pass has its own tile (round 4): it stages three maps instead of two and keeps three filtered maps instead of five, so a 64 x 32 tile
+// (halo re-reads 1.38x instead of 1.72x: rocprofv3 round 3 had this kernel fetching 3.7x its input) fits in the LDS budget that limits the forward
+// kernel to 32 x 32 (FGS_LOSS_BWD_TILE_W / _H: A/B knobs).
+#ifndef FGS_LOSS_BWD_TILE_W
+#define FGS_LOSS_BWD_TILE_W 64
+#define FGS_LOSS_BWD_TILE_H 32
+#endif
+constexpr int kBwdTileW = FGS_LOSS_BWD_TILE_W, kBwdTileH = FGS_LOSS_BWD_TILE_H;
+constexpr int kBwdRegionW = kBwdTileW + 2 * kHalo, kBwdRegionH = kBwdTileH + 2 * kHalo;
+constexpr int kBwdRows = (kBwdTileW * kBwdTileH) / 256;                               // thread = one output column x kBwdRows consecutive rows
+constexpr int kBwdHzGroups = kBwdTileW / 4;
+static_assert(kBwdTileW * (kBwdTileH / kBwdRows) == 256 && kBwdTileW % 4 == 0, "one (column, row strip) per thread");
+
 __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, const GaussWindow gw) {
-    // The horizontally filtered maps go back into the memory of the staged region (dead once every thread has read its inputs into
-    // registers): 21.2 KB per workgroup instead of 37.3 -- six workgroups per CU (register-limited) instead of four.
-    constexpr int kMapFloats = kRegionH * kLossTileW;
-    static_assert(3 * kRegionH * kRegionW >= 3 * kMapFloats, "the three filtered maps fit in the staged region");
-    __shared__ float sd[3][kRegionH][kRegionW];
-    float (*const hz)[kRegionH][kLossTileW] = reinterpret_cast<float (*)[kRegionH][kLossTileW]>(&sd[0][0][0]);
-    const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
+    // The horizontally filtered maps go back into the memory of the staged region (dead once every thread has read its inputs into registers).
+    constexpr int kMapFloats = kBwdRegionH * kBwdTileW;
+    static_assert(3 * kBwdRegionH * kBwdRegionW >= 3 * kMapFloats, "the three filtered maps fit in the staged region");
+    __shared__ float sd[3][kBwdRegionH][kBwdRegionW];
+    float (*const hz)[kBwdRegionH][kBwdTileW] = reinterpret_cast<float (*)[kBwdRegionH][kBwdTileW]>(&sd[0][0][0]);
+    const int x0 = blockIdx.x * kBwdTileW, y0 = blockIdx.y * kBwdTileH, c = blockIdx.z;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ m0 = a.d_mu + c * plane; const float* __restrict__ m1 = a.d_m11 + c * plane; const float* __restrict__ m2 = a.d_m12 + c * plane;
-    stage_region<3>(sd, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? m0[e] : (k == 1 ? m1[e] : m2[e]); });
+    for (int idx = threadIdx.x; idx < kBwdRegionH * kBwdRegionW; idx += 256) {       // flat index: every lane loads (division by a constant)
+        const int ry = idx / kBwdRegionW, rx = idx - ry * kBwdRegionW;
+        const int gy = y0 + ry - kHalo, gx = x0 + rx - kHalo;
+        const bool in = gy >= 0 && gy < a.height && gx >= 0 && gx < a.width;         // zero padding
+        const size_t e = (size_t)gy * a.width + gx;
+        sd[0][ry][rx] = in ? m0[e] : 0.0f; sd[1][ry][rx] = in ? m1[e] : 0.0f; sd[2][ry][rx] = in ? m2[e] : 0.0f;
+    }
     __syncthreads();
-    constexpr int kItems = kRegionH * kHzGroups, kItemsPerThread = (kItems + 255) / 256;
+    constexpr int kItems = kBwdRegionH * kBwdHzGroups, kItemsPerThread = (kItems + 255) / 256;
     float keep[kItemsPerThread][3][4];
 #pragma unroll
     for (int it = 0; it < kItemsPerThread; ++it) {
         const int item = threadIdx.x + it * 256;
         if (item < kItems) {
-            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+            const int ry = item / kBwdHzGroups, cx = (item % kBwdHzGroups) * 4;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float p[14];
@@ -209,7 +230,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
     for (int it = 0; it < kItemsPerThread; ++it) {
         const int item = threadIdx.x + it * 256;
         if (item < kItems) {
-            const int ry = item / kHzGroups, cx = (item % kHzGroups) * 4;
+            const int ry = item / kBwdHzGroups, cx = (item % kBwdHzGroups) * 4;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -222,16 +243,16 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
     // `grad * upstream` is one more pass over the 25 MB gradient image (11 us per iteration at 1080p)
     const float up = a.upstream != nullptr ? *a.upstream : 1.0f;
     const float ks = -a.lambda_dssim / n_total * up, kl = a.lambda_l1 / n_total * up;
-    const int ox = threadIdx.x % kLossTileW, oy0 = (threadIdx.x / kLossTileW) * kRowsPerThread;
+    const int ox = threadIdx.x % kBwdTileW, oy0 = (threadIdx.x / kBwdTileW) * kBwdRows;
     const int gx = x0 + ox;
-    float v[3][kRowsPerThread];
+    float v[3][kBwdRows];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        float col[kRowsPerThread + kTaps - 1];
+        float col[kBwdRows + kTaps - 1];
 #pragma unroll
-        for (int t = 0; t < kRowsPerThread + kTaps - 1; ++t) col[t] = hz[m][oy0 + t][ox];
+        for (int t = 0; t < kBwdRows + kTaps - 1; ++t) col[t] = hz[m][oy0 + t][ox];
 #pragma unroll
-        for (int o = 0; o < kRowsPerThread; ++o) {
+        for (int o = 0; o < kBwdRows; ++o) {
             float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < kTaps; ++t) acc += gw.w[t] * col[o + t];
@@ -239,7 +260,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
         }
     }
 #pragma unroll
-    for (int o = 0; o < kRowsPerThread; ++o) {
+    for (int o = 0; o < kBwdRows; ++o) {
         const int gy = y0 + oy0 + o;
         if (gy >= a.height || gx >= a.width) continue;
         const size_t e = c * plane + (size_t)gy * a.width + gx;
@@ -269,13 +290,14 @@ hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), block, 0, s, a, grid.x * grid.y * grid.z);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.grad == nullptr) return e;
-    hipLaunchKernelGGL(ssim_backward_kernel, grid, block, 0, s, a, gw);
+    const dim3 grid_b((a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, 3);
+    hipLaunchKernelGGL(ssim_backward_kernel, grid_b, block, 0, s, a, gw);
     return hipGetLastError();
 }
 
 hipError_t launch_l1_dssim_backward(const LossArgs& a, hipStream_t s) {
     const GaussWindow gw = make_window();
-    const dim3 grid((a.width + kLossTileW - 1) / kLossTileW, (a.height + kLossTileH - 1) / kLossTileH, 3), block(256);
+    const dim3 grid((a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, 3), block(256);
     hipLaunchKernelGGL(ssim_backward_kernel, grid, block, 0, s, a, gw);
     return hipGetLastError();
 }
