@@ -42,12 +42,13 @@ def measure(tag, params, views, view_ids):
     del g
 
 
-sys.argv = ['bench.py']
-params, views, _ = bench.build_scene(bench.parse())
-measure('S2', params, views, [0, 2])
-p2 = dict(params); p2['opacities'] = params['opacities'] - 3.0
-measure('layered (S2, logits - 3)', p2, views, [0, 2])
-del params, p2
+if not os.environ.get('FGS_PAIR_STATS_ONLY_PLY'):
+    sys.argv = ['bench.py']
+    params, views, _ = bench.build_scene(bench.parse())
+    measure('S2', params, views, [0, 2])
+    p2 = dict(params); p2['opacities'] = params['opacities'] - 3.0
+    measure('layered (S2, logits - 3)', p2, views, [0, 2])
+    del params, p2
 if os.environ.get('FGS_PLY'):
     sys.argv = ['bench.py', '--ply', os.environ['FGS_PLY']]
     params, views, what = bench.build_scene(bench.parse())

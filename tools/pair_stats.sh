@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$C -I$R/include -Xclang -target-feature -Xclang -packed-fp32-ops -DFGS_PAIR_STATS"
   /opt/rocm/bin/hipcc $F -c $C/blend_backward.hip -o $C/_build/bb_pairstats.o
   /opt/rocm/bin/hipcc $F -c $C/blend_forward.hip -o $C/_build/bf_pairstats.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "blend_backward.o\|blend_forward.o\|_timeline.o\|_pairstats.o\|k1timer") $C/_build/bb_pairstats.o $C/_build/bf_pairstats.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "blend_backward.o\|blend_forward.o\|/bb_\|/bf_\|k1timer") $C/_build/bb_pairstats.o $C/_build/bf_pairstats.o
   ls -la $LIB | awk '{print $5, $9}'
 else
   FGS_HIP_LIBRARY=$LIB python $R/tools/pair_stats.py
