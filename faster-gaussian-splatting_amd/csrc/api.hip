@@ -355,18 +355,20 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     ba.width = settings->width; ba.height = settings->height; ba.grid_w = geo.grid_w; ba.n_tiles = geo.n_tiles;
     ba.to_chw = to_chw; ba.clamp_output = clamp_output;
     uint32_t n_buckets_cap = 0;
-    // K8+K9 (fwd:218-231) and K10's tile plan in one single-workgroup kernel; every mode (the inference blend is planned the same way)
-    if (!training && !(fgs::g_tile_row_group == static_cast<int>(kPlannedBlocks) || fgs::g_tile_row_group == static_cast<int>(kBandsThroughPlan))) {
-        // inference with a closed-form tile mapping: no bucket scan, no plan
-    } else if (g_library_bucket_scan && training) {
+    // The tile -> workgroup mapping is read ONCE per pass and travels in BlendArgs, so that planning and launch see the same value (it is a
+    // process-wide A/B switch another thread may flip). K8+K9 (fwd:218-231) and K10's optional block plan are one single-workgroup kernel.
+    const uint32_t row_group = static_cast<uint32_t>(fgs::g_tile_row_group.load());
+    const bool need_plan = row_group == kPlannedBlocks || row_group == kBandsThroughPlan;     // A/B mappings that read a device-side table
+    const bool need_scan = training || need_plan;                                             // per-tile bucket offsets: the training blend's checkpoints
+    ba.row_group = row_group;
+    if (need_scan) {
         StageScope t(ST_BUCKET_SCAN, stream);
-        FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));
-    } else {
-        StageScope t(ST_BUCKET_SCAN, stream);
-        // the block plan is made only when that mapping is selected (A/B, fgs_debug_set_option(10, 254)); the default mapping is closed-form
-        const bool plan = fgs::g_tile_row_group == static_cast<int>(kPlannedBlocks) || fgs::g_tile_row_group == static_cast<int>(kBandsThroughPlan);
-        FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, plan ? tb.tile_plan : nullptr, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
-        ba.tile_plan = plan ? tb.tile_plan : nullptr;
+        if (g_library_bucket_scan && training) {
+            FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));      // (A/B: rocPRIM scan, no plan)
+        } else {
+            FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, need_plan ? tb.tile_plan : nullptr, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
+            ba.tile_plan = need_plan ? tb.tile_plan : nullptr;
+        }
     }
     ba.grid_h = geo.grid_h;
     if (training) {

@@ -387,16 +387,14 @@ __global__ void __launch_bounds__(kBlendBlock) pruning_scores_kernel(const Blend
 }
 
 hipError_t launch_pruning_scores(const BlendArgs& a_in, hipStream_t s) {
-    BlendArgs a = a_in;
-    a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    BlendArgs a = a_in;                          // row_group: set by the caller (api.hip reads the switch once per pass)
     if (a.tile_plan == nullptr && (a.row_group == kPlannedBlocks || a.row_group == kBandsThroughPlan)) a.row_group = 0u;
     hipLaunchKernelGGL(pruning_scores_kernel, dim3(blend_grid(a)), dim3(kBlendBlock), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_blend(bool training, const BlendArgs& a_in, hipStream_t s) {
-    BlendArgs a = a_in;
-    a.row_group = static_cast<uint32_t>(g_tile_row_group.load());
+    BlendArgs a = a_in;                          // row_group: set by the caller (api.hip reads the switch once per pass)
     if (a.tile_plan == nullptr && (a.row_group == kPlannedBlocks || a.row_group == kBandsThroughPlan)) a.row_group = 0u;          // no plan was made: the bands
     const dim3 grid(blend_grid(a)), block(kBlendBlock);
     if (training) hipLaunchKernelGGL(blend_kernel<true>, grid, block, 0, s, a);

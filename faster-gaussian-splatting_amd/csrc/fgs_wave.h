@@ -4,8 +4,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fgs_wave.h is written for gfx950 (CDNA4, wave64): the DPP scans below use row_bcast:15 / row_bcast:31, which exist on gfx9 / CDNA only"
+#endif
+
 namespace fgs {
 
+// PRECONDITION of every scan / reduction / shift below (wave_inclusive_sum, wave_exclusive_sum, wave_sum, wave_max, wave_sum_to_lane63,
+// wave_shift_up1*, pipeline_advance, wave_mfma_16x16x4): FULL EXEC -- all 64 lanes active, in particular lane 63, with no gaps. DPP reads of an
+// inactive lane return the `old` / zero operand and v_readlane(63) of an inactive lane is undefined. Every call site is convergent code (no call
+// under a divergent branch); the on-device self-test (fgs_debug_wave_selftest, tests/test_gpu_parity.py) exercises them with non-trivial data.
 __device__ __forceinline__ unsigned lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

@@ -290,7 +290,8 @@ int32_t fgs_morton_order(const float* means, const float* lo, const float* hi, i
  *   loss = lambda_l1 * mean|image - target| + lambda_dssim * (1 - SSIM(image, target))        (Loss.py:15-16, Trainer.py:52-53)
  * replacing torch.nn.functional.l1_loss + NeRFICG's fused_dssim (Optim/Losses/DSSIM.py, not vendored). Writes three device
  * floats out[0] = mean|x-y|, out[1] = mean SSIM, out[2] = the loss (no host sync) and, if grad_image != NULL,
- * dloss/dimage [3,H,W]. scratch: fgs_l1_dssim_scratch_bytes(width, height) bytes. */
+ * dloss/dimage [3,H,W]. scratch: fgs_l1_dssim_scratch_bytes(width, height) bytes, 8-byte aligned (it holds float2 partial sums; a
+ * misaligned pointer is refused with FGS_ERR_INVALID_ARGUMENT). */
 size_t fgs_l1_dssim_scratch_bytes(int32_t width, int32_t height);
 int32_t fgs_l1_dssim_loss(const float* image, const float* target, int32_t width, int32_t height, float lambda_l1, float lambda_dssim,
                           float* out3, float* grad_image, void* scratch, void* stream);
@@ -326,20 +327,22 @@ int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t
 int32_t fgs_debug_depth_sort(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, float near_plane, float far_plane,
                              void* temp, size_t temp_bytes, void* stream);
 /* Selects the blend-backward formulation: 3 (default) = live-bucket list + compacted pixels + two-value pipeline state, 2 / 0 =
- * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel). A/B switch for tests and bench: process-wide,
- * unsynchronised; all variants must give the same gradients. */
+ * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel, DPP reductions), 4 = lane = pixel walk with the
+ * per-Gaussian sums reduced on the matrix cores (round 4; measured against 3 in profiles/r04_k11m_closeout.txt). A/B switch for tests and
+ * bench: process-wide, unsynchronised; all variants must give the same gradients. */
 int32_t fgs_debug_set_backward_variant(int32_t variant);
 /* Tuning switches for A/B measurements inside one process (process-wide, unsynchronised: bench / test processes only):
  * key 0 = blend-backward variant, 1 = Adam float4 pieces per thread (1, 2, 4), 2 = Adam non-temporal accesses, 3 = fused
  * backward+Adam as one kernel (1, default) or round 1's two (0), 5 = K1 tile counting: 0 flattened (default) or n sequential
- * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop),
+ * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop; variant 4: 4 no
+ * matrix instructions / write-out, 8 no pair arithmetic),
  * 8 = Adam walks the arenas from the end (1, default) or the start (0), 9 = depth sort: bit 0 key - bits(near) in 9-bit passes, bit 1
  * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower), 10 = forward-blend tile -> workgroup
  * mapping: 252 (default) = one vertical strip of tile columns per XCD, walked row by row from the top (251: from the bottom), 0 = one
  * contiguous band of tile rows per XCD (rounds 1-2), g = 1..64 = groups of g rows dealt to the XCDs in turn, 255 = the bands walked
  * bottom-up, 254 = blocks of tiles weighed and dealt to the XCDs on the device (plan_tiles_kernel), 253 = the bands read through the plan
  * table (blend_forward.hip has the measurements), 11 = 1: rocPRIM scan for the per-tile bucket offsets (and no block plan), 12 = 1: the
- * block plan without sorting (XCD x = block column x).
+ * block plan without sorting (XCD x = block column x), 13 = upper bound of the grid of blend-backward variant 4.
  * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
 
