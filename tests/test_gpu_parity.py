@@ -147,6 +147,21 @@ def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant)
         hip_backend.lib.fgs_debug_set_backward_variant(3)
 
 
+def test_equal_depth_keys_keep_every_order_independent_quantity(hip_backend, oracle):
+    """Hundreds of exactly equal depth keys (the fuzz scenes avoid ties): on hardware their blending order is K1's atomic compaction order, as in
+    the reference (kf:204-208) -- image and gradients legitimately depend on it, everything else must agree with the oracle exactly
+    (helpers.check_order_independent_quantities), and the image stays within what reordering equal-depth layers can do."""
+    p, view = helpers.tied_depth_scene()
+    S, RS = helpers.settings_pair(view, device=DEV)
+    dp = _to(p)
+    res = hip_backend.forward(*[dp[k] for k in helpers.NAMES], RS)
+    torch.cuda.synchronize()
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    dec = helpers.decode_forward(hip_backend, res, p['means'].shape[0], view.width, view.height)
+    helpers.check_order_independent_quantities(dec, f, view.width, view.height)
+    assert float(np.abs(res.image.cpu().numpy() - f['image']).max()) < 0.5          # a different order of tied layers, not a different scene
+
+
 def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
     """Same as the simulation test: 0xFF-poisoned scratch must not reach any output (NaN checkpoints of finished pixels)."""
     p, v = make_s0(seed=11, n=1500)

@@ -322,3 +322,14 @@ def test_forward_without_host_synchronisation(sim_backend, oracle):
     assert host.tolist() == [sync.state[0], n_inst, 1] and torch.isfinite(small.image).all()
     grads = back(small)                                                                # backward over the truncated lists stays in bounds
     assert all(torch.isfinite(g).all() for g in grads)
+
+
+def test_equal_depth_keys_keep_every_order_independent_quantity(sim_backend, oracle):
+    """Hundreds of exactly equal depth keys: counts, bounds, sorted keys, per-tile instance sets, depth order inside the lists and the final
+    transmittance agree with the oracle (helpers.check_order_independent_quantities); image and gradients are order-dependent among ties."""
+    p, view = helpers.tied_depth_scene()
+    S, RS = helpers.settings_pair(view)
+    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    dec = helpers.decode_forward(sim_backend, res, p['means'].shape[0], view.width, view.height)
+    helpers.check_order_independent_quantities(dec, f, view.width, view.height)
