@@ -6,8 +6,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02}
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o bench -- $B > $R/gpurun_out/${TAG}_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU -d $R/gpurun_out/${TAG}_fetch -o bench -- $B > $R/gpurun_out/${TAG}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_WAVES -d $R/gpurun_out/${TAG}_write -o bench -- $B > $R/gpurun_out/${TAG}_write.log 2>&1
+# counter passes: the child command of bench.py's own live counters (headline training steps + fused steps; no layered / trained-like extras, whose
+# launches at other sizes would be averaged into the per-dispatch totals)
+P="python $R/bench.py --steps 3 --warmup 1 --no-extras --blocks 1 --no-cpu-baseline --no-pmc --pmc-child"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU -d $R/gpurun_out/${TAG}_fetch -o bench -- $P > $R/gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_WAVES -d $R/gpurun_out/${TAG}_write -o bench -- $P > $R/gpurun_out/${TAG}_write.log 2>&1
 S="python $R/bench.py --gpus 1 --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-pmc --dp-mode sharded --force-dp"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_sharded_stats -o bench -- $S > $R/gpurun_out/${TAG}_sharded_stats.log 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value $R/tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate > $R/gpurun_out/${TAG}_valu_rate.txt 2>&1
