@@ -368,7 +368,7 @@ def main():
     # Stage table: a separate, untimed pass of PROFILE_STEPS iterations with HIP events around every stage. The events themselves cost
     # GPU idle time (~5 us each, ~0.2 ms per iteration with all ~15 stages bracketed: measured with rocprofv3 --kernel-trace), so the
     # timed region below brackets only the dominant stage found here -- the `roofline` figure is still measured live, over the timed steps.
-    PROFILE_STEPS = 4
+    PROFILE_STEPS = 1 if sim else 4
     be.profile_enable(True)
     be.profile_read()
     for i in range(PROFILE_STEPS):

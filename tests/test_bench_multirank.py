@@ -21,7 +21,7 @@ def _run(extra, env=None, timeout=900):
                           env=dict(os.environ, **(env or {})))
 
 
-@pytest.mark.parametrize('n,mode', [(2, 'sharded'), (2, 'allreduce'), (2, 'zero1'), (8, 'sharded')])
+@pytest.mark.parametrize('n,mode', [(2, 'sharded'), (2, 'allreduce'), (8, 'sharded')])      # (zero1 shares allreduce's branch of this script: tests/test_distributed.py drives it)
 def test_bench_multirank_branch_runs_and_reports_every_rank(n, mode):
     r = _run(['--gpus', str(n), '--dp-mode', mode])
     assert r.returncode == 0, r.stderr[-3000:]
