@@ -369,6 +369,9 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         near = masks['near'] & keep
         keep = keep & ~near
         report['near_gaussians'] = float(near.mean()) if near.size else 0.0
+        # the looser class is capped: measured on hardware at most 0.13 of the Gaussians of an adversarial fuzz scene (profiles/r04_gpu_tolerance_slack.txt
+        # part 4, seed 8) and 0.10 at the layered S2 scene; a class that swallows a quarter of a scene would make the 1e-4 bar meaningless
+        assert report['near_gaussians'] < 0.25, (label, 'share of Gaussians in the near class', report['near_gaussians'])
         for k, a in grads.items():
             report[k + '_near'] = masked_rel_inf(np.asarray(a).reshape(g_ref[k].shape), g_ref[k], near)
             assert report[k + '_near'] < near_tol, (label, k + ' (Gaussians behind a borderline pair)', report)
