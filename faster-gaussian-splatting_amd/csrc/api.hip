@@ -1078,7 +1078,7 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
 }
 
 int32_t fgs_debug_set_backward_variant(int32_t variant) {
-    if (variant < 0 || variant > 5) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC), 3 (live list + compacted pixels), 4 (lane = pixel, matrix-core reduction) or 5 (4 as a pixel wave + a matrix wave)");
+    if (variant < 0 || variant > 4) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC), 3 (live list + compacted pixels) or 4 (lane = pixel, matrix-core reduction)");
     fgs::g_backward_variant = variant;
     return FGS_OK;
 }

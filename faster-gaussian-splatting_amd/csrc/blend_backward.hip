@@ -902,240 +902,6 @@ __global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const Blend
     if (lane == 0) for (int i = 0; i < 8; ++i) if (ph_[i] != 0) atomicAdd(&g_k11m_phases[i], ph_[i]);
 #endif
 }
-// ---- variant 5: variant 4 split over TWO waves ------------------------------------------------------------------------------------------------
-// Variant 4's three parts -- vector work per pair, matrix passes, per-item loads -- added up because one in-order wave did them one after the
-// other and only four such waves fit a SIMD. Here a workgroup is a PAIR of waves with one barrier per batch of eight pairs between them:
-//   * the pixel wave (lane = pixel) walks the strip's list and writes w / hh of batch n into row buffer n & 1;
-//   * the matrix wave reads batch n - 1 from the other buffer, runs its 16 matrix instructions and adds the results to the bucket's LDS
-//     accumulators -- on ANOTHER SIMD's matrix pipe, while the pixel wave's vector instructions run; it also stages the records, and at the end
-//     of the item converts the moments and issues the global atomics (lane = Gaussian) while the pixel wave already loads the next item's pixels.
-constexpr unsigned kPairThreads = 2u * kWave;
-__global__ void __launch_bounds__(kPairThreads) blend_backward_pair_kernel(const BlendBackwardArgs a) {
-    __shared__ float4 s_rec[3 * kBucket];                                      // mean.xy conic.ab | conic.c opacity r g (clamped) | b (clamped) bounds_x bounds_y flags
-    __shared__ float s_acc[9 * kBucket];                                       // planes Sh Sx Sy Sxx Sxy Syy c0 c1 c2 of the bucket's Gaussians
-    __shared__ __attribute__((aligned(16))) float s_rows[2][kPixRows * kPixStride];   // w / hh rows of the batch being written and of the batch being multiplied
-    __shared__ __attribute__((aligned(16))) float s_feat[9 * kPixStride];     // the strip's feature rows [g_r g_g g_b 1 x' y' x'^2 x'y' y'^2] = matrix operand A
-    __shared__ uint8_t s_order[kBucket + kPixSlots + 4];                       // bucket-relative index of the i-th Gaussian the current strip walks
-    __shared__ uint32_t s_n_pairs;                                             // pairs of the current strip (0: nothing to do)
-    const unsigned lane = threadIdx.x & 63u, half = lane >> 5;
-    const bool pixel_wave = wave_uniform(static_cast<unsigned>(threadIdx.x)) < kWave;      // wave-uniform, and the compiler is told so
-    const unsigned pos = (lane & 3u) * 16u + (lane >> 2);                      // pixel p = 4 s + q of matrix k-step s sits at q * 16 + s of its row
-    const unsigned col = lane & 15u, q = lane >> 4;                            // the matrix wave's column / k index in the matrix instruction
-    const unsigned lx = half * kSubtileW + (lane & 7u), ly_in_strip = (lane >> 3) & 3u;
-    const unsigned n_live = *a.live_count;
-    unsigned item = blockIdx.x;
-    uint2 work = make_uint2(0u, 0u), range = make_uint2(0u, 0u);
-    unsigned bucket_base = 0;
-    if (item < n_live) {                                                       // the scalar head of an item is fetched one item ahead (variant 4)
-        work = a.work_list[item];
-        range = a.ranges[work.x];
-        bucket_base = work.x == 0 ? 0u : a.bucket_offsets[work.x - 1];
-    }
-    for (; item < n_live; item += gridDim.x) {                                 // workgroup-uniform
-        const unsigned tile = work.x, tb = work.y;
-        const unsigned tile_n = range.y - range.x;
-        const unsigned bucket = bucket_base + tb;
-        const unsigned first_gaussian = tb * kBucket;
-        const unsigned n_here = min(static_cast<unsigned>(kBucket), tile_n - first_gaussian);
-        const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
-        const unsigned range_x = range.x;
-        {
-            const unsigned next = item + gridDim.x;
-            if (next < n_live) {
-                work = a.work_list[next];
-                range = a.ranges[work.x];
-                bucket_base = work.x == 0 ? 0u : a.bucket_offsets[work.x - 1];
-            }
-        }
-        // ---- pixel wave: the three strips' pixel records and checkpoints (kb:349-380), six values per strip ----
-        float gx_[3] = {}, gy_[3] = {}, gz_[3] = {}, T_[3] = {}, S_[3] = {};
-        unsigned rel_[3] = {};
-        uint32_t prim = 0, hot_slot_word = 0;
-        if (pixel_wave) {
-#pragma unroll
-            for (unsigned st = 0; st < 3u; ++st) {
-                const unsigned local = (st * kSubtileH + ly_in_strip) * kTileW + lx;
-                const float4 cst = a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1];
-                const float4 g = a.pixrec[((size_t)tile * kTilePixels + local) * 2];
-                const float4 ck = a.ckpt[(size_t)bucket * kTilePixels + local];
-                const unsigned last = __float_as_uint(cst.w);                  // 0 outside the image
-                const bool live = last > first_gaussian;                       // a pixel that finished before this bucket receives nothing (kf:436)
-                rel_[st] = live ? last - first_gaussian : 0u;
-                gx_[st] = g.x; gy_[st] = g.y; gz_[st] = g.z;
-                T_[st] = live ? ck.w : 0.0f;
-                S_[st] = live ? ((cst.x - ck.x) * g.x + (cst.y - ck.y) * g.y + (cst.z - ck.z) * g.z) - g.w : 0.0f;     // kb:371-377 projected on dL/dC
-            }
-        } else {
-            // ---- matrix wave: the bucket's records (kb:297-319), lane = Gaussian; clears the accumulators ----
-            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-            uint32_t flags = 0;
-            if (lane < n_here) {
-                prim = a.inst_prims[range_x + first_gaussian + lane];
-                const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
-                r0 = r[0]; r1 = r[1]; r2 = r[2];
-                flags = (r1.z >= 0.0f ? 1u : 0u) | (r1.w >= 0.0f ? 2u : 0u) | (r2.x >= 0.0f ? 4u : 0u);      // kb:313-318
-                hot_slot_word = __float_as_uint(r2.w);
-            }
-            s_rec[lane] = r0;
-            s_rec[kBucket + lane] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
-            s_rec[2 * kBucket + lane] = make_float4(fmaxf(r2.x, 0.0f), r2.y, r2.z, __uint_as_float(flags));
-#pragma unroll
-            for (unsigned e = 0; e < 9u; ++e) s_acc[e * kBucket + lane] = 0.0f;
-        }
-        __syncthreads();                                                       // records staged, accumulators cleared
-
-#pragma unroll 1
-        for (unsigned strip = 0; strip < static_cast<unsigned>(kTilePixels / kWave); ++strip) {
-            const unsigned ly = strip * kSubtileH + ly_in_strip;
-            const float pxf = static_cast<float>(tile_x * kTileW + lx) + 0.5f, pyf = static_cast<float>(tile_y * kTileH + ly) + 0.5f;
-            const unsigned rel = strip == 0u ? rel_[0] : strip == 1u ? rel_[1] : rel_[2];
-            const float4 g = make_float4(strip == 0u ? gx_[0] : strip == 1u ? gx_[1] : gx_[2], strip == 0u ? gy_[0] : strip == 1u ? gy_[1] : gy_[2],
-                                         strip == 0u ? gz_[0] : strip == 1u ? gz_[1] : gz_[2], 0.0f);
-            float T = strip == 0u ? T_[0] : strip == 1u ? T_[1] : T_[2], sS = strip == 0u ? S_[0] : strip == 1u ? S_[1] : S_[2];
-            uint64_t pending = 0, mask_l = 0, mask_r = 0;
-            if (pixel_wave) {
-                // Gaussians at or behind every pixel's last contributor take nothing (kb:412); wave-uniform through v_readfirstlane
-                const unsigned rel_max = wave_uniform(wave_max(rel));
-                if (rel_max != 0u) {
-                    const float xr = static_cast<float>(lx) - 7.5f, yr = static_cast<float>(ly) - 5.5f;
-                    s_feat[0 * kPixStride + pos] = g.x; s_feat[1 * kPixStride + pos] = g.y; s_feat[2 * kPixStride + pos] = g.z;
-                    s_feat[3 * kPixStride + pos] = 1.0f; s_feat[4 * kPixStride + pos] = xr; s_feat[5 * kPixStride + pos] = yr;
-                    s_feat[6 * kPixStride + pos] = xr * xr; s_feat[7 * kPixStride + pos] = xr * yr; s_feat[8 * kPixStride + pos] = yr * yr;
-                    // cull the bucket against this strip's two 8x4 sub-tiles (kf:445-451), lane = Gaussian
-                    const unsigned sub_y0 = tile_y * kTileH + strip * kSubtileH, sub_y1 = sub_y0 + kSubtileH;
-                    const unsigned subl_x0 = tile_x * kTileW, subl_x1 = subl_x0 + kSubtileW, subr_x1 = subl_x1 + kSubtileW;
-                    bool in_l = false, in_r = false;
-                    if (lane < n_here) {
-                        const float4 gc = s_rec[2 * kBucket + lane];
-                        const uint32_t bx = __float_as_uint(gc.y), by = __float_as_uint(gc.z);
-                        const unsigned x_min = bx & 0xffffu, x_max = bx >> 16, y_min = by & 0xffffu, y_max = by >> 16;
-                        const bool in_y = y_min < sub_y1 && sub_y0 < y_max;
-                        in_l = in_y && x_min < subl_x1 && subl_x0 < x_max;
-                        in_r = in_y && x_min < subr_x1 && subl_x1 < x_max;
-                    }
-                    mask_l = wave_ballot(in_l); mask_r = wave_ballot(in_r);
-                    pending = wave_uniform(static_cast<uint64_t>((mask_l | mask_r) & (rel_max >= 64u ? ~0ull : ((1ull << rel_max) - 1ull))));
-                    // slot -> Gaussian of the matrix batches: the i-th pair of the walk is the i-th set bit of `pending` (every lane stores)
-                    s_order[((pending >> lane) & 1ull) ? lanes_below(pending) : kBucket + kPixSlots] = static_cast<uint8_t>(lane);
-                }
-                if (lane == 0) s_n_pairs = static_cast<uint32_t>(__popcll(static_cast<unsigned long long>(pending)));
-            }
-            __syncthreads();                                                   // the strip's pair count, feature rows and order table are published
-            const unsigned n_pairs = s_n_pairs;
-            if (n_pairs == 0u) { __syncthreads(); continue; }                  // (the count is read by everybody before the next strip overwrites it)
-            const unsigned n_batches = (n_pairs + kPixSlots - 1u) / kPixSlots;
-            float A[16];
-            if (!pixel_wave) {                                                 // row c of the feature matrix, 16 k-steps
-                const float4* ap = reinterpret_cast<const float4*>(s_feat + min(col, 8u) * kPixStride + q * 16u);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 t = ap[i];
-                    const bool used = col < 9u;
-                    A[4 * i] = used ? t.x : 0.0f; A[4 * i + 1] = used ? t.y : 0.0f; A[4 * i + 2] = used ? t.z : 0.0f; A[4 * i + 3] = used ? t.w : 0.0f;
-                }
-            }
-            // round `batch`: the pixel wave fills batch `batch` while the matrix wave multiplies batch `batch - 1`; one barrier per round
-            for (unsigned batch = 0; batch <= n_batches; ++batch) {
-                if (pixel_wave) {
-                    if (batch < n_batches && !(a.ablate & 8)) {
-                        float* v_row = s_rows[batch & 1u] + pos;
-                        for (unsigned sl = 0; sl < kPixSlots; ++sl) {          // wave-uniform
-                            if (pending == 0ull) break;
-                            const unsigned j = static_cast<unsigned>(__ffsll(static_cast<unsigned long long>(pending))) - 1u;
-                            pending &= pending - 1ull;
-                            const float4* const entry = s_rec + j;
-                            const float4 ga = entry[0], gb = entry[kBucket];
-                            const float colb = entry[2 * kBucket].x;
-                            const float dx = ga.x - pxf, dy = ga.y - pyf;
-                            const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
-                            const float gauss = __expf(fminf(power, 0.0f));
-                            const float alpha_raw = gb.y * gauss;
-                            // contributes (kb:412,419-421; kf:445-467): alpha >= 1/255, in front of the pixel's last contributor, box on this lane's sub-tile;
-                            // branch-free as in variant 4 (a pair that does not contribute runs with alpha = 0)
-                            const uint64_t not_mine = (((mask_l >> j) & 1ull) ? 0ull : 0x00000000ffffffffull) | (((mask_r >> j) & 1ull) ? 0ull : 0xffffffff00000000ull);
-                            const uint64_t pass = wave_ballot(alpha_raw >= kMinAlphaThreshold && j < rel) & ~not_mine;
-                            const float alpha = lane_select(pass, 0.0f, alpha_raw);
-                            const float w = T * alpha;
-                            const float cg = gb.z * g.x + gb.w * g.y + colb * g.z;
-                            sS -= w * cg;                                       // kb:429 projected on dL/dC
-                            const float oma = 1.0f - alpha;
-                            const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
-                            const float dl_dalpha = T * cg - sS * oma_rcp;      // kb:434-436
-                            const float hh = (-0.5f * alpha) * dl_dalpha;
-                            T *= oma;
-                            v_row[0] = w;
-                            v_row[kPixSlots * kPixStride] = hh;
-                            v_row += kPixStride;
-                        }
-                    }
-                } else if (batch > 0u && !(a.ablate & 4)) {
-                    const unsigned done = (batch - 1u) * kPixSlots;
-                    const unsigned n = min(kPixSlots, n_pairs - done);
-                    const float4* bp = reinterpret_cast<const float4*>(s_rows[(batch - 1u) & 1u] + col * kPixStride + q * 16u);
-                    const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-                    const unsigned slot = col & 7u;
-                    const unsigned gi = s_order[done + slot];
-                    fgs_acc4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};      // two chains: a dependent matrix instruction waits 40 cycles, an independent one 32
-                    wave_mfma_16x16x4(A[0], b0.x, d0); wave_mfma_16x16x4(A[1], b0.y, d1); wave_mfma_16x16x4(A[2], b0.z, d0); wave_mfma_16x16x4(A[3], b0.w, d1);
-                    wave_mfma_16x16x4(A[4], b1.x, d0); wave_mfma_16x16x4(A[5], b1.y, d1); wave_mfma_16x16x4(A[6], b1.z, d0); wave_mfma_16x16x4(A[7], b1.w, d1);
-                    wave_mfma_16x16x4(A[8], b2.x, d0); wave_mfma_16x16x4(A[9], b2.y, d1); wave_mfma_16x16x4(A[10], b2.z, d0); wave_mfma_16x16x4(A[11], b2.w, d1);
-                    wave_mfma_16x16x4(A[12], b3.x, d0); wave_mfma_16x16x4(A[13], b3.y, d1); wave_mfma_16x16x4(A[14], b3.z, d0); wave_mfma_16x16x4(A[15], b3.w, d1);
-                    // this lane holds D[row 4 q + r][col]: rows 0..2 = colour sums (columns 0..7, the w rows), rows 3..8 = moment sums (columns 8..15, the hh rows);
-                    // one wave owns the accumulators and a Gaussian sits in one slot of one batch per strip: plain read-modify-write
-                    const bool is_w = col < 8u;
-                    if (slot < n) {
-                        if (q == 0u) {
-                            if (is_w) {
-                                s_acc[6 * kBucket + gi] += d0[0] + d1[0]; s_acc[7 * kBucket + gi] += d0[1] + d1[1]; s_acc[8 * kBucket + gi] += d0[2] + d1[2];
-                            } else s_acc[gi] += d0[3] + d1[3];
-                        } else if (!is_w) {
-                            if (q == 1u) {
-                                s_acc[1 * kBucket + gi] += d0[0] + d1[0]; s_acc[2 * kBucket + gi] += d0[1] + d1[1];
-                                s_acc[3 * kBucket + gi] += d0[2] + d1[2]; s_acc[4 * kBucket + gi] += d0[3] + d1[3];
-                            } else if (q == 2u) s_acc[5 * kBucket + gi] += d0[0] + d1[0];
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- matrix wave, lane = Gaussian: moments about the tile centre -> the nine gradients, added to the planes (kb:459-470) ----
-        if (!pixel_wave && lane < n_here) {
-            const float Sh = s_acc[lane], Sx = s_acc[kBucket + lane], Sy = s_acc[2 * kBucket + lane];
-            const float Sxx = s_acc[3 * kBucket + lane], Sxy = s_acc[4 * kBucket + lane], Syy = s_acc[5 * kBucket + lane];
-            const float c0 = s_acc[6 * kBucket + lane], c1 = s_acc[7 * kBucket + lane], c2 = s_acc[8 * kBucket + lane];
-            const bool silent = Sh == 0.0f && Sx == 0.0f && Sy == 0.0f && Sxx == 0.0f && Sxy == 0.0f && Syy == 0.0f && c0 == 0.0f && c1 == 0.0f && c2 == 0.0f;
-            if (!silent && !(a.ablate & 1)) {
-                const float4 ga = s_rec[lane], gb = s_rec[kBucket + lane], gc = s_rec[2 * kBucket + lane];
-                const float ca = ga.z, cb = ga.w, cc = gb.x, op = gb.y;
-                const float Dx = ga.x - (static_cast<float>(tile_x * kTileW) + 8.0f), Dy = ga.y - (static_cast<float>(tile_y * kTileH) + 6.0f);
-                const float a_x = Dx * Sh - Sx, a_y = Dy * Sh - Sy;
-                const float a_xx = Dx * (Dx * Sh - 2.0f * Sx) + Sxx, a_yy = Dy * (Dy * Sh - 2.0f * Sy) + Syy;
-                const float a_xy = Dx * (Dy * Sh - Sy) - Dy * Sx + Sxy;
-                const unsigned flags = __float_as_uint(gc.w);
-                unsigned tx0, tx1, ty0, ty1;
-                tile_rect(__float_as_uint(gc.y), __float_as_uint(gc.z), tx0, tx1, ty0, ty1);
-                const unsigned footprint = (tx1 - tx0) * (ty1 - ty0);
-                const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
-                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + prim;
-                const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
-                unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
-                unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
-                unsafeAtomicAdd(dst + 2 * plane, a_xx);
-                unsafeAtomicAdd(dst + 3 * plane, a_xy);
-                unsafeAtomicAdd(dst + 4 * plane, a_yy);
-                unsafeAtomicAdd(dst + 5 * plane, a.proper_aa ? -2.0f * Sh / op : -2.0f * Sh * (1.0f - op));
-                unsafeAtomicAdd(dst + 6 * plane, (flags & 1u) ? c0 : 0.0f);
-                unsafeAtomicAdd(dst + 7 * plane, (flags & 2u) ? c1 : 0.0f);
-                unsafeAtomicAdd(dst + 8 * plane, (flags & 4u) ? c2 : 0.0f);
-            }
-        }
-        // (no barrier here: the matrix wave restages the records and clears the accumulators itself, after the reads above; the pixel wave touches
-        // neither before the barrier that follows the staging of the next item)
-    }
-}
-
 #ifdef FGS_K11M_PHASES
 }  // namespace fgs
 extern "C" __attribute__((visibility("default"))) int fgs_debug_k11m_phases(unsigned long long* out, int reset) {
@@ -1191,15 +957,6 @@ hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
 hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
     const BlendBackwardArgs& a = a_in;
     if (a.n_buckets_cap == 0) return hipSuccess;
-    if (g_backward_variant == 5) {
-        BlendBackwardArgs a = a_in;
-        a.ablate = g_backward_ablate;
-        const unsigned cap_blocks = static_cast<unsigned>(g_k11m_max_blocks.load());
-        const unsigned blocks = a.n_buckets_cap < cap_blocks ? a.n_buckets_cap : cap_blocks;
-        hipLaunchKernelGGL(blend_backward_pair_kernel, dim3(blocks), dim3(kPairThreads), 0, s, a);
-        hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
-        return hipGetLastError();
-    }
     if (g_backward_variant == 4) {
         BlendBackwardArgs a = a_in;
         a.ablate = g_backward_ablate;
