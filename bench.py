@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--watchdog', type=int, default=900, help='seconds after which a hung rank dumps its stacks and exits (0 = off)')
     ap.add_argument('--pmc-child', action='store_true', help='internal: the short child run of the rocprofv3 counter passes (training + fused steps only)')
     ap.add_argument('--force-dp', action='store_true', help='world size 1: run the multi-GPU step (exchange = local copy) instead of the single-GPU iteration (profiling)')
+    ap.add_argument('--shared-device', action='store_true',
+                    help='TEST of the N > 1 branch on a one-GPU box, not a measurement: every rank uses cuda:0 and the real HIP library, the exchanges '
+                         'go through gloo (RCCL refuses two ranks on one device); the line says so in `data`')
     ap.add_argument('--sim', action='store_true',
                     help='TEST INFRASTRUCTURE, not a measurement: run this script\'s multi-rank control flow on CPU -- the tests/sim build of the same HIP '
                          'sources as backend, CPU tensors, gloo instead of RCCL -- so that the N > 1 branch is executed before an 8-GPU node ever runs it '
@@ -235,13 +238,14 @@ def main():
     sim = args.sim
     if not torch.cuda.is_available() and not sim:
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
-    device = torch.device('cpu') if sim else torch.device('cuda', local_rank)
+    shared = args.shared_device and not sim
+    device = torch.device('cpu') if sim else torch.device('cuda', 0 if shared else local_rank)
     if not sim:
         torch.cuda.set_device(device)
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         import datetime
         limit = datetime.timedelta(seconds=max(args.watchdog, 120) if args.watchdog else 1800)
-        if sim:
+        if sim or shared:
             dist.init_process_group('gloo', timeout=limit)
         else:
             dist.init_process_group('nccl', device_id=device, timeout=limit)
@@ -529,7 +533,8 @@ def main():
         'metric': 'train_iters_per_sec', 'value': args.steps * world / elapsed, 'unit': 'iters/s (1 view each, whole job)',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic' if not sim else 'synthetic; SIMULATION on CPU (tests/sim build of the HIP sources, gloo): a test of this script, NOT a measurement',
+        'data': ('synthetic; ALL RANKS SHARE cuda:0 (gloo exchanges through host memory): a test of the multi-rank branch on the real kernels, NOT a measurement' if shared else 'synthetic') if not sim
+                else 'synthetic; SIMULATION on CPU (tests/sim build of the HIP sources, gloo): a test of this script, NOT a measurement',
         'config': {'workload': workload + '; full training iteration fwd+loss+bwd+Adam (BASELINE.json configs[2]), loss 0.8*L1+0.2*DSSIM, '
                                'densification_info updated', 'parallelism': f'view-parallel dp{world} ({args.dp_mode})' if vp is not None else 'single GPU',
                    'n_gaussians': n, 'visible': V, 'instances': I, 'buckets64': B, 'instances_walked': Ip, 'buckets64_walked': Bp, 'active_sh_bases': K_,
@@ -539,9 +544,9 @@ def main():
                    # the gradient tensors untouched (bit-identical): how often that held / did not in this process
                    'live_block_handover': FGS.live_block_stats(),
                    'world': dist.get_world_size() if dist.is_initialized() else 1, 'ranks': roster,
-                   'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if (dist.is_initialized() and not sim) else None,
+                   'rccl_version': '.'.join(str(x) for x in torch.cuda.nccl.version()) if (dist.is_initialized() and not sim and not shared) else None,
                    'backend': dist.get_backend() if dist.is_initialized() else 'none (single process)',
-                   'device': 'cpu (simulation)' if sim else f'cuda:{local_rank} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
+                   'device': 'cpu (simulation)' if sim else f'cuda:{device.index} ({torch.cuda.get_device_name(device)})', 'dp_mode': args.dp_mode if vp is not None else None,
                    'wire_bytes_per_rank_per_step': wire_bytes(args.dp_mode) if vp is not None else 0,
                    # sharded exchange on rank 0: time inside the step's three exchanges (counts all-gather, records all-to-all, accumulators
                    # all-to-all), averaged over all blocks incl. warm-up; nothing overlaps them (harness/sharded.py), so exposed = total
