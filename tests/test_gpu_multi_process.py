@@ -21,19 +21,19 @@ DEV = 'cuda:0'
 STEPS = 2
 
 
-def _device_scene():
-    """tests/test_distributed.py's two-view scene (200 Gaussians, 48 x 36) on the device."""
+def _device_scene(world=2):
+    """tests/test_distributed.py's scene (200 Gaussians, 48 x 36) on the device, one view and one target per rank."""
     _setup_paths()
     from harness.scenes import View, make_s0
     params, v0 = make_s0(seed=5, n=200)
     settings = []
-    for shift in (0.0, 0.6):
+    for shift in [0.6 * i / (world - 1) for i in range(world)]:
         w2c = v0.w2c.clone()
         w2c[0, 3] = shift
         view = View(w2c, torch.tensor([-shift, 0.0, -4.0]), 48, 36, 48.0, 48.0, 24.0, 18.0, 0.2, 1e4, torch.zeros(3))
         settings.append(helpers.settings_pair(view, device=DEV)[1])
     dp = {k: v.to(DEV).contiguous() for k, v in params.items()}
-    dt = [torch.full((3, 36, 48), 0.3 + 0.2 * i, device=DEV) for i in range(2)]
+    dt = [torch.full((3, 36, 48), 0.3 + 0.2 * i / (world - 1), device=DEV) for i in range(world)]
     return dp, settings, dt
 
 
@@ -48,7 +48,7 @@ def _worker(rank, world, mode, port, out_dir):
         from harness.distributed import SEGMENTS, ViewParallelTrainer
         from harness.sharded import ShardedTrainer, shard_of
         be = default_backend()
-        dp, ds, dt = _device_scene()
+        dp, ds, dt = _device_scene(world)
         if mode.startswith('sharded'):
             tr = ShardedTrainer(be, shard_of(dp, rank, world), LRS, fused=(mode == 'sharded'))
             for _ in range(STEPS):
@@ -67,16 +67,16 @@ def _worker(rank, world, mode, port, out_dir):
         dist.destroy_process_group()
 
 
-def _reference(be):
-    """One process, replicated parameters: the two views' gradients (each scaled 1/2) summed, one Adam launch per step."""
+def _reference(be, world):
+    """One process, replicated parameters: the views' gradients (each scaled 1 / world) summed, one Adam launch per step."""
     from harness.distributed import SEGMENTS, ViewParallelTrainer
-    dp, ds, dt = _device_scene()
+    dp, ds, dt = _device_scene(world)
     tr = ViewParallelTrainer(be, dp, LRS)          # no process group: used for its arena / Adam plumbing only
     for _ in range(STEPS):
         tr.step_count += 1
         total = torch.zeros_like(tr.grad_arena)
         for s, t in zip(ds, dt):
-            tr._render_backward(s, lambda img: 0.5 * tr.image_gradient(img, t), True)
+            tr._render_backward(s, lambda img: (1.0 / world) * tr.image_gradient(img, t), True)
             total += tr.grad_arena
         tr.grad_arena.copy_(total)
         tr._adam(0, tr.param_arena.numel(), 0)
@@ -84,27 +84,27 @@ def _reference(be):
     return {k: tr.params[k].cpu() for k in SEGMENTS}, tr.densification_info.cpu(), {k: v.cpu() for k, v in dp.items()}
 
 
-@pytest.mark.parametrize('mode', ['sharded', 'sharded_unfused', 'allreduce', 'zero1'])
-def test_two_processes_on_the_hip_kernels_equal_the_summed_gradient_step(hip_backend, tmp_path, mode):
+@pytest.mark.parametrize('mode,world', [('sharded', 2), ('sharded_unfused', 2), ('allreduce', 2), ('zero1', 2), ('sharded', 5), ('zero1', 3)])
+def test_processes_sharing_the_device_on_the_hip_kernels_equal_the_summed_gradient_step(hip_backend, tmp_path, mode, world):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, mode, port, str(tmp_path)), nprocs=2, join=True)
-    r = [torch.load(tmp_path / f'{mode}_{i}.pt') for i in range(2)]
-    ref, ref_info, start = _reference(hip_backend)
+    mp.spawn(_worker, args=(world, mode, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'{mode}_{i}.pt') for i in range(world)]
+    ref, ref_info, start = _reference(hip_backend, world)
     for k in ref:
-        assert torch.equal(r[0]['full'][k], r[1]['full'][k]), k                      # both ranks end with the same model, bit for bit
+        assert all(torch.equal(r[0]['full'][k], r[i]['full'][k]) for i in range(1, world)), k      # every rank ends with the same model, bit for bit
         step_ref = (ref[k] - start[k]).numpy()
         assert abs(step_ref).max() > 0
         # float atomics arrive in another order: compare the step taken, relative to the largest step of the tensor
         assert helpers.rel_inf((r[0]['full'][k] - start[k]).numpy(), step_ref) < 1e-4, (mode, k)
         if mode.startswith('sharded'):
-            for i in range(2):
-                assert torch.equal(r[i]['shard'][k], r[0]['full'][k][i::2]), k       # rank i owns Gaussians i, i + 2, ...
+            for i in range(world):
+                assert torch.equal(r[i]['shard'][k], r[0]['full'][k][i::world]), k   # rank i owns Gaussians i, i + world, ...
     if mode.startswith('sharded'):
-        for i in range(2):      # owners accumulate the densification statistics of BOTH views: no collective needed
-            assert helpers.rel_inf(r[i]['info'].numpy(), ref_info[:, i::2].numpy()) < 1e-4
-        assert torch.equal(r[0]['counts'], r[1]['counts']) and int(r[0]['counts'][..., 0].sum()) > 0
+        for i in range(world):      # owners accumulate the densification statistics of ALL views: no collective needed
+            assert helpers.rel_inf(r[i]['info'].numpy(), ref_info[:, i::world].numpy()) < 1e-4
+        assert all(torch.equal(r[0]['counts'], r[i]['counts']) for i in range(1, world)) and int(r[0]['counts'][..., 0].sum()) > 0
     else:
         assert helpers.rel_inf(r[0]['info'].numpy(), ref_info.numpy()) < 1e-4
 
