@@ -328,12 +328,43 @@ def post_optimizer_step(g: Gaussians, inject_noise: bool, lr_means: float, ops=N
 
 
 # ---- a whole (possibly time-compressed) training run from a random initialisation: Trainer.py:86-201 end to end ---------------------------------
+def run_mcmc_callbacks(g: Gaussians, iteration: int, schedule: dict, cap_max: int, generator: torch.Generator | None = None, ops=None) -> dict | None:
+    """The callbacks of Trainer.py:114-165 under USE_MCMC: SH degree, `mcmc_densification` in the densification window, Morton order; no
+    opacity reset (Trainer.py:154-165 skip it) and no densification statistics."""
+    s, out = schedule, None
+    if iteration >= s['sh_interval'] and iteration % s['sh_interval'] == 0:
+        g.increase_used_sh_degree()
+    if s['densification_start'] <= iteration <= s['densification_end'] and (iteration - s['densification_start']) % s['densification_interval'] == 0:
+        out = mcmc_densification(g, 0.005, cap_max, generator, ops)
+    if iteration <= s['morton_end'] and iteration % s['morton_interval'] == 0:
+        apply_morton_ordering(g)
+    return out
+
+
+def add_mcmc_regularisation_gradients(g: Gaussians, lambda_opacity: float, lambda_scale: float) -> None:
+    """d/d(parameters) of  lambda_opacity * mean(sigmoid(opacities)) + lambda_scale * mean(exp(scales))  (Loss.py:17-18, Model.py:136-142; 0.01 each
+    with MCMC, fastergs_garden.yaml:100-101), added to the photometric gradients between backward and optimizer step."""
+    with torch.no_grad():
+        if lambda_opacity:
+            a = torch.sigmoid(g.opacities.detach())
+            g.opacities.grad.add_(a * (1.0 - a), alpha=lambda_opacity / a.numel())
+        if lambda_scale:
+            e = torch.exp(g.scales.detach())
+            g.scales.grad.add_(e, alpha=lambda_scale / e.numel())
+
+
 def train_from_scratch(views, targets, bbox_lo: torch.Tensor, bbox_hi: torch.Tensor, *, n_points: int = 100_000, iterations: int = 30_000,
-                       schedule_scale: float = 1.0, seed: int = 7, max_gaussians: int = 0, on_iteration=None) -> tuple[Gaussians, dict]:
+                       schedule_scale: float = 1.0, seed: int = 7, max_gaussians: int = 0, on_iteration=None, policy: str = 'adc',
+                       max_primitives: int = 1_000_000, ops=None) -> tuple[Gaussians, dict]:
     """RANDOM_INITIALIZATION of fastergs_garden.yaml (N_POINTS uniform samples of the bounding box, carved to the points inside at least one training
     frustum: utils.py:29-52; Model.py:202-231) and the garden schedule with every interval multiplied by `schedule_scale` (1.0 = the reference's
     30 000 iterations; bench.py's `trained_like` block runs a tenth), random view order (Trainer.py:84), through `run_callbacks` on the tensors'
-    device. Returns the trained Gaussians and {'count_curve': [[iteration, count], ...], 'extent': ...}."""
+    device. `policy='mcmc'` is the configuration's USE_MCMC variant (the comments of fastergs_garden.yaml:69,79-83,100-101): MCMC initialisation
+    (scales x 0.1, opacity 0.5), relocation + 5 % growth per densification step up to `max_primitives`, densification until 24 900 and Morton order
+    until 25 000, no opacity reset, SGLD noise after every optimizer step, opacity and scale regularisation 0.01.
+    Returns the trained Gaussians and {'count_curve': [[iteration, count], ...], 'extent': ...}."""
+    assert policy in ('adc', 'mcmc')
+    mcmc = policy == 'mcmc'
     from .scenes import initialize_from_point_cloud
     from .trainer import training_iteration
     dev = views[0].w2c.device
@@ -345,14 +376,19 @@ def train_from_scratch(views, targets, bbox_lo: torch.Tensor, bbox_hi: torch.Ten
         z = cam[:, 2]
         x, y = cam[:, 0] / z * v.focal_x + v.center_x, cam[:, 1] / z * v.focal_y + v.center_y
         seen |= (z > v.near_plane) & (z < v.far_plane) & (x >= 0) & (x < v.width) & (y >= 0) & (y < v.height)
-    g = Gaussians(initialize_from_point_cloud(pts[seen].contiguous()), dev, active_sh_degree=0)
+    g = Gaussians(initialize_from_point_cloud(pts[seen].contiguous(), use_mcmc=mcmc), dev, active_sh_degree=0)
     centers = torch.stack([v.position for v in views])
     extent = float(1.1 * (centers - centers.mean(dim=0)).norm(dim=1).max())                 # Trainer.py:91
     lr = dict(__import__('harness.trainer', fromlist=['GARDEN_LR']).GARDEN_LR)
     lr['means_max_steps'] = max(1, int(round(lr['means_max_steps'] * schedule_scale)))
     g.training_setup(training_cameras_extent=extent, lr=lr)
-    reset_densification_info(g)
     schedule = dict(GARDEN_SCHEDULE)
+    if mcmc:
+        schedule.update(densification_end=24_900, morton_end=25_000)
+        ensure_state(g)
+        regularise = lambda: add_mcmc_regularisation_gradients(g, 0.01, 0.01)
+    else:
+        reset_densification_info(g)
     for k in ('densification_start', 'densification_end', 'densification_interval', 'opacity_reset_interval', 'morton_interval', 'morton_end', 'sh_interval'):
         schedule[k] = max(1, int(round(schedule[k] * schedule_scale)))
     dgen = torch.Generator().manual_seed(seed + 1)
@@ -360,13 +396,17 @@ def train_from_scratch(views, targets, bbox_lo: torch.Tensor, bbox_hi: torch.Ten
     for it in range(iterations):
         if max_gaussians and g.means.shape[0] >= max_gaussians:
             schedule['grad_threshold'] = float('inf')               # a budget guard (not in the reference): keeps pruning, stops cloning / splitting
-        stats = run_callbacks(g, it, schedule, dgen)
+        stats = run_mcmc_callbacks(g, it, schedule, max_primitives, dgen, ops) if mcmc else run_callbacks(g, it, schedule, dgen)
         if stats:
             curve.append([it, stats['total']])
         if it % len(views) == 0:
             order = torch.randperm(len(views), generator=gen).tolist()
         v = order[it % len(views)]
-        loss = training_iteration(g, views[v], targets[v], it, densification_end=schedule['densification_end'])
+        if mcmc:
+            loss = training_iteration(g, views[v], targets[v], it, densification_end=0, before_step=regularise)
+            post_optimizer_step(g, True, next(pg['lr'] for pg in g.optimizer.param_groups if pg['name'] == 'means'), ops)
+        else:
+            loss = training_iteration(g, views[v], targets[v], it, densification_end=schedule['densification_end'])
         if on_iteration is not None:
             on_iteration(it, loss)
     return g, {'count_curve': curve, 'extent': extent, 'schedule': schedule}

@@ -13,10 +13,11 @@ os.environ.setdefault('FGS_TOOL_DEVICE', 'cpu')
 import torch
 import helpers
 import FasterGSCudaBackend
-from FasterGSCudaBackend import _backend, rasterization
+from FasterGSCudaBackend import _backend, aux_ops, rasterization
 
 _backend._DEFAULT = helpers.sim_backend()
 rasterization._require_gpu = lambda t: None
+aux_ops._gpu = lambda t: None
 for name in ('synchronize', 'reset_peak_memory_stats', 'empty_cache'):
     setattr(torch.cuda, name, lambda *a, **k: None)
 for name in ('max_memory_allocated', 'max_memory_reserved'):

@@ -35,6 +35,9 @@ ap.add_argument('--max-seconds', type=float, default=0.0); ap.add_argument('--sa
 ap.add_argument('--eval-at', default='7000,15000,30000'); ap.add_argument('--async-forward', action='store_true')
 ap.add_argument('--width', type=int, default=1920); ap.add_argument('--height', type=int, default=1080)     # smaller images: dry runs only
 ap.add_argument('--schedule-scale', type=float, default=1.0, help='dry runs: every interval of the schedule times this')
+ap.add_argument('--ring-size', type=int, default=16, help='training cameras per ring (4 rings; a quarter as many held-out cameras on each of 2 rings): dry runs only')
+ap.add_argument('--policy', default='adc', choices=['adc', 'mcmc'], help="mcmc: the configuration's USE_MCMC variant (fastergs_garden.yaml:69,79-83,100-101; Trainer.py:120-165,199)")
+ap.add_argument('--max-primitives', type=int, default=1_000_000, help='MCMC: MAX_PRIMITIVES')
 a = ap.parse_args()
 dev = torch.device(os.environ.get('FGS_TOOL_DEVICE', 'cuda:0'))      # the CPU dry run under tests/sim/run_with_sim.py sets this to cpu
 W, H, FOCAL = a.width, a.height, 1420.0 * a.width / 1920.0
@@ -47,8 +50,9 @@ def ring(n, radius, height, phase):
 
 TARGET = (0.0, 1.3, 0.0) if a.gt_scene == 'surface' else (0.0, 0.3, 0.0)
 # y is down: a camera `height` above the ground plane sits at y = -height. Radii / heights keep every camera outside the scene's box.
-train_views = ring(16, 6.2, 1.0, 0.0) + ring(16, 6.6, 2.6, 0.5) + ring(16, 7.0, 4.2, 0.25) + ring(16, 6.0, 0.2, 0.75)
-held_views = ring(4, 6.4, 1.8, 0.3) + ring(4, 6.8, 3.4, 0.8)
+RS, RH = a.ring_size, max(1, a.ring_size // 4)
+train_views = ring(RS, 6.2, 1.0, 0.0) + ring(RS, 6.6, 2.6, 0.5) + ring(RS, 7.0, 4.2, 0.25) + ring(RS, 6.0, 0.2, 0.75)
+held_views = ring(RH, 6.4, 1.8, 0.3) + ring(RH, 6.8, 3.4, 0.8)
 train_views, held_views = [v.to(dev) for v in train_views], [v.to(dev) for v in held_views]
 
 t_setup = time.perf_counter()
@@ -70,12 +74,16 @@ for v in train_views:
     x, y = cam[:, 0] / z * v.focal_x + v.center_x, cam[:, 1] / z * v.focal_y + v.center_y
     seen |= (z > v.near_plane) & (z < v.far_plane) & (x >= 0) & (x < v.width) & (y >= 0) & (y < v.height)
 pts = pts[seen].contiguous()
-init = initialize_from_point_cloud(pts)
+init = initialize_from_point_cloud(pts, use_mcmc=a.policy == 'mcmc')
 g = T.Gaussians(init, dev, active_sh_degree=0)
 centers = torch.stack([v.position for v in train_views])
 extent = float(1.1 * (centers - centers.mean(dim=0)).norm(dim=1).max())                 # Trainer.py:91
 g.training_setup(training_cameras_extent=extent)
-D.reset_densification_info(g)
+mcmc = a.policy == 'mcmc'
+if mcmc:
+    D.ensure_state(g)
+else:
+    D.reset_densification_info(g)
 FGS.set_async_forward(a.async_forward)
 setup_s = time.perf_counter() - t_setup
 
@@ -90,6 +98,8 @@ def evaluate():
 
 eval_at = sorted({int(x) for x in a.eval_at.split(',') if x} | {a.iters})
 schedule = dict(D.GARDEN_SCHEDULE)
+if mcmc:
+    schedule.update(densification_end=24_900, morton_end=25_000)
 if a.schedule_scale != 1.0:
     for k in ('densification_start', 'densification_end', 'densification_interval', 'opacity_reset_interval', 'morton_interval', 'morton_end', 'sh_interval'):
         schedule[k] = max(1, int(round(schedule[k] * a.schedule_scale)))
@@ -107,14 +117,18 @@ for it in range(a.iters):
         schedule['grad_threshold'] = float('inf')        # density control keeps pruning, stops cloning / splitting (a budget guard, not in the reference)
         events.append(f'iteration {it}: {g.means.shape[0]} Gaussians >= --max-gaussians {a.max_gaussians}: growth stopped')
     tc = time.perf_counter()
-    stats = D.run_callbacks(g, it, schedule, dgen)
+    stats = D.run_mcmc_callbacks(g, it, schedule, a.max_primitives, dgen) if mcmc else D.run_callbacks(g, it, schedule, dgen)
     if stats:
         torch.cuda.synchronize(); t_cb += time.perf_counter() - tc
         curve.append([it, stats['total']])
     if it % len(order) == 0:
         order = torch.randperm(len(train_views), generator=gen).tolist()
     v = order[it % len(order)]
-    loss_sum += T.training_iteration(g, train_views[v], targets[v], it, densification_end=schedule['densification_end'])
+    if mcmc:
+        loss_sum += T.training_iteration(g, train_views[v], targets[v], it, densification_end=0, before_step=lambda: D.add_mcmc_regularisation_gradients(g, 0.01, 0.01))
+        D.post_optimizer_step(g, True, next(pg['lr'] for pg in g.optimizer.param_groups if pg['name'] == 'means'))
+    else:
+        loss_sum += T.training_iteration(g, train_views[v], targets[v], it, densification_end=schedule['densification_end'])
     done = it + 1
     if done % 100 == 0:
         s = float(loss_sum); loss_sum.zero_()
@@ -137,7 +151,9 @@ if a.save_ply:
     save_ply(g, a.save_ply)
 final = evals[str(done)]
 print(json.dumps({
-    'what': 'from-scratch full-schedule training run (tools/train_full.py): random initialisation + carving, fastergs_garden.yaml schedule uncompressed',
+    'what': 'from-scratch full-schedule training run (tools/train_full.py): random initialisation + carving, fastergs_garden.yaml schedule uncompressed'
+            + (f'; USE_MCMC variant (MAX_PRIMITIVES {a.max_primitives}, densification until 24 900, noise after every step, opacity / scale regularisation 0.01)' if mcmc else ''),
+    'policy': a.policy,
     'ground_truth': f'{a.gt_scene} scene (disk scale {a.disk_scale}, jitter {a.jitter}), {a.gt} Gaussians, {W}x{H}, {len(train_views)} training + {len(held_views)} held-out cameras', 'extent': extent,
     'init_points': a.points, 'gaussians_after_carving': curve[0][1], 'iterations_done': done, 'iterations_planned': a.iters,
     'gaussians_end': g.means.shape[0], 'gaussians_max': max(c[1] for c in curve), 'count_curve_every_10th_call': curve[::10] + [curve[-1]],
