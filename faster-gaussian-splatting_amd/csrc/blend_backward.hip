@@ -165,16 +165,16 @@ __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward
     // tail is bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles).
     const bool silent = ((ever >> lane) & 1ull) == 0;
     if (valid_prim && !silent) {                                           // kb:459-470
-        const size_t n = a.n;
-        unsafeAtomicAdd(a.acc + prim, d_mx);
-        unsafeAtomicAdd(a.acc + n + prim, d_my);
-        unsafeAtomicAdd(a.acc + 2 * n + prim, d_ca);
-        unsafeAtomicAdd(a.acc + 3 * n + prim, d_cb);
-        unsafeAtomicAdd(a.acc + 4 * n + prim, d_cc);
-        unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? d_op : op * (1.0f - op) * d_op);
-        unsafeAtomicAdd(a.acc + 6 * n + prim, d_c0);
-        unsafeAtomicAdd(a.acc + 7 * n + prim, d_c1);
-        unsafeAtomicAdd(a.acc + 8 * n + prim, d_c2);
+        float* const rec = a.acc + (size_t)prim * kAccRecordWords;         // the Gaussian's record of nine consecutive floats
+        unsafeAtomicAdd(rec, d_mx);
+        unsafeAtomicAdd(rec + 1, d_my);
+        unsafeAtomicAdd(rec + 2, d_ca);
+        unsafeAtomicAdd(rec + 3, d_cb);
+        unsafeAtomicAdd(rec + 4, d_cc);
+        unsafeAtomicAdd(rec + 5, a.proper_aa ? d_op : op * (1.0f - op) * d_op);
+        unsafeAtomicAdd(rec + 6, d_c0);
+        unsafeAtomicAdd(rec + 7, d_c1);
+        unsafeAtomicAdd(rec + 8, d_c2);
     }
 }
 
@@ -289,16 +289,16 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
         for (int k = 0; k < 9; ++k) t[k] = s_acc[0][tid][k] + s_acc[1][tid][k] + s_acc[2][tid][k];
         const uint32_t prim = s_prim[tid];
         const float op = s_b[tid].y;
-        const size_t n = a.n;
-        unsafeAtomicAdd(a.acc + prim, t[0]);
-        unsafeAtomicAdd(a.acc + n + prim, t[1]);
-        unsafeAtomicAdd(a.acc + 2 * n + prim, t[2]);
-        unsafeAtomicAdd(a.acc + 3 * n + prim, t[3]);
-        unsafeAtomicAdd(a.acc + 4 * n + prim, t[4]);
-        unsafeAtomicAdd(a.acc + 5 * n + prim, a.proper_aa ? t[5] : op * (1.0f - op) * t[5]);
-        unsafeAtomicAdd(a.acc + 6 * n + prim, t[6]);
-        unsafeAtomicAdd(a.acc + 7 * n + prim, t[7]);
-        unsafeAtomicAdd(a.acc + 8 * n + prim, t[8]);
+        float* const rec = a.acc + (size_t)prim * kAccRecordWords;         // the Gaussian's record of nine consecutive floats
+        unsafeAtomicAdd(rec, t[0]);
+        unsafeAtomicAdd(rec + 1, t[1]);
+        unsafeAtomicAdd(rec + 2, t[2]);
+        unsafeAtomicAdd(rec + 3, t[3]);
+        unsafeAtomicAdd(rec + 4, t[4]);
+        unsafeAtomicAdd(rec + 5, a.proper_aa ? t[5] : op * (1.0f - op) * t[5]);
+        unsafeAtomicAdd(rec + 6, t[6]);
+        unsafeAtomicAdd(rec + 7, t[7]);
+        unsafeAtomicAdd(rec + 8, t[8]);
     }
 }
 
@@ -550,24 +550,52 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         }
 
         // A Gaussian whose nine sums are all zero has nothing to add (it never passed the alpha test, or only at pixels with a zero
-        // image gradient); the kernel's tail is bound by atomic throughput on contended lines (near-camera Gaussians cover thousands of tiles).
+        // image gradient).
         const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
                             && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
-        if (valid_prim && !silent && !(a.ablate & 1)) {                                          // kb:459-470
-            // a hot Gaussian adds into its private replica (fgs_config.h); everybody else into the planes
-            const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
-            float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + prim;
-            const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
-            unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
-            unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
-            unsafeAtomicAdd(dst + 2 * plane, a_xx);
-            unsafeAtomicAdd(dst + 3 * plane, a_xy);
-            unsafeAtomicAdd(dst + 4 * plane, a_yy);
+        if (!(a.ablate & 1)) {                                                                   // kb:459-470
+            // The nine sums of a Gaussian leave as its RECORD of nine consecutive floats, SEVEN Gaussians per atomic instruction (lane l of
+            // instruction k adds word 63 k + l of the bucket's 64 x 9 block, transposed through the LDS the rings no longer need). Round 4: the
+            // memory pipeline merges the lanes of one atomic instruction that fall into one 128-byte line and is bound by LINE requests, about
+            // 20 000 per microsecond whatever they carry (tools/atomic_rate.hip: 64 scattered floats 20.8 k atomics / us, 64 consecutive ones 278 k).
+            // With one plane per sum (rounds 1-3) an item cost 9 instructions x as many lines as its 64 primitives are scattered over: hidden
+            // behind the arithmetic on a Morton-ordered synthetic scene, HALF of this kernel's time on a model trained under the MCMC policy
+            // (1.56 -> 0.81 ms, profiles/r04_k11_record_atomics.txt). Now: ~1.3 lines per Gaussian, 10 instructions per item.
             // dL/dopacity = sum G dL/dalpha with G = alpha / opacity; through the sigmoid unless proper antialiasing (kb:462-466)
-            unsafeAtomicAdd(dst + 5 * plane, a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op));
-            unsafeAtomicAdd(dst + 6 * plane, a_c0 * f0);
-            unsafeAtomicAdd(dst + 7 * plane, a_c1 * f1);
-            unsafeAtomicAdd(dst + 8 * plane, a_c2 * f2);
+            const float v5 = a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op);
+            const float v0 = 2.0f * (ca * a_x + cb * a_y), v1 = 2.0f * (cb * a_x + cc * a_y);
+            const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
+            const bool adds = valid_prim && !silent;
+            if (adds && hot_word != 0u) {                    // a hot Gaussian adds into its private replica (fgs_config.h), one plane per sum
+                float* dst = a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u);
+                unsafeAtomicAdd(dst, v0);
+                unsafeAtomicAdd(dst + kMaxHot, v1);
+                unsafeAtomicAdd(dst + 2 * kMaxHot, a_xx);
+                unsafeAtomicAdd(dst + 3 * kMaxHot, a_xy);
+                unsafeAtomicAdd(dst + 4 * kMaxHot, a_yy);
+                unsafeAtomicAdd(dst + 5 * kMaxHot, v5);
+                unsafeAtomicAdd(dst + 6 * kMaxHot, a_c0 * f0);
+                unsafeAtomicAdd(dst + 7 * kMaxHot, a_c1 * f1);
+                unsafeAtomicAdd(dst + 8 * kMaxHot, a_c2 * f2);
+            }
+            float* const s_t = reinterpret_cast<float*>(s_base + kPixBase);                      // [64][9] in the dead 16-byte ring
+            uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_base);                         // record index of each lane's Gaussian, or "nothing to add"
+            constexpr uint32_t kNoRecord = 0xffffffffu;
+            wave_lds_fence();                                                                     // the loop's last ring reads are done
+            float* const mine = s_t + lane * kAccRecordWords;
+            mine[0] = v0; mine[1] = v1; mine[2] = a_xx; mine[3] = a_xy; mine[4] = a_yy; mine[5] = v5;
+            mine[6] = a_c0 * f0; mine[7] = a_c1 * f1; mine[8] = a_c2 * f2;
+            s_off[lane] = (adds && hot_word == 0u) ? prim : kNoRecord;
+            wave_lds_fence();
+            const unsigned sub = lane / kAccRecordWords, comp = lane - sub * kAccRecordWords;     // lane 63 idles: 7 records of 9 words per instruction
+#pragma unroll
+            for (unsigned k = 0; k < (kBucket + 6u) / 7u; ++k) {
+                const unsigned gsn = 7u * k + sub;
+                if (lane < 63u && gsn < static_cast<unsigned>(kBucket)) {
+                    const uint32_t rec = s_off[gsn];
+                    if (rec != kNoRecord) unsafeAtomicAdd(a.acc + (size_t)rec * kAccRecordWords + comp, s_t[63u * k + lane]);
+                }
+            }
         }
 #ifdef FGS_PAIR_STATS
         if (lane == 0) {
@@ -882,8 +910,8 @@ __global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const Blend
                 tile_rect(__float_as_uint(gc.y), __float_as_uint(gc.z), tx0, tx1, ty0, ty1);
                 const unsigned footprint = (tx1 - tx0) * (ty1 - ty0);
                 const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
-                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + prim;
-                const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : static_cast<size_t>(a.n);
+                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + (size_t)prim * kAccRecordWords;
+                const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : 1u;             // replicas are planes, the Gaussian's own record nine consecutive floats
                 unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
                 unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
                 unsafeAtomicAdd(dst + 2 * plane, a_xx);
@@ -937,7 +965,7 @@ __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendB
     float sum = 0.0f;
 #pragma unroll
     for (unsigned r = 0; r < kHotReplicas; ++r) sum += a.acc_hot[((size_t)r * 9u + k) * kMaxHot + slot];
-    if (sum != 0.0f) a.acc[(size_t)k * a.n + a.hot_list[slot]] += sum;      // one slot per primitive: no other writer at this point
+    if (sum != 0.0f) a.acc[(size_t)a.hot_list[slot] * kAccRecordWords + k] += sum;      // one slot per primitive: no other writer at this point
 }
 
 std::atomic<int> g_k11m_max_blocks{FGS_K11M_MAX_BLOCKS};   // variant 4: upper bound of its grid (fgs_debug_set_option(13, n)); items beyond it are walked grid-stride

@@ -107,7 +107,7 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const float* final_T; const uint32_t* n_processed; const uint32_t* max_n_processed;
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
-    float* acc;                           // planar [9][N]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b)
+    float* acc;                           // records [N][9]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b) of each Gaussian, nine consecutive floats
     float* acc_hot;                       // [kHotReplicas][9][kMaxHot]: private accumulators of the hot Gaussians
     const uint32_t* hot_list; const uint32_t* hot_count;   // slot -> primitive, number of slots handed out (may exceed kMaxHot)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket and their number
@@ -124,7 +124,7 @@ struct AdamHyper { float step_size, beta1, beta2, eps, bc2_sqrt_rcp; };
 struct BackwardView {                   // what K12 needs per camera view (one on the single-GPU path, up to kMaxBatchViews on the sharded path)
     CameraArgs cam;
     const uint32_t* n_touched;            // [N] tile count of the view, 0 = invisible
-    const float* acc;                     // single view: planar [9][N] (K11's accumulators). Sharded path (several views per launch):
+    const float* acc;                     // single view: records [N][9] (K11's accumulators). Sharded path (several views per launch):
     const uint32_t* slot;                 //   the returned 9-float accumulator RECORDS, that of visible primitive i being record slot[i]
     float* view_dir;                      // [N][3] scratch: unit view direction of visible primitives, consumed by the SH-rest pass
 };

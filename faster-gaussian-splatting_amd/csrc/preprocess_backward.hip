@@ -67,9 +67,9 @@ __device__ __forceinline__ bool gaussian_backward(const PreprocessBackwardArgs& 
         }
         visible = true;
         const Camera cam = (MULTI && vw > 0) ? load_camera(V.cam) : cam0;
-        // single view: K11's planar accumulators [9][N]; sharded path: the returned record of this primitive, 9 contiguous floats
-        const float* const accp = MULTI ? V.acc + (size_t)V.slot[i] * kAccRecordWords : V.acc + i;
-        const size_t es = MULTI ? 1 : n;
+        // K11's record of this primitive, 9 contiguous floats: single view [N][9]; sharded path: the record that came back, found through the slot table
+        const float* const accp = V.acc + (size_t)(MULTI ? V.slot[i] : i) * kAccRecordWords;
+        constexpr size_t es = 1;
         const float gcol[3] = {accp[6 * es], accp[7 * es], accp[8 * es]};
         if (KEEP_DIR) { gcol_out[0] = gcol[0]; gcol_out[1] = gcol[1]; gcol_out[2] = gcol[2]; }
 
@@ -556,12 +556,12 @@ __device__ __forceinline__ PairGrad pair_gradient(const ShRestArgs& a, const ShR
     const uint32_t pair = pair_in < n_pairs ? pair_in : n_pairs - 1u;
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t gi = pair / R, k = pair - gi * R;
-    const size_t n = a.n;
     const uint32_t touched = V.n_touched[gi];
     const float x = V.view_dir[3 * (size_t)gi], y = V.view_dir[3 * (size_t)gi + 1], z = V.view_dir[3 * (size_t)gi + 2];
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    if (!RECORDS) {                      // K11's planar accumulators: always in bounds, requested together with everything else
-        c0 = V.acc[6 * n + gi]; c1 = V.acc[7 * n + gi]; c2 = V.acc[8 * n + gi];
+    if (!RECORDS) {                      // K11's own records [N][9]: always in bounds, requested together with everything else
+        const float* const accp = V.acc + (size_t)gi * kAccRecordWords;
+        c0 = accp[6]; c1 = accp[7]; c2 = accp[8];
     } else if (touched != 0) {           // sharded path: a record exists only for visible primitives (slot[] of the others is scratch)
         const float* const accp = V.acc + (size_t)V.slot[gi] * kAccRecordWords;
         c0 = accp[6]; c1 = accp[7]; c2 = accp[8];
@@ -597,7 +597,6 @@ __device__ __forceinline__ void sh_rest_block_to_lds(const ShRestArgs& a, const 
     const uint32_t R = RT > 0 ? static_cast<uint32_t>(RT) : a.total_sh_rest;
     const uint32_t gi = first + lane;
     const bool in_range = gi < a.n;
-    const size_t n = a.n;
     float g[kMaxRest][3];
 #pragma unroll
     for (int k = 0; k < kMaxRest; ++k) { g[k][0] = 0.0f; g[k][1] = 0.0f; g[k][2] = 0.0f; }
@@ -607,8 +606,8 @@ __device__ __forceinline__ void sh_rest_block_to_lds(const ShRestArgs& a, const 
         if (!in_range || V.n_touched[gi] == 0) continue;
         const float x = V.view_dir[3 * (size_t)gi], y = V.view_dir[3 * (size_t)gi + 1], z = V.view_dir[3 * (size_t)gi + 2];
         float c[3];
-        if (!MULTI) { c[0] = V.acc[6 * n + gi]; c[1] = V.acc[7 * n + gi]; c[2] = V.acc[8 * n + gi]; }       // planar accumulators
-        else { const float* r = V.acc + (size_t)V.slot[gi] * kAccRecordWords; c[0] = r[6]; c[1] = r[7]; c[2] = r[8]; }
+        const float* const r = V.acc + (size_t)(MULTI ? V.slot[gi] : gi) * kAccRecordWords;       // K11's record (sharded path: through the slot table)
+        c[0] = r[6]; c[1] = r[7]; c[2] = r[8];
         float B[kMaxRest];
 #pragma unroll
         for (int k = 0; k < kMaxRest; ++k) B[k] = 0.0f;                 // degrees above the active one keep a zero gradient

@@ -142,15 +142,15 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
     depth_keys[dst] = w6.x; prim_idx[dst] = dst; n_touched[dst] = w6.y;   // the visible list in slot order: equal depth keys keep that order through the stable sort
 }
 
-// planar accumulators [9][n] (what K11 adds into, by primitive slot) -> one 36-byte record per record j of the concatenation, ready to be cut into
-// per-shard segments
+// K11's accumulator records [n][9] (by primitive slot) -> the same 36-byte records in the order of the concatenation (record j), ready to be cut
+// into per-shard segments
 __global__ void __launch_bounds__(256) pack_acc_kernel(const float* __restrict__ acc, uint32_t n, float* __restrict__ out, const ShardOrder order) {
-    const uint32_t src = blockIdx.x * 256u + threadIdx.x;                     // thread = primitive slot: coalesced plane reads, the record is scattered
+    const uint32_t src = blockIdx.x * 256u + threadIdx.x;                     // thread = primitive slot: the wave reads 64 consecutive records, each is scattered
     if (src >= n) return;
     const uint32_t j = record_of_slot(src, order);
     float v[kAccRecordWords];
 #pragma unroll
-    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)k * n + src];
+    for (int k = 0; k < kAccRecordWords; ++k) v[k] = acc[(size_t)src * kAccRecordWords + k];
 #pragma unroll
     for (int k = 0; k < kAccRecordWords; ++k) out[(size_t)kAccRecordWords * j + k] = v[k];
 }

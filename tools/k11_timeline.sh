@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   make -C $C -j8 > /dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$C -I$R/include -Xclang -target-feature -Xclang -packed-fp32-ops \
       -DFGS_K11_TIMELINE -c $C/blend_backward.hip -o $C/_build/bb_timeline.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "blend_backward.o\|bb_timeline.o\|bf_timeline.o\|k1timer") $C/_build/bb_timeline.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "blend_backward.o\|/bb_\|/bf_\|k1timer") $C/_build/bb_timeline.o
   ls -la $LIB | awk '{print $5, $9}'
 else
   for shift in 0.0 -3.0; do FGS_HIP_LIBRARY=$LIB python $R/tools/k11_timeline.py $shift; done
