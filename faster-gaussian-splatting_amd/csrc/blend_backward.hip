@@ -956,7 +956,7 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_pair_stats(u
 namespace fgs {
 #endif
 
-// after K11: the hot Gaussians' replicas are summed and added to their entries of the nine planes (one thread per (slot, plane))
+// after K11: the hot Gaussians' replicas are summed and added to their records (one thread per (slot, sum))
 __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendBackwardArgs a) {
     const unsigned n_hot = min(*a.hot_count, kMaxHot);
     const unsigned e = blockIdx.x * 256u + threadIdx.x;

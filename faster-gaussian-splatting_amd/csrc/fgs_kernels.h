@@ -146,7 +146,7 @@ hipError_t launch_preprocess_backward(bool fused_adam, const PreprocessBackwardA
 
 struct ShRestView { const float* view_dir; const uint32_t* n_touched; const float* acc; const uint32_t* slot; };   // acc / slot as in BackwardView
 struct ShRestArgs {                     // the 45/59 of the per-Gaussian payload, streamed flat and fully coalesced
-    int n_views; ShRestView view[kMaxBatchViews];    // n_views > 1 or a slot table = the sharded path (records), else planar accumulators
+    int n_views; ShRestView view[kMaxBatchViews];    // n_views > 1 or a slot table = the sharded path (records found through the slot table), else K11's own records [N][9]
     float* grad_sh_rest;                  // unfused: [N][K-1][3] written for every primitive
     float* p; float* m; float* v; AdamHyper h;   // fused (one view)
     uint32_t n; uint32_t total_sh_rest; uint32_t active_sh_bases;

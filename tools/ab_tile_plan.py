@@ -3,16 +3,16 @@
   rows interleaved; key 11 = 1 restores the rocPRIM bucket scan (and with it the bands).
 Reports the stage times of blend_forward (training and inference), bucket_scan (= plan_tiles_kernel or the rocPRIM scan) and stage_pixels
 (= plan_blend_backward_kernel + stage_pixels_kernel), interleaved over 4 rounds so that clock / placement drift hits every variant alike."""
-import sys, torch
+import os, sys, torch
 sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd']
 import bench
 from FasterGSCudaBackend._backend import default_backend
 from harness import trainer as T
-sys.argv = ['bench.py']
+sys.argv = ['bench.py'] + (['--ply', os.environ['FGS_PLY']] if os.environ.get('FGS_PLY') else [])     # FGS_PLY: a trained scene instead of S2
 params, views, _ = bench.build_scene(bench.parse())
 dev = torch.device('cuda:0'); be = default_backend()
 VARIANTS = (('columns-top-down (default)', 252, 0, 0), ('bands', 0, 0, 0), ('bands+rocprim-scan', 0, 1, 0), ('plan', 254, 0, 0), ('rows1', 1, 0, 0))
-for shift in (0.0, -3.0):
+for shift in ((0.0,) if os.environ.get('FGS_PLY') else (0.0, -3.0)):
     p2 = dict(params); p2['opacities'] = params['opacities'] + shift
     g = T.Gaussians(p2, dev)
     g.training_setup(training_cameras_extent=5.0)

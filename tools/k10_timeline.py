@@ -6,7 +6,7 @@ shift = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 import bench
 from FasterGSCudaBackend._backend import default_backend
 from harness import trainer as T
-sys.argv = ['bench.py']
+sys.argv = ['bench.py'] + (['--ply', os.environ['FGS_PLY']] if os.environ.get('FGS_PLY') else [])     # FGS_PLY: a trained scene instead of S2
 params, views, _ = bench.build_scene(bench.parse())
 params['opacities'] = params['opacities'] + shift
 dev = torch.device('cuda:0'); be = default_backend()
