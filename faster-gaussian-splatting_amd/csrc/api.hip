@@ -401,6 +401,8 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
                   int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state) {
     if (int rc = check_settings(settings)) return rc;
     if (!state || n_primitives < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad state / n_primitives");
+    if (static_cast<uint64_t>(n_primitives) * kAccRecordWords + BackwardScratch::kHotFloats > 0xfffffff0ull)      // K11 addresses the accumulator records by 32-bit float offsets
+        return fail(FGS_ERR_INVALID_ARGUMENT, "n_primitives %d: more than 477 M Gaussians per backward pass are not supported", n_primitives);
     if (!prim_blob || !tile_blob || !scratch || (state->n_instances > 0 && !inst_blob) || (state->n_buckets > 0 && !bucket_blob))
         return fail(FGS_ERR_INVALID_ARGUMENT, "NULL scratch buffer");
     P.geo = geometry_of(settings->width, settings->height);

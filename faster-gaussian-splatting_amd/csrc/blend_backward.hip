@@ -566,26 +566,18 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             const float v0 = 2.0f * (ca * a_x + cb * a_y), v1 = 2.0f * (cb * a_x + cc * a_y);
             const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
             const bool adds = valid_prim && !silent;
-            if (adds && hot_word != 0u) {                    // a hot Gaussian adds into its private replica (fgs_config.h), one plane per sum
-                float* dst = a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u);
-                unsafeAtomicAdd(dst, v0);
-                unsafeAtomicAdd(dst + kMaxHot, v1);
-                unsafeAtomicAdd(dst + 2 * kMaxHot, a_xx);
-                unsafeAtomicAdd(dst + 3 * kMaxHot, a_xy);
-                unsafeAtomicAdd(dst + 4 * kMaxHot, a_yy);
-                unsafeAtomicAdd(dst + 5 * kMaxHot, v5);
-                unsafeAtomicAdd(dst + 6 * kMaxHot, a_c0 * f0);
-                unsafeAtomicAdd(dst + 7 * kMaxHot, a_c1 * f1);
-                unsafeAtomicAdd(dst + 8 * kMaxHot, a_c2 * f2);
-            }
+            // float offset of the record from a.acc: the Gaussian's own record, or -- a hot Gaussian (fgs_config.h) -- the record of its slot in the
+            // tile's replica (acc_hot follows acc in the scratch blob: [kHotReplicas][kMaxHot][9])
+            const uint32_t rec_off = hot_word != 0u ? static_cast<uint32_t>(a.acc_hot - a.acc) + ((tile % kHotReplicas) * kMaxHot + (hot_word - 1u)) * kAccRecordWords
+                                                    : prim * kAccRecordWords;
             float* const s_t = reinterpret_cast<float*>(s_base + kPixBase);                      // [64][9] in the dead 16-byte ring
-            uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_base);                         // record index of each lane's Gaussian, or "nothing to add"
+            uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_base);                         // record offset of each lane's Gaussian, or "nothing to add"
             constexpr uint32_t kNoRecord = 0xffffffffu;
             wave_lds_fence();                                                                     // the loop's last ring reads are done
             float* const mine = s_t + lane * kAccRecordWords;
             mine[0] = v0; mine[1] = v1; mine[2] = a_xx; mine[3] = a_xy; mine[4] = a_yy; mine[5] = v5;
             mine[6] = a_c0 * f0; mine[7] = a_c1 * f1; mine[8] = a_c2 * f2;
-            s_off[lane] = (adds && hot_word == 0u) ? prim : kNoRecord;
+            s_off[lane] = adds ? rec_off : kNoRecord;
             wave_lds_fence();
             const unsigned sub = lane / kAccRecordWords, comp = lane - sub * kAccRecordWords;     // lane 63 idles: 7 records of 9 words per instruction
 #pragma unroll
@@ -593,7 +585,7 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
                 const unsigned gsn = 7u * k + sub;
                 if (lane < 63u && gsn < static_cast<unsigned>(kBucket)) {
                     const uint32_t rec = s_off[gsn];
-                    if (rec != kNoRecord) unsafeAtomicAdd(a.acc + (size_t)rec * kAccRecordWords + comp, s_t[63u * k + lane]);
+                    if (rec != kNoRecord) unsafeAtomicAdd(a.acc + (size_t)rec + comp, s_t[63u * k + lane]);
                 }
             }
         }
@@ -910,8 +902,9 @@ __global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const Blend
                 tile_rect(__float_as_uint(gc.y), __float_as_uint(gc.z), tx0, tx1, ty0, ty1);
                 const unsigned footprint = (tx1 - tx0) * (ty1 - ty0);
                 const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
-                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * 9u) * kMaxHot + (hot_word - 1u) : a.acc + (size_t)prim * kAccRecordWords;
-                const size_t plane = hot_word != 0u ? static_cast<size_t>(kMaxHot) : 1u;             // replicas are planes, the Gaussian's own record nine consecutive floats
+                // the Gaussian's own record of nine consecutive floats, or (hot) the record of its slot in the tile's replica
+                float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * kMaxHot + (hot_word - 1u)) * kAccRecordWords : a.acc + (size_t)prim * kAccRecordWords;
+                constexpr size_t plane = 1;
                 unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
                 unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
                 unsafeAtomicAdd(dst + 2 * plane, a_xx);
@@ -960,11 +953,11 @@ namespace fgs {
 __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendBackwardArgs a) {
     const unsigned n_hot = min(*a.hot_count, kMaxHot);
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
-    const unsigned slot = e % kMaxHot, k = e / kMaxHot;          // consecutive threads: consecutive slots of one plane
-    if (slot >= n_hot || k >= 9u) return;
+    const unsigned slot = e / kAccRecordWords, k = e % kAccRecordWords;          // consecutive threads: the nine sums of a slot, then the next slot
+    if (slot >= n_hot) return;
     float sum = 0.0f;
 #pragma unroll
-    for (unsigned r = 0; r < kHotReplicas; ++r) sum += a.acc_hot[((size_t)r * 9u + k) * kMaxHot + slot];
+    for (unsigned r = 0; r < kHotReplicas; ++r) sum += a.acc_hot[((size_t)r * kMaxHot + slot) * kAccRecordWords + k];
     if (sum != 0.0f) a.acc[(size_t)a.hot_list[slot] * kAccRecordWords + k] += sum;      // one slot per primitive: no other writer at this point
 }
 

@@ -42,8 +42,8 @@ constexpr int kBlendBlock = kTilePixels;       // 3 waves
 constexpr int kBackwardWavesPerBlock = 1;      // 1 bucket per 64-thread workgroup: inactive buckets free their slot at once
 // "Hot" Gaussians: footprints above kHotFootprint candidate tiles (0.1 % of the visible ones at S2) are front-most in hundreds to
 // thousands of tiles, so K11 adds into their nine accumulators from as many waves -- and a 128-byte line of device memory retires
-// only ~1 atomic per ns (tools/atomic_rate.hip), with 32 Morton-neighbours sharing every line of a plane. They get kHotReplicas
-// private accumulator sets each (replica = tile mod kHotReplicas), folded into the planes after K11.
+// only ~1 atomic per ns (tools/atomic_rate.hip). They get kHotReplicas private records each (replica = tile mod kHotReplicas,
+// [replica][slot][9], written by the same record flush as everybody else's), folded into their own records after K11.
 constexpr unsigned kHotFootprint = 256;
 constexpr unsigned kMaxHot = 16384;            // more hot Gaussians than this: the rest accumulate directly (correct, only slower)
 constexpr unsigned kHotReplicas = 16;

@@ -108,7 +108,7 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     const uint32_t* bucket_tile; const float4* ckpt;
     float4* pixrec;                       // [T][192][2] staged per-pixel constants
     float* acc;                           // records [N][9]: d/d(mean2d.x, mean2d.y, conic a,b,c, opacity, colour r,g,b) of each Gaussian, nine consecutive floats
-    float* acc_hot;                       // [kHotReplicas][9][kMaxHot]: private accumulators of the hot Gaussians
+    float* acc_hot;                       // [kHotReplicas][kMaxHot][9]: private records of the hot Gaussians; follows acc in the scratch blob (K11 addresses both as float offsets from acc)
     const uint32_t* hot_list; const uint32_t* hot_count;   // slot -> primitive, number of slots handed out (may exceed kMaxHot)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket and their number
     uint32_t* live_offsets;                   // [T] first list slot of each tile (planning pass -> stage_pixels_kernel)
