@@ -164,11 +164,11 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         }
     }
 
-    // ---- medium footprints (33 .. kHugeFootprint candidate tiles): re-tested by this wave, 64 candidates per step, with
+    // ---- medium footprints (33 .. kBigInstanceFootprint candidate tiles): re-tested by this wave, 64 candidates per step, with
     // ballot-prefix write slots (kf:283-326) ----
     const unsigned count = tbw * (ty1 - ty0);
     const bool recompute = active && mask == 0u;
-    uint64_t pending = wave_ballot(recompute && count <= kHugeFootprint);
+    uint64_t pending = wave_ballot(recompute && count <= kBigInstanceFootprint);
     if (pending != 0) {
         const float4* rr = reinterpret_cast<const float4*>(rec + prim);
         const float4 r0 = rr[0], r1 = rr[1];
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     // ---- huge footprints go to a work list: depth order puts the nearest (largest) Gaussians next to each other, so
     // finishing them here would serialise tens of thousands of candidate tiles in a handful of waves (measured: +0.2 ms on
     // views with screen-filling Gaussians). A second kernel gives each of them a whole workgroup. ----
-    const bool is_big = recompute && count > kHugeFootprint;
+    const bool is_big = recompute && count > kBigInstanceFootprint;
     const uint64_t big_mask = wave_ballot(is_big);
     if (big_mask != 0) {
         const int leader = __ffsll(static_cast<unsigned long long>(big_mask)) - 1;

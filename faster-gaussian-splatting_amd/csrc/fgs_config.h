@@ -25,7 +25,14 @@ constexpr int kSubtileH = 4;                  // one wave64 covers a 16x4 strip 
 // --- CDNA4 work shapes ---
 constexpr int kWave = 64;
 constexpr int kBucket = 64;            // Gaussians per backward bucket = one wavefront (reference: 32 = one warp)
-constexpr unsigned kHugeFootprint = 1024;   // candidate tiles above which a footprint gets its own workgroup (K1 and K5)
+#ifndef FGS_HUGE_FOOTPRINT
+#define FGS_HUGE_FOOTPRINT 1024
+#endif
+constexpr unsigned kHugeFootprint = FGS_HUGE_FOOTPRINT;   // candidate tiles above which a footprint gets its own workgroup (K1; K5: kBigInstanceFootprint)
+#ifndef FGS_K5_BIG_FOOTPRINT
+#define FGS_K5_BIG_FOOTPRINT 256
+#endif
+constexpr unsigned kBigInstanceFootprint = FGS_K5_BIG_FOOTPRINT;   // K5: candidate tiles above which a footprint is expanded by a workgroup of the second kernel instead of by its wave
 constexpr int kSeqTiles = 0;           // 0 (default): K1 counts small footprints in flattened (Gaussian, candidate) order (preprocess.hip); n > 0: A/B reference,
 // the reference's scheme with n sequential candidates per lane --          // candidate tiles each lane tests itself before the wave cooperates (reference: 4, cfg:54; measured 4: 0.355 ms, 8: 0.300, 12: 0.252, 16: 0.248, 24: 0.256, 32: 0.269 on S2)
 // One packed counter atomic per workgroup (see preprocess.hip). Round 3: 256 instead of 512 threads -- a quarter of K1's wave time was spent
