@@ -352,4 +352,9 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k1_phases(unsign
     }
     return 0;
 }
+// the raw per-wave table ([wave][8] cycles, waves in launch order): for the distribution of a phase over the waves (is the kernel's time a tail?)
+extern "C" __attribute__((visibility("default"))) int fgs_debug_k1_phase_waves(unsigned long long* out, unsigned n_waves) {
+    if (n_waves > fgs::kK1TimerWaves) n_waves = fgs::kK1TimerWaves;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fgs::g_k1_phase), sizeof(unsigned long long) * 8u * n_waves) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   make -C $C -j8 > /dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$C -I$R/include -ffp-contract=off -DFGS_K1_PHASE_TIMER \
       -c $C/preprocess.hip -o $C/_build/preprocess_k1timer.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "preprocess.o\|preprocess_k1timer.o") $C/_build/preprocess_k1timer.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $(ls $C/_build/*.o | grep -v "/preprocess.o\|preprocess_k1timer.o\|/bb_\|/bf_") $C/_build/preprocess_k1timer.o
   ls -la $LIB | awk '{print $5, $9}'
 else
   FGS_HIP_LIBRARY=$LIB python $R/tools/k1_phase_timer.py
