@@ -347,3 +347,42 @@ def test_partial_optimizer_state_keeps_moments_row_aligned(sim_backend, device_p
         else:
             assert st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape, grp['name']
             assert float(st['exp_avg'][0].abs().max()) == 0.5        # survivors keep their moments
+
+
+def test_mcmc_regularisation_gradients_equal_autograd():
+    """Loss.py:17-18 with Model.py:136-142 under USE_MCMC: lambda * mean(sigmoid(opacities)) + lambda * mean(exp(scales)); the harness adds the analytic
+    gradient between backward and optimizer step (harness.densify.add_mcmc_regularisation_gradients)."""
+    g = _gaussians(120)
+    torch.manual_seed(5)
+    photometric = {k: torch.randn_like(getattr(g, k)) * 1e-3 for k in ('opacities', 'scales')}
+    for k, v in photometric.items():
+        getattr(g, k).grad = v.clone()
+    D.add_mcmc_regularisation_gradients(g, 0.01, 0.02)
+    o = g.opacities.detach().clone().requires_grad_(True)
+    s = g.scales.detach().clone().requires_grad_(True)
+    (0.01 * torch.sigmoid(o).mean() + 0.02 * torch.exp(s).mean()).backward()
+    assert torch.allclose(g.opacities.grad, photometric['opacities'] + o.grad, rtol=1e-6, atol=1e-10)
+    assert torch.allclose(g.scales.grad, photometric['scales'] + s.grad, rtol=1e-6, atol=1e-10)
+    before = g.opacities.grad.clone()
+    D.add_mcmc_regularisation_gradients(g, 0.0, 0.0)                      # the configuration's default lambdas: nothing happens
+    assert torch.equal(g.opacities.grad, before)
+
+
+def test_run_mcmc_callbacks_follow_the_schedule():
+    """Trainer.py:114-165 under USE_MCMC: SH degree every interval, relocation / growth inside the densification window only, Morton order until its
+    end, never an opacity reset."""
+    g = _gaussians(200)
+    g.active_sh_degree = 0
+    sched = dict(D.GARDEN_SCHEDULE, densification_start=2, densification_end=6, densification_interval=2, morton_interval=4, morton_end=8, sh_interval=3,
+                 opacity_reset_interval=2)
+    gen = torch.Generator().manual_seed(3)
+    logits = g.opacities.detach().clone()
+    counts, degrees = [], []
+    for it in range(10):
+        out = D.run_mcmc_callbacks(g, it, sched, cap_max=230, generator=gen, ops=_sim_ops())
+        counts.append(None if out is None else out['total'])
+        degrees.append(g.active_sh_degree)
+    assert [c is not None for c in counts] == [False, False, True, False, True, False, True, False, False, False]      # iterations 2, 4, 6
+    assert counts[2] == 210 and counts[4] == 220 and counts[6] == 230                                                   # + 5 % per step up to the cap
+    assert degrees[2] == 0 and degrees[3] == 1 and degrees[6] == 2 and degrees[9] == 3
+    assert float(g.opacities.detach().max()) >= float(logits.max()) - 1e-6                                             # no reset to logit(0.01)
