@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const Blend
         }
         wave_lds_fence();
 
-        // ---- per Gaussian (lane = Gaussian again): moments about the tile centre -> the nine gradients, added to the planes (kb:459-470) ----
+        // ---- per Gaussian (lane = Gaussian again): moments about the tile centre -> the nine gradients, added to the Gaussian's record (kb:459-470) ----
         if (lane < n_here) {
             const float Sh = s_acc[lane], Sx = s_acc[kBucket + lane], Sy = s_acc[2 * kBucket + lane];
             const float Sxx = s_acc[3 * kBucket + lane], Sxy = s_acc[4 * kBucket + lane], Syy = s_acc[5 * kBucket + lane];
@@ -904,16 +904,15 @@ __global__ void __launch_bounds__(kWave) blend_backward_pixel_kernel(const Blend
                 const uint32_t hot_word = footprint > kHotFootprint ? hot_slot_word : 0u;
                 // the Gaussian's own record of nine consecutive floats, or (hot) the record of its slot in the tile's replica
                 float* dst = hot_word != 0u ? a.acc_hot + ((size_t)(tile % kHotReplicas) * kMaxHot + (hot_word - 1u)) * kAccRecordWords : a.acc + (size_t)prim * kAccRecordWords;
-                constexpr size_t plane = 1;
                 unsafeAtomicAdd(dst, 2.0f * (ca * a_x + cb * a_y));
-                unsafeAtomicAdd(dst + plane, 2.0f * (cb * a_x + cc * a_y));
-                unsafeAtomicAdd(dst + 2 * plane, a_xx);
-                unsafeAtomicAdd(dst + 3 * plane, a_xy);
-                unsafeAtomicAdd(dst + 4 * plane, a_yy);
-                unsafeAtomicAdd(dst + 5 * plane, a.proper_aa ? -2.0f * Sh / op : -2.0f * Sh * (1.0f - op));
-                unsafeAtomicAdd(dst + 6 * plane, (flags & 1u) ? c0 : 0.0f);
-                unsafeAtomicAdd(dst + 7 * plane, (flags & 2u) ? c1 : 0.0f);
-                unsafeAtomicAdd(dst + 8 * plane, (flags & 4u) ? c2 : 0.0f);
+                unsafeAtomicAdd(dst + 1, 2.0f * (cb * a_x + cc * a_y));
+                unsafeAtomicAdd(dst + 2, a_xx);
+                unsafeAtomicAdd(dst + 3, a_xy);
+                unsafeAtomicAdd(dst + 4, a_yy);
+                unsafeAtomicAdd(dst + 5, a.proper_aa ? -2.0f * Sh / op : -2.0f * Sh * (1.0f - op));
+                unsafeAtomicAdd(dst + 6, (flags & 1u) ? c0 : 0.0f);
+                unsafeAtomicAdd(dst + 7, (flags & 2u) ? c1 : 0.0f);
+                unsafeAtomicAdd(dst + 8, (flags & 4u) ? c2 : 0.0f);
             }
         }
         wave_lds_fence();                                                      // the next item restages the records and clears the accumulators

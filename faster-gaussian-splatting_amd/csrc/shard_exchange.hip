@@ -18,8 +18,8 @@ static_assert(kSplatRecordWords == 14 && sizeof(PrimRec) == 48, "a splat record 
 
 // One lane per visible Gaussian j of a (shard, view); grid.y = view; `counts_out` = (V, I). Record order = the order K1
 // compacted the visible list in, with one exception: K1 appends the huge-footprint Gaussians (thousands of tiles each -- the
-// heavy hitters of K11's atomics) as ONE run at the end, and 32 neighbours in record order share a 128-byte line of every
-// accumulator plane on the renderer (measured: K11 0.71 -> 0.97 ms on views with ~200 of them). They trade places with
+// heavy hitters of K11's atomics) as ONE run at the end, and neighbours in record order share the 128-byte lines of the
+// accumulators on the renderer (measured with one plane per sum, rounds 2-3: K11 0.71 -> 0.97 ms on views with ~200 of them). They trade places with
 // evenly spaced regular records instead. slot[i] = record index of visible primitive i, for fgs_shard_backward.
 __global__ void __launch_bounds__(256) pack_splat_records_kernel(const PackRecordsBatch b) {
     const PackRecordsView& w = b.v[blockIdx.y];
