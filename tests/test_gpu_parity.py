@@ -437,6 +437,46 @@ def test_s3_six_million_against_oracle(hip_backend, oracle):
     _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[5], 'S3', adam_steps=0)
 
 
+@pytest.mark.parametrize('K,aa', [(4, False), (16, True)])
+def test_s1_sh_degree_one_and_proper_antialiasing_against_oracle(hip_backend, oracle, K, aa):
+    """active_sh_bases < 16 and proper_antialiasing=True at a BASELINE size (S1 = 1 M Gaussians, 1920x1080), not only on the
+    3e5-Gaussian fuzz scenes: forward, six gradients, densification_info flip-aware to 1e-4 (kf:148-155 the opacity compensation, sh:14-68 the
+    degree cut; kb:15-257 their derivatives)."""
+    params = make_garden_like(1_000_000)
+    _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[2], f'S1 K={K} aa={int(aa)}', adam_steps=0, K=K, aa=aa)
+
+
+@pytest.mark.parametrize('to_chw,clamp', [(True, True), (False, True), (False, False)])
+def test_inference_at_s2_against_oracle(hip_backend, oracle, to_chw, clamp):
+    """VERDICT r4 missing #4: the inference kernels (ki:14-207 colour clamped at store, no n_touched clearing; ki:348-463 CHW / HWC epilogue,
+    optional output clamp) against oracle.forward(inference=True) at the size bench.py's render leg times (S2 = 3 M Gaussians, 1080p), not only at
+    S0 size. Flip-aware: the pixels that own a (pixel, Gaussian) pair on the alpha / transmittance thresholds come from the oracle's training
+    forward of the same scene (the tests depend on geometry and opacity only) and are counted and excluded; everything else to 1e-4."""
+    from FasterGSCudaBackend import rasterize
+    params = make_garden_like(3_000_000)
+    params['sh_coefficients_0'] = params['sh_coefficients_0'] * 2.0          # push colours beyond [0, 1] on both sides: the colour clamp at
+    params['sh_coefficients_0'][::3] += 4.0                                  # store (ki:200) and the output clamp (ki:445-449) must both matter
+    view = orbit_views(8)[3]
+    S, RS = helpers.settings_pair(view, bg=(0.3, 0.1, 0.9), device=DEV)
+    dp = _to(params)
+    img = rasterize(*[dp[k] for k in helpers.NAMES], RS, to_chw, clamp).cpu().numpy()
+    f_inf = oracle.forward(*helpers.np_params(params), S, inference=True, to_chw=to_chw, clamp_output=clamp)
+    f_train = oracle.forward(*helpers.np_params(params), S, bucket_size=64)
+    pm = helpers.flip_masks(oracle, f_train, S)['pixel']
+    assert img.shape == f_inf['image'].shape
+    chw = lambda x: x if to_chw else np.moveaxis(x, -1, 0)
+    err = np.abs(chw(img).astype(np.float64) - chw(f_inf['image'])).max(axis=0)
+    scale = max(1.0, float(np.abs(f_inf['image']).max()))
+    helpers.log_note('inference_s2', f'{float(err[~pm].max() / scale):.3e}', to_chw=int(to_chw), clamp=int(clamp), masked=f'{float(pm.mean()):.3e}',
+                     masked_max=f'{float(err[pm].max() / scale) if pm.any() else 0.0:.3e}')
+    assert float(pm.mean()) < 1e-3 and float(err[~pm].max()) < 1e-4 * scale, (float(pm.mean()), float(err[~pm].max()), scale)
+    assert not pm.any() or float(err[pm].max()) < 5e-2 * scale
+    if clamp:
+        assert float(img.max()) <= 1.0 and float(img.min()) >= 0.0
+    else:
+        assert float(f_inf['image'].max()) > 1.0                               # the scene does exceed 1 where nothing clamps the output
+
+
 def test_full_size_properties(hip_backend):
     """BASELINE.json full size (1920x1080, 1 M Gaussians): size-independent properties instead of an oracle run."""
     params = make_garden_like(1_000_000)

@@ -106,9 +106,11 @@ def test_shard_backward_sums_views_on_device(hip_backend):
             assert helpers.rel_inf(g.cpu().numpy(), t[s::2].cpu().numpy()) < 1e-4, (k, s)
 
 
-@pytest.mark.parametrize('fused', [True, False])
-def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
-    """4 owners x 4 views, 3 steps, against ViewParallelTrainer summing the four per-view gradients itself."""
+@pytest.mark.parametrize('fused,steps', [(True, 3), (False, 3), (True, 1), (False, 1)])
+def test_local_shard_group_equals_replicated_trainer(hip_backend, fused, steps):
+    """4 owners x 4 views against ViewParallelTrainer summing the four per-view gradients itself: ONE step held to the strict 1e-4 max-norm bar
+    (alpha-test flips cannot compound inside one step: a regression in record_of_slot / pack_acc that hits a few records fails here), and three steps
+    with the drift allowance explained below (VERDICT r4 weak #5, advisor finding on this file)."""
     from harness.distributed import SEGMENTS, ViewParallelTrainer
     from harness.sharded import LocalShardGroup
     params = {k: v.to(DEV) for k, v in make_garden_like(40_000).items()}
@@ -131,7 +133,7 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
             o, n, shape = t.layout[k]
             t.exp_avg[o:o + n].view(shape).copy_(m0[s::4])
             t.exp_avg_sq[o:o + n].view(shape).copy_(v0[s::4])
-    for _ in range(3):
+    for _ in range(steps):
         grp.step(RS, targets)
         tr.step_count += 1
         total = torch.zeros_like(tr.grad_arena)
@@ -148,6 +150,10 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend, fused):
         # over THREE steps: a parameter moved by 1e-7 flips an alpha >= 1/255 decision somewhere in the next render, and the Gaussians of that pixel then
         # differ at the 1e-4 level (which entries do depends on the noise: the interleaved record placement of round 4 moved the worst one from below to
         # above 1e-4). So: all but 1e-4 of the entries within 1e-4 of the largest update, none beyond 2e-3.
+        helpers.log_note('sharded_vs_replicated', f'{helpers.rel_inf(d_got, d_ref):.3e}', tensor=k, steps=steps, fused=int(fused))
+        if steps == 1:
+            assert helpers.rel_inf(d_got, d_ref) < 1e-4, (k, helpers.rel_inf(d_got, d_ref))
+            continue
         assert helpers.outlier_fraction(d_got, d_ref, 0.0, 1e-4 * float(np.abs(d_ref).max())) < 1e-4, (k, 'entries beyond 1e-4 of the largest update')
         assert helpers.rel_inf(d_got, d_ref) < 2e-3, (k, helpers.rel_inf(d_got, d_ref))
     info = torch.cat([t.densification_info for t in grp.ranks], dim=1)
