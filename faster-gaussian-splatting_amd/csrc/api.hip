@@ -105,6 +105,7 @@ Geometry geometry_of(int width, int height) {
 
 struct PrimitiveBuffers {             // cf. bu:45-94
     PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters; uint32_t* hot_list;
+    uint4* foot[2]; uint32_t* tile_counts;      // footprint rows in compaction / depth order, tile counts in depth order (fgs_math.h, radix_sort.hip)
     char* temp; size_t temp_bytes;
     static PrimitiveBuffers carve(Carver& c, uint32_t n) {
         PrimitiveBuffers b;
@@ -115,6 +116,8 @@ struct PrimitiveBuffers {             // cf. bu:45-94
         b.offsets = c.take<uint32_t>("offsets", n);
         b.counters = c.take<uint32_t>("counters", kCounterWords);
         b.hot_list = c.take<uint32_t>("hot_list", kMaxHot);
+        b.foot[0] = c.take<uint4>("foot0", n); b.foot[1] = c.take<uint4>("foot1", n);
+        b.tile_counts = c.take<uint32_t>("tile_counts", n);
         b.temp_bytes = depth_sort_temp_bytes(n);
         b.temp = c.take<char>("sort_temp", b.temp_bytes);
         return b;
@@ -281,7 +284,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     PreprocessArgs pa{};
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
-    pa.hot_list = pb.hot_list;
+    pa.hot_list = pb.hot_list; pa.foot = pb.foot[0];
     pa.n = n; pa.cam = camera_of(*settings, geo); pa.ranges = tb.ranges; pa.n_tiles = geo.n_tiles; pa.seq_tiles = g_seq_tiles;
     if (n == 0) FGS_HIP(hipMemsetAsync(tb.ranges, 0, sizeof(uint2) * geo.n_tiles, stream));   // no preprocess launch to clear them
     { StageScope t(ST_PREPROCESS, stream); FGS_HIP(launch_preprocess(!training, pa, stream)); }
@@ -289,12 +292,10 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     if (instance_capacity > 0) {
         // Host-synchronisation-free form (fgs_forward_async): nothing is read back. Every launch behind K1 is sized by a bound -- the
         // primitive count for the visible list, the caller's capacity for the instance stages -- and reads the exact count on the device.
-        if (!depth_sort_takes_device_count() || !tile_sort_takes_device_count())
-            return fail(FGS_ERR_INVALID_ARGUMENT, "the synchronisation-free forward needs the built-in radix sort for both sorts (fgs_debug_set_option(6, 3))");
         int depth_sel = 0;
         if (n > 0) {
             StageScope t(ST_DEPTH_SORT, stream);
-            FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), stream));
+            FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream));
         }
         return forward_tail(mode, pb, tb, geo, n, static_cast<uint32_t>(instance_capacity), depth_sel, settings, image, to_chw, clamp_output, resize, user,
                             state_out, stream, scores, true);
@@ -309,9 +310,9 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     FGS_HIP(hipMemcpyAsync(host, pb.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     FGS_HIP(hipEventRecord(ready, stream));
     int depth_sel = -1;
-    if (n > 0 && depth_sort_takes_device_count()) {
+    if (n > 0) {
         StageScope t(ST_DEPTH_SORT, stream);
-        FGS_HIP(run_depth_sort_device_count(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), stream));
+        FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream));
     }
     FGS_HIP(hipEventSynchronize(ready));
     const uint32_t n_visible = host[0], n_instances = host[1];
@@ -331,9 +332,9 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     const uint32_t* const visible_ptr = device_counts ? pb.counters : nullptr;
     const uint32_t* const instances_ptr = device_counts ? pb.counters + 5 : nullptr;
     // K2-K4 (fwd:104-127)
-    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, depth_key_range(settings->near_plane, settings->far_plane), stream)); }
+    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, visible_ptr, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
-    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, sorted_prims, pb.n_touched, pb.offsets, n_visible, visible_ptr, stream)); }
+    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, pb.tile_counts, pb.offsets, n_visible, visible_ptr, stream)); }
 
     // K5-K7 (fwd:179-216)
     Carver inst_size(nullptr);
@@ -342,7 +343,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
-    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, sorted_prims, pb.offsets, pb.n_touched, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
+    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, pb.foot[1], sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
                                                                                  visible_ptr, device_counts ? n_instances : 0xffffffffu, pb.counters,
                                                                                  pb.keys[depth_sel ^ 1], pb.counters + 2, stream)); }
     int tile_sel = 0;
@@ -628,7 +629,7 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
             FGS_HIP(hipMemsetAsync(b.counters, 0, kCounterWords * sizeof(uint32_t), stream));
             PreprocessArgs& pa = pb.v[k];
             pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
-            pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets; pa.hot_list = b.hot_list;
+            pa.rec = b.rec; pa.n_touched = b.n_touched; pa.depth_keys = b.keys[0]; pa.prim_idx = b.prims[0]; pa.counters = b.counters; pa.huge_list = b.offsets; pa.hot_list = b.hot_list; pa.foot = nullptr;
             pa.count_appended = 1; pa.seq_tiles = g_seq_tiles;
             pa.n = n; pa.cam = camera_of(settings[v], geo); pa.ranges = nullptr; pa.n_tiles = 0;   // the tile ranges belong to the renderer of the view
             // slot table for fgs_shard_backward: the second depth-key buffer is free on this path (no sort on the owner)
@@ -688,7 +689,7 @@ int32_t fgs_forward_from_shard_records(const void* records, int32_t n_records, i
     PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
     FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
     { StageScope t(ST_RECORDS, stream);
-      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, order, stream)); }
+      FGS_HIP(launch_unpack_splat_records(static_cast<const uint32_t*>(records), n, pb.rec, pb.n_touched, pb.keys[0], pb.prims[0], pb.foot[0], tb.ranges, geo.n_tiles, pb.hot_list, pb.counters + 4, order, stream)); }
     return forward_tail(MODE_TRAINING, pb, tb, geo, n, static_cast<uint32_t>(n_instances), -1, settings, image, 1, 0, resize, resize_user, state_out, stream, nullptr);
 }
 
@@ -1095,7 +1096,6 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 7: fgs::g_backward_ablate = value & 15; return FGS_OK;
         case 13: if (value < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "K11 variant 4 needs at least one workgroup"); fgs::g_k11m_max_blocks = value; return FGS_OK;
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
-        case 6: fgs::g_sort_implementation = value & 3; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
         case 10: if (value < 0 || (value > 64 && (value < 251 || value > 255))) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
                  fgs::g_tile_row_group = value; return FGS_OK;

@@ -2,96 +2,69 @@
 //   depth sort (32-bit keys) -> exclusive scan of tile counts in depth order -> instance creation (exact overlap)
 //   -> stable tile sort on end_bit bits -> per-tile [start,end) ranges -> inclusive scan of per-tile bucket counts.
 // Semantics: reference rasterization/src/forward.cu:104-231 + kernels_forward.cuh:211-360 (two-stage "Splatshop" sort,
-// no 64-bit tile|depth key). The two sorts are radix_sort.hip (rocPRIM's onesweep stays selectable for A/B runs), the scans
-// use rocPRIM (the native AMD device primitives); the gather of K3
-// (apply_depth_ordering_cu) and the bucket-count kernel K8 are folded into the scans as transform iterators, so two
-// kernel launches and two V/T-sized round trips through HBM disappear.
+// no 64-bit tile|depth key). Both sorts are radix_sort.hip; the offsets scan is rocPRIM's (the native AMD device primitive).
+// Round 5: the depth sort's last scatter pass carries a 16-byte FOOTPRINT ROW per visible Gaussian (tile box + exact-overlap
+// bitmap, fgs_math.h) into depth order and writes its tile count beside it, so the scan (K3 + K4: apply_depth_ordering_cu + ExclusiveSum)
+// and the instance kernel (K5) read streams: until round 4 both gathered a 128-byte line per Gaussian for 4 / 16 useful bytes
+// (rocprofv3: K5 fetched 3.2x its algorithmic bytes).
 // Built with -ffp-contract=off (the exact-overlap test must agree bit-for-bit with the one in preprocess.hip).
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 #include "fgs_tile_scan.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
-#include <rocprim/types/double_buffer.hpp>
 
 namespace fgs {
 
 // ---- K2-K4 -------------------------------------------------------------------------------------------------
-struct TouchedFromRec {                  // offsets input: n_touched of the i-th primitive in depth order (kf:211-221)
-    const uint32_t* n_touched;           // compact 4-byte array (L2-resident gather), not the 48-byte records
-    __host__ __device__ uint32_t operator()(uint32_t prim) const { return n_touched[prim]; }
-};
-
 size_t depth_sort_temp_bytes(uint32_t n) {
-    size_t sort_bytes = 0, scan_bytes = 0;
-    rocprim::double_buffer<uint32_t> k(nullptr, nullptr), v(nullptr, nullptr);
-    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k, v, n, 0u, 32u);
-    const size_t own = own_sort_temp_bytes(n, 32);                         // radix_sort.hip; either implementation fits
-    sort_bytes = own > sort_bytes ? own : sort_bytes;
-    auto in = rocprim::make_transform_iterator(static_cast<const uint32_t*>(nullptr), TouchedFromRec{nullptr});
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, in, static_cast<uint32_t*>(nullptr), 0u, n, rocprim::plus<uint32_t>());
+    size_t scan_bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, n, rocprim::plus<uint32_t>());
+    const size_t sort_bytes = own_sort_temp_bytes(n, 32);
     return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
 }
 
-hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                          uint32_t n_visible, DepthKeyRange range, hipStream_t s) {
+hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
+                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s) {
     selector = 0;
     if (n_visible == 0) return hipSuccess;
-    if (g_sort_implementation & 2) return own_depth_sort(temp, temp_bytes, keys, vals, selector, n_visible, nullptr, range, s);
-    rocprim::double_buffer<uint32_t> k(keys[0], keys[1]), v(vals[0], vals[1]);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n_visible, 0u, 32u, s);
-    if (e != hipSuccess) return e;
-    selector = (v.current() == vals[0]) ? 0 : 1;
-    return hipSuccess;
+    const SortPayload payload{foot[0], foot[1], tile_counts, 0};
+    return own_depth_sort(temp, temp_bytes, keys, vals, selector, n_visible, n_visible_ptr, range, s, &payload);
 }
 
-bool depth_sort_takes_device_count() { return (g_sort_implementation & 2) != 0; }
-hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                                       uint32_t capacity, const uint32_t* n_visible_ptr, DepthKeyRange range, hipStream_t s) {
-    return own_depth_sort(temp, temp_bytes, keys, vals, selector, capacity, n_visible_ptr, range, s);
-}
-
-// the same input when the host does not know the visible count: entries at and beyond *count contribute nothing
-struct TouchedGuarded {
-    const uint32_t* sorted_prims; const uint32_t* n_touched; const uint32_t* count;
-    __host__ __device__ uint32_t operator()(uint32_t i) const { return i < *count ? n_touched[sorted_prims[i]] : 0u; }
+// the scan input when the host does not know the visible count: entries at and beyond *count contribute nothing
+struct CountGuarded {
+    const uint32_t* tile_counts; const uint32_t* count;
+    __host__ __device__ uint32_t operator()(uint32_t i) const { return i < *count ? tile_counts[i] : 0u; }
 };
 
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
+hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* tile_counts, uint32_t* offsets,
                             uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;
     if (n_visible_ptr != nullptr) {       // n_visible is a bound (the primitive count), the exact count lives on the device
-        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TouchedGuarded{sorted_prims, n_touched, n_visible_ptr});
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), CountGuarded{tile_counts, n_visible_ptr});
         return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
     }
-    auto in = rocprim::make_transform_iterator(sorted_prims, TouchedFromRec{n_touched});
-    return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
+    return rocprim::exclusive_scan(temp, temp_bytes, tile_counts, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
 }
 
 // ---- K5 ----------------------------------------------------------------------------------------------------
 // Emits (tile key, primitive) for every exactly-overlapped tile of every depth-sorted visible primitive, in row-major
 // order over its tile bounding box (kf:225-328). CDNA4 shape: a wave owns 64 consecutive primitives, whose outputs form
-// ONE contiguous range [offset(first), offset(last)+n). Small footprints (<= 32 candidate tiles -- the common case) carry
-// their exact-overlap bitmap from preprocess, so nothing is re-tested: the wave walks its output range 64 slots at a
-// time, each lane finds the owning primitive by a 6-step search over the wave's offsets in LDS and decodes the r-th set
-// bit of its bitmap -- every store instruction covers 64 consecutive slots. Larger footprints are re-tested by the
-// whole wave, 64 candidate tiles per step, with ballot-prefix write slots (also consecutive).
-__device__ __forceinline__ unsigned nth_set_bit(uint32_t m, unsigned r) {   // position of the r-th (0-based) set bit of m
-    unsigned pos = 0;
-#pragma unroll
-    for (unsigned w = 16; w >= 1; w >>= 1) {
-        const unsigned c = static_cast<unsigned>(__popc(m & ((1u << w) - 1u)));
-        if (r >= c) { r -= c; m >>= w; pos += w; }
-    }
-    return pos;
-}
-
+// ONE contiguous range [offset(first), offset(last)+n), and reads their footprint rows (fgs_math.h) as a stream. Boxes of
+// <= 64 candidate tiles (99 % of the visible Gaussians and 85 % of the instances at S2) carry their exact-overlap bitmap from
+// preprocess, so nothing is re-tested and no record is touched. Round 5: the wave walks the CANDIDATE tiles of its bitmap
+// footprints laid end to end, 64 per step (rounds 1-4 walked the output slots: a 6-step owner search in LDS plus a 5-step
+// "r-th set bit" per slot, ~80 vector instructions per step). Every footprint sets one head bit at its first candidate
+// slot; a lane finds its owner as (heads before the step) + (head bits at or below its lane) -- one broadcast LDS read
+// and an mbcnt --, tests its candidate's bit of the owner's bitmap and writes to (owner's first output slot) + (set bits
+// below): consecutive lanes store ascending addresses with the unset candidates left out. Escape rows (larger boxes) are
+// re-tested from the record by the whole wave, 64 candidate tiles per step, with ballot-prefix write slots (also consecutive).
 template <typename KeyT>
 __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
-    const uint32_t* __restrict__ sorted_prims, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ n_touched,
+    const uint4* __restrict__ foot, const uint32_t* __restrict__ offsets,
     const PrimRec* __restrict__ rec, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w,
     const uint32_t n_visible_value, const uint32_t* __restrict__ n_visible_ptr, const uint32_t capacity, uint32_t* __restrict__ counters,
     uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
@@ -105,73 +78,73 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         counters[6] = n_instances > capacity ? 1u : 0u;
     }
     constexpr int kWaves = kInstanceBlock / kWave;
-    __shared__ uint32_t s_off[kWaves][kWave];         // global write offset of each primitive
-    __shared__ uint32_t s_loc[kWaves][kWave];         // wave-local slot of each bitmap primitive's first instance
-    __shared__ uint32_t s_mask[kWaves][kWave];        // overlap bitmap (0: large footprint or padding lane)
-    __shared__ uint32_t s_prim[kWaves][kWave];
-    __shared__ uint32_t s_org[kWaves][kWave];         // tile-box origin: tx0 | ty0 << 16
-    __shared__ uint32_t s_div[kWaves][kWave];         // box width | ceil(2^16 / width) << 8   (width <= 32)
+    // per bitmap footprint of the wave, compacted (index = its rank among the wave's bitmap footprints):
+    __shared__ uint4 s_pack[kWaves][kWave];           // first candidate slot, overlap bitmap (2 words), first output slot
+    __shared__ uint4 s_geo[kWaves][kWave];            // primitive, box origin tx0 | ty0 << 16, box width, ceil(2^16 / width)
+    __shared__ uint32_t s_head[kWaves][2 * kWave];    // the wave's 64 x 64 candidate slots: bit = a footprint starts here
 
     const unsigned gid = blockIdx.x * kInstanceBlock + threadIdx.x;
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const bool active = gid < n_visible;
     if (wave_ballot(active) == 0) return;              // wave-uniform; waves are independent (no workgroup barrier)
     const unsigned i = active ? gid : n_visible - 1;
-    const uint32_t prim = sorted_prims[i];
-    const float4 r2 = reinterpret_cast<const float4*>(rec + prim)[2];     // colour.b, bounds x, bounds y, overlap bitmap
-    unsigned tx0, tx1, ty0, ty1;
-    tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
-    const unsigned tbw = tx1 - tx0;
-    const uint32_t mask = (active && tbw * (ty1 - ty0) <= 32u) ? __float_as_uint(r2.w) : 0u;   // larger footprints keep a hot-accumulator slot there
+    const uint4 row = foot[i];
+    const uint32_t prim = row.x;
     const uint32_t my_off = offsets[i];
-    // No read of n_touched[prim]: that second random gather (a 128-byte line per primitive for 4 bytes, like the record's) made this kernel
-    // fetch 528 MB per launch at S2 for ~100 MB of input (rocprofv3 FETCH_SIZE, round 2). A bitmap footprint's count is the number of set
-    // bits (preprocess wrote exactly the overlapped tiles), and every entry of the visible list has at least one tile (preprocess appends
-    // only cnt > 0: visible = active && cnt > 0, kf:190), which is all the other two paths need to know.
+    const bool small = active && row.y != kFootprintEscape;
 
-    // Bitmap primitives of this wave get wave-local output slots: prefix of their counts. Walking these (not the global
-    // range) keeps the loop proportional to what is written here -- a wave holding screen-filling Gaussians would otherwise
-    // step over tens of thousands of slots that belong to the other two paths.
-    const uint32_t n_small = static_cast<uint32_t>(__popc(mask));
-    const uint32_t local = wave_exclusive_sum(n_small);
-    const uint32_t total_small = wave_sum(n_small);
-    s_off[wv][lane] = my_off;
-    s_loc[wv][lane] = local;      // non-decreasing; a lane without bitmap shares its value with the next bitmap lane, which wins ties
-    s_mask[wv][lane] = mask;
-    s_prim[wv][lane] = prim;
-    s_org[wv][lane] = tx0 | (ty0 << 16);
-    s_div[wv][lane] = tbw | (((65536u + tbw - 1u) / (tbw ? tbw : 1u)) << 8);
+    // ---- bitmap footprints: their candidates end to end, 64 per step ----
+    const unsigned tbw_small = ((row.y >> 20) & 63u) + 1u;
+    const uint32_t n_cand = small ? tbw_small * (((row.y >> 26) & 63u) + 1u) : 0u;
+    const uint32_t cand_end = wave_inclusive_sum(n_cand);
+    const uint32_t cand_start = cand_end - n_cand;
+    const uint32_t total_cand = wave_read(cand_end, kWave - 1);
+    const unsigned slot = lanes_below(wave_ballot(small));
+    s_head[wv][lane] = 0u; s_head[wv][kWave + lane] = 0u;
     wave_lds_fence();
-
-    // ---- small footprints: walk the wave's local output slots, 64 per step ----
-    for (uint32_t sl = lane; sl < total_small; sl += kWave) {
-        unsigned lo = 0;                               // largest lane index with s_loc[lo] <= sl; ties resolve to the bitmap lane
-#pragma unroll
-        for (unsigned step = 32; step >= 1; step >>= 1) {
-            const unsigned mid = lo + step;
-            if (mid < 64u && s_loc[wv][mid] <= sl) lo = mid;
-        }
-        const uint32_t m = s_mask[wv][lo];
-        const unsigned rank = sl - s_loc[wv][lo];
-        const unsigned pos = nth_set_bit(m, rank);
-        const uint32_t dv = s_div[wv][lo], org = s_org[wv][lo];
-        const unsigned w = dv & 0xffu, row = (pos * (dv >> 8)) >> 16, col = pos - row * w;
-        const unsigned tx = (org & 0xffffu) + col, ty = (org >> 16) + row;
-        const uint32_t o = s_off[wv][lo] + rank;
-        if (o < capacity) {
-            inst_keys[o] = static_cast<KeyT>(ty * grid_w + tx);
-            inst_prims[o] = s_prim[wv][lo];
+    if (small) {
+        s_pack[wv][slot] = make_uint4(cand_start, row.z, row.w, my_off);
+        s_geo[wv][slot] = make_uint4(prim, (row.y & 1023u) | (((row.y >> 10) & 1023u) << 16), tbw_small, (65536u + tbw_small - 1u) / tbw_small);
+        atomicOr(&s_head[wv][cand_start >> 5], 1u << (cand_start & 31u));                                  // distinct bits: every footprint has >= 1 candidate
+    }
+    wave_lds_fence();
+    unsigned heads_before = 0;                         // wave-uniform
+    for (uint32_t base = 0; base < total_cand; base += kWave) {
+        const uint64_t heads = wave_uniform(static_cast<uint64_t>(s_head[wv][base >> 5]) | (static_cast<uint64_t>(s_head[wv][(base >> 5) + 1u]) << 32));
+        const uint32_t p = base + lane;
+        // owner = the last footprint starting at or before this candidate slot; slot 0 of the wave is a head, so the index is never negative
+        const unsigned owner = heads_before + lanes_below(heads) + static_cast<unsigned>((heads >> lane) & 1ull) - 1u;
+        heads_before += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(heads)));
+        const uint4 pk = s_pack[wv][owner];
+        const unsigned t = (p - pk.x) & 63u;           // candidate index inside the owner's box (< 64 for every lane below total_cand)
+        const uint64_t bitmap = static_cast<uint64_t>(pk.y) | (static_cast<uint64_t>(pk.z) << 32);
+        if (p < total_cand && ((bitmap >> t) & 1ull) != 0ull) {
+            const uint4 geo = s_geo[wv][owner];
+            const unsigned row_t = (t * geo.w) >> 16, col_t = t - row_t * geo.z;                         // t / width, t % width (t < 64, width <= 64)
+            const uint32_t o = pk.w + static_cast<unsigned>(__popcll(static_cast<unsigned long long>(bitmap & ((1ull << t) - 1ull))));
+            if (o < capacity) {
+                inst_keys[o] = static_cast<KeyT>(((geo.y >> 16) + row_t) * grid_w + (geo.y & 0xffffu) + col_t);
+                inst_prims[o] = geo.x;
+            }
         }
     }
 
-    // ---- medium footprints (33 .. kBigInstanceFootprint candidate tiles): re-tested by this wave, 64 candidates per step, with
-    // ballot-prefix write slots (kf:283-326) ----
-    const unsigned count = tbw * (ty1 - ty0);
-    const bool recompute = active && mask == 0u;
+    // ---- escape rows (boxes of 65 .. kBigInstanceFootprint candidate tiles): re-tested by this wave from the record, 64 candidates per step,
+    // with ballot-prefix write slots (kf:283-326) ----
+    const bool recompute = active && !small;
+    unsigned tx0 = 0, ty0 = 0, tbw = 1, count = 0;
+    float4 r0{}, r1{};
+    if (recompute) {                                   // the only lanes that touch the record
+        const float4* rr = reinterpret_cast<const float4*>(rec + prim);
+        r0 = rr[0]; r1 = rr[1];
+        const float4 r2 = rr[2];                       // colour.b, bounds x, bounds y, hot-accumulator slot
+        unsigned tx1, ty1;
+        tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
+        tbw = tx1 - tx0;
+        count = tbw * (ty1 - ty0);
+    }
     uint64_t pending = wave_ballot(recompute && count <= kBigInstanceFootprint);
     if (pending != 0) {
-        const float4* rr = reinterpret_cast<const float4*>(rec + prim);
-        const float4 r0 = rr[0], r1 = rr[1];
         const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
         while (pending != 0) {
             const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
@@ -262,7 +235,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
     }
 }
 
-hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const uint32_t* n_touched,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s) {
@@ -270,12 +243,12 @@ hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, 
     const dim3 grid((n_visible + kInstanceBlock - 1) / kInstanceBlock), block(kInstanceBlock);
     const dim3 big_grid(n_visible < 1024u ? n_visible : 1024u);       // grid-stride over the (short) device-side work list
     if (key_bytes == 2) {
-        hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, sorted_prims, offsets, n_touched, rec,
+        hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, foot_sorted, offsets, rec,
                            static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint16_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
                            static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, capacity);
     } else {
-        hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, sorted_prims, offsets, n_touched, rec,
+        hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, foot_sorted, offsets, rec,
                            static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint32_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
                            static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, capacity);
@@ -284,45 +257,20 @@ hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, 
 }
 
 // ---- K6 ----------------------------------------------------------------------------------------------------
-template <typename KeyT>
-static size_t tile_sort_temp_bytes_t(uint32_t n, int end_bit) {
-    size_t bytes = 0;
-    rocprim::double_buffer<KeyT> k(nullptr, nullptr);
-    rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, n, 0u, static_cast<unsigned>(end_bit));
-    const size_t own = own_sort_temp_bytes(n, end_bit);
-    return own > bytes ? own : bytes;
-}
-size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit) {
-    return key_bytes == 2 ? tile_sort_temp_bytes_t<uint16_t>(n_instances, end_bit) : tile_sort_temp_bytes_t<uint32_t>(n_instances, end_bit);
-}
+size_t tile_sort_temp_bytes(uint32_t n_instances, int /*key_bytes*/, int end_bit) { return own_sort_temp_bytes(n_instances, end_bit); }
 
-template <typename KeyT>
-static hipError_t run_tile_sort_t(void* temp, size_t temp_bytes, void* keys[2], uint32_t* vals[2], int& selector, uint32_t n,
-                                  int end_bit, hipStream_t s) {
-    rocprim::double_buffer<KeyT> k(static_cast<KeyT*>(keys[0]), static_cast<KeyT*>(keys[1]));
-    rocprim::double_buffer<uint32_t> v(vals[0], vals[1]);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, n, 0u, static_cast<unsigned>(end_bit), s);
-    if (e != hipSuccess) return e;
-    selector = (v.current() == vals[0]) ? 0 : 1;      // fwd:205 records which half holds the sorted list
-    return hipSuccess;
-}
-bool tile_sort_takes_device_count() { return (g_sort_implementation & 1) != 0; }
+// n_instances_ptr != nullptr: n_instances is the capacity of the arrays, the count lives on the device. selector: which half of the
+// double buffers holds the sorted list (fwd:205).
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
                          uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s) {
     selector = 0;
     if (n_instances == 0) return hipSuccess;
-    if (g_sort_implementation & 1) {       // n_instances_ptr != nullptr: n_instances is the capacity, the count lives on the device
-        if (key_bytes == 2) {
-            uint16_t* k16[2] = {static_cast<uint16_t*>(keys[0]), static_cast<uint16_t*>(keys[1])};
-            return own_sort_pairs_u16_device_count(temp, temp_bytes, k16, vals, selector, n_instances, n_instances_ptr, end_bit, s);
-        }
-        uint32_t* k32[2] = {static_cast<uint32_t*>(keys[0]), static_cast<uint32_t*>(keys[1])};
-        return own_sort_pairs_u32_device_count(temp, temp_bytes, k32, vals, selector, n_instances, n_instances_ptr, end_bit, s);
+    if (key_bytes == 2) {
+        uint16_t* k16[2] = {static_cast<uint16_t*>(keys[0]), static_cast<uint16_t*>(keys[1])};
+        return own_sort_pairs_u16_device_count(temp, temp_bytes, k16, vals, selector, n_instances, n_instances_ptr, end_bit, s);
     }
-    if (n_instances_ptr != nullptr) return hipErrorInvalidValue;
-    return key_bytes == 2 ? run_tile_sort_t<uint16_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s)
-                          : run_tile_sort_t<uint32_t>(temp, temp_bytes, keys, vals, selector, n_instances, end_bit, s);
+    uint32_t* k32[2] = {static_cast<uint32_t*>(keys[0]), static_cast<uint32_t*>(keys[1])};
+    return own_sort_pairs_u32_device_count(temp, temp_bytes, k32, vals, selector, n_instances, n_instances_ptr, end_bit, s);
 }
 
 // ---- K7 (kf:331-348); ranges are pre-zeroed by the host (fwd:54) ----------------------------------------------

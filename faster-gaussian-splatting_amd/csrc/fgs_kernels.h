@@ -16,6 +16,7 @@ struct PreprocessArgs {                 // K1
     const float* sh0; const float* sh_rest;
     PrimRec* rec; uint32_t* n_touched;
     uint32_t* depth_keys; uint32_t* prim_idx;     // compacted (unsorted) visible list
+    uint4* foot;                                   // footprint row of every entry of that list (fgs_math.h), or nullptr (sharded owner: no sort behind K1)
     uint32_t* counters;                            // [0] n_visible, [1] n_instances (one packed 64-bit word), [2] K5 work list, [3] huge list, [4] hot slots
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint32_t* hot_list;                            // [kMaxHot] primitive index of hot-accumulator slot s (counters[4] = slots handed out)
@@ -36,25 +37,23 @@ hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s);
 struct DepthKeyRange { uint32_t base; int bits; };
 DepthKeyRange depth_key_range(float near_plane, float far_plane);
 size_t depth_sort_temp_bytes(uint32_t n);
-hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                          uint32_t n_visible, DepthKeyRange range, hipStream_t s);
-// the same with the count still on the device (n_visible_ptr), `capacity` >= *n_visible_ptr; false if this build path needs the host count
-bool depth_sort_takes_device_count();
-hipError_t run_depth_sort_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector,
-                                       uint32_t capacity, const uint32_t* n_visible_ptr, DepthKeyRange range, hipStream_t s);
+// `n_visible` = the visible count, or with n_visible_ptr != nullptr a bound of the count stored there on the device (the sort reads it there: it
+// can be enqueued before the host knows the count). foot[0] = the footprint rows in compaction order (K1), foot[1] receives them in depth order,
+// tile_counts their tile counts in depth order; vals[selector] = the primitives in depth order.
+hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
+                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s);
 // n_visible_ptr != nullptr: n_visible is a bound (the primitive count) and the exact count is read on the device
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* sorted_prims, const uint32_t* n_touched, uint32_t* offsets,
+hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* tile_counts, uint32_t* offsets,
                             uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s);
 
 // K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
 // The *_ptr forms serve the host-synchronisation-free forward pass: counts are bounds / capacities, the exact ones are read on the device
 // (n_visible from counters[0]; the instance count clamped to `capacity` is written to counters[5], an overflow flag to counters[6]).
-hipError_t launch_create_instances(int key_bytes, const uint32_t* sorted_prims, const uint32_t* offsets, const uint32_t* n_touched,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s);
-bool tile_sort_takes_device_count();
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
                          uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s);
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s);
@@ -68,10 +67,12 @@ constexpr unsigned kColumnsTopDown = 252u, kColumnsBottomUp = 251u;   // one ver
 constexpr unsigned kBandsThroughPlan = 253u;         // A/B only: the round-1 bands, but with the plan's dependent load on every workgroup's path
 extern std::atomic<int> g_plan_experiment;
 extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
-extern std::atomic<int> g_sort_implementation;       // bit 0: tile sort, bit 1: depth sort use radix_sort.hip; cleared = rocPRIM onesweep
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
+// Side table carried out of the depth sort's LAST scatter pass (radix_sort.hip): the sort's values start as the input positions (the first pass
+// makes them up), the last pass gathers rows_in[value] and writes the row, its first word as the sorted value, and the row's tile count in sorted order.
+struct SortPayload { const uint4* rows_in; uint4* rows_out; uint32_t* count_out; int iota_values; };
 hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
-                          DepthKeyRange range, hipStream_t s);
+                          DepthKeyRange range, hipStream_t s, const SortPayload* payload = nullptr);
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);
 // the item count lives on the device (*n_ptr <= capacity): lets the depth sort start before the host has read the counters back
@@ -187,7 +188,7 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s);
 // how the renderer's record concatenation is made of the shards' segments (n_shards <= 1: the records keep their order)
 struct ShardOrder { int n_shards; uint32_t count[kMaxBatchViews]; };
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
+                                       uint32_t* prim_idx, uint4* foot, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
                                        hipStream_t s);
 hipError_t launch_pack_acc(const float* acc, uint32_t n, float* out, const ShardOrder& order, hipStream_t s);
 

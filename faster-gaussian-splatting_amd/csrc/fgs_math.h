@@ -252,4 +252,26 @@ __device__ __forceinline__ void tile_rect(uint32_t bx, uint32_t by, unsigned& tx
     ty0 = y_min / kTileH; ty1 = (y_max + kTileH - 1) / kTileH;
 }
 
+// Footprint row: 16 bytes per VISIBLE Gaussian, written by preprocess in compaction order and carried into depth order by the depth sort's last
+// scatter pass (radix_sort.hip), so that the offsets scan and the instance kernel stream what they need instead of gathering a record line per
+// Gaussian:  x = primitive index,  y = tile box (tx0 | ty0 << 10 | (width - 1) << 20 | (height - 1) << 26),  z, w = exact-overlap bitmap of the
+// box's <= 64 candidate tiles, row-major. Boxes of more than 64 candidates, or beyond 1024 tiles in x or y, are ESCAPE rows: y = kFootprintEscape,
+// z = the tile count -- the instance kernel re-tests those from the record.
+constexpr uint32_t kFootprintEscape = 0xffffffffu;          // width - 1 = height - 1 = 63 is no box of <= 64 candidates
+constexpr unsigned kFootprintBitmapTiles = 64;
+__device__ __forceinline__ bool footprint_box_fits(unsigned tx0, unsigned ty0, unsigned tbw, unsigned n_max) {
+    return n_max >= 1u && n_max <= kFootprintBitmapTiles && tx0 < 1024u && ty0 < 1024u && tbw >= 1u;
+}
+__device__ __forceinline__ uint32_t footprint_box(unsigned tx0, unsigned ty0, unsigned tbw, unsigned tbh) {
+    return tx0 | (ty0 << 10) | ((tbw - 1u) << 20) | ((tbh - 1u) << 26);
+}
+__host__ __device__ __forceinline__ uint32_t footprint_tile_count(const uint4& row) {
+    if (row.y == kFootprintEscape) return row.z;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<uint32_t>(__popc(row.z) + __popc(row.w));
+#else
+    return static_cast<uint32_t>(__builtin_popcount(row.z) + __builtin_popcount(row.w));
+#endif
+}
+
 }  // namespace fgs

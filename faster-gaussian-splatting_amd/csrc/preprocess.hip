@@ -57,6 +57,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 
     bool visible = false;
     unsigned cnt = 0;
+    uint32_t foot_box = kFootprintEscape, foot_lo = 0, foot_hi = 0;        // the Gaussian's footprint row (fgs_math.h)
     if (wave_ballot(active) != 0) {                                                    // wave-uniform: skip culled waves (kf:70)
         float opacity = sigmoid_f(a.opacities[idx]);
         if (opacity < kMinAlphaThreshold) active = false;                              // kf:75
@@ -108,7 +109,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
             const bool huge = active && n_max > kHugeFootprint;
             if (huge) active = false;
             const TileTest tt = make_tile_test(m2x - 0.5f, m2y - 0.5f, ca, cb, cc, power_threshold);
-            uint32_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 32
+            uint64_t hit_mask = 0;          // bit t = candidate tile t (row-major in the tile bounding box) is overlapped; t < 64
             unsigned first_shared = 0;      // candidates below this index were handled by one of the first two schemes
             if (a.seq_tiles > 0) {
                 // (A/B reference, fgs_debug_set_option(5, n)) the reference's scheme: every lane tests the first n candidates of its
@@ -118,7 +119,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 if (active) {
                     const unsigned n_seq = n_max < first_shared ? n_max : first_shared;
                     for (unsigned t = 0; t < n_seq; ++t)
-                        if (tile_contributes(tt, tx0 + t % tbw, ty0 + t / tbw)) { ++cnt; hit_mask |= 1u << t; }
+                        if (tile_contributes(tt, tx0 + t % tbw, ty0 + t / tbw)) { ++cnt; hit_mask |= 1ull << t; }
                 }
             } else {
                 // Flattened: the (Gaussian, candidate) pairs of all footprints of <= 64 candidates are laid end to end (prefix sum of
@@ -163,8 +164,8 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                         const int len = hi - lo;
                         const uint64_t mine = (hits >> lo) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
                         cnt += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(mine)));
-                        const int first_t = lo - rel;                                  // candidate index of the pair at lane lo
-                        if (first_t < 32) hit_mask |= static_cast<uint32_t>(mine << first_t);
+                        const int first_t = lo - rel;                                  // candidate index of the pair at lane lo (< 64: flat footprints only)
+                        hit_mask |= mine << first_t;
                     }
                 }
             }
@@ -188,15 +189,19 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                     const bool hit = t < o_cnt && tile_contributes(ot, o_tx0 + t % o_tbw, o_ty0 + t / o_tbw);
                     const uint64_t hits = wave_ballot(hit);
                     found += static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
-                    if (base == first && first < 32u && lane == static_cast<unsigned>(src)) hit_mask |= static_cast<uint32_t>(hits << first);
+                    if (base == first && first < 64u && lane == static_cast<unsigned>(src)) hit_mask |= hits << first;
                 }
                 if (lane == static_cast<unsigned>(src)) cnt += found;
             }
 
             FGS_K1_MARK(3);                                                            // footprints of > 64 candidates
             visible = active && cnt > 0;                                               // kf:190
+            if (footprint_box_fits(tx0, ty0, tbw, n_max)) {                            // every candidate of the box was tested above: the bitmap is exact
+                foot_box = footprint_box(tx0, ty0, tbw, ty1 - ty0);
+                foot_lo = static_cast<uint32_t>(hit_mask); foot_hi = static_cast<uint32_t>(hit_mask >> 32);
+            }
             // hot-accumulator slots for K11 (fgs_config.h): one counter atomic per wave that holds such a footprint
-            uint32_t slot_word = n_max <= 32u ? hit_mask : 0u;
+            uint32_t slot_word = n_max <= 32u ? static_cast<uint32_t>(hit_mask) : 0u;
             const bool hot = (visible || huge) && n_max > kHotFootprint;
             const uint64_t hot_mask = wave_ballot(hot);
             if (hot_mask != 0) {
@@ -258,6 +263,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         for (unsigned w = 0; w < wave; ++w) off += s_vis[w];
         a.depth_keys[off] = __float_as_uint(depth);
         a.prim_idx[off] = idx;
+        if (a.foot != nullptr) a.foot[off] = foot_box == kFootprintEscape ? make_uint4(idx, kFootprintEscape, cnt, 0u) : make_uint4(idx, foot_box, foot_lo, foot_hi);
     }
     FGS_K1_MARK(5);                                             // tile-count store, workgroup barrier + compaction atomic, key / index store
     FGS_K1_FLUSH;
@@ -310,6 +316,7 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
                 const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
                 a.depth_keys[off] = __float_as_uint(depth);
                 a.prim_idx[off] = idx;
+                if (a.foot != nullptr) a.foot[off] = make_uint4(idx, kFootprintEscape, cnt, 0u);
                 if (a.count_appended) atomicAdd(&a.counters[2], 1u);     // sharded path: how many entries this kernel appended
             }
         }

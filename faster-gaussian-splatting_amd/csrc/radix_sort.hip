@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
                                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                      const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const uint32_t key_base,
                                                                      const int shift, const uint32_t* __restrict__ table,
-                                                                     const uint32_t* __restrict__ totals, const uint32_t n_blocks) {
+                                                                     const uint32_t* __restrict__ totals, const uint32_t n_blocks, const SortPayload pl) {
     constexpr int kBlockItems = SortShape<IPT>::kBlockItems, kWaveItems = SortShape<IPT>::kWaveItems;
     constexpr uint32_t kBins = 1u << BITS, mask = kBins - 1u;
     constexpr int DPT = kBins > static_cast<uint32_t>(kSortThreads) ? static_cast<int>(kBins) / kSortThreads : 1;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         const uint32_t idx = seg + r * kWave + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : static_cast<KeyT>(key_base);
-        val[r] = valid ? vals_in[idx] : 0u;
+        val[r] = pl.iota_values ? idx : (valid ? vals_in[idx] : 0u);
     }
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {                                                    // input order: round by round, lane by lane
@@ -218,12 +218,48 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
     __syncthreads();
     const uint32_t block_first = blockIdx.x * kBlockItems;
     const uint32_t n_here = n - block_first < static_cast<uint32_t>(kBlockItems) ? n - block_first : static_cast<uint32_t>(kBlockItems);
-    for (uint32_t pos = threadIdx.x; pos < n_here; pos += kSortThreads) {
-        const KeyT k = s_key[pos];
-        const uint32_t d = digit_of(k, key_base, shift, mask);
-        const uint32_t dst = s_dst[d] + (pos - s_first[d]);
-        keys_out[dst] = k;
-        vals_out[dst] = s_val[pos];
+    if (pl.rows_in == nullptr) {
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += kSortThreads) {
+            const KeyT k = s_key[pos];
+            const uint32_t d = digit_of(k, key_base, shift, mask);
+            const uint32_t dst = s_dst[d] + (pos - s_first[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_val[pos];
+        }
+        return;
+    }
+    // Last pass of the depth sort: the values are row indices into a 16-byte side table (preprocess.hip: one footprint row per visible Gaussian, in
+    // compaction order). The row is gathered HERE and leaves in sorted order, so that the offsets scan and the instance kernel behind the sort
+    // stream it -- their own per-Gaussian random gathers (a 128-byte line for 4 / 16 useful bytes each) were 3x their algorithmic traffic. Four
+    // gathers per thread are in flight at a time; a row's first word is the primitive index (= the sorted value), its tile count goes to count_out.
+#ifndef FGS_SORT_GATHER_BATCH
+#define FGS_SORT_GATHER_BATCH 4
+#endif
+    constexpr int kBatch = FGS_SORT_GATHER_BATCH < IPT ? FGS_SORT_GATHER_BATCH : IPT;
+    static_assert(IPT % kBatch == 0, "whole gather batches");
+#pragma unroll 1
+    for (int b = 0; b < IPT / kBatch; ++b) {
+        uint4 row[kBatch];
+        uint32_t dst[kBatch];
+        KeyT key_b[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t pos = (b * kBatch + j) * kSortThreads + threadIdx.x;
+            const bool in = pos < n_here;
+            const uint32_t p = in ? pos : 0u;
+            key_b[j] = s_key[p];
+            const uint32_t d = digit_of(key_b[j], key_base, shift, mask);
+            dst[j] = in ? s_dst[d] + (p - s_first[d]) : 0xffffffffu;
+            row[j] = pl.rows_in[in ? s_val[p] : 0u];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (dst[j] == 0xffffffffu) continue;
+            keys_out[dst[j]] = key_b[j];
+            vals_out[dst[j]] = row[j].x;
+            pl.rows_out[dst[j]] = row[j];
+            pl.count_out[dst[j]] = footprint_tile_count(row[j]);
+        }
     }
 }
 
@@ -244,8 +280,9 @@ SortPlan plan_sort(uint32_t n, int end_bit, int max_bits, int items_per_thread) 
 
 template <typename KeyT, int IPT>
 void launch_scatter(int bits, dim3 grid, dim3 block, hipStream_t s, const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out,
-                    uint32_t n, const uint32_t* n_ptr, uint32_t key_base, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks) {
-#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B, IPT>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, key_base, shift, table, totals, n_blocks); break;
+                    uint32_t n, const uint32_t* n_ptr, uint32_t key_base, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks,
+                    const SortPayload& pl) {
+#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B, IPT>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, key_base, shift, table, totals, n_blocks, pl); break;
     switch (bits) { FGS_SCATTER(1) FGS_SCATTER(2) FGS_SCATTER(3) FGS_SCATTER(4) FGS_SCATTER(5) FGS_SCATTER(6) FGS_SCATTER(7) FGS_SCATTER(8) default: FGS_SCATTER(9) }
 #undef FGS_SCATTER
 }
@@ -254,7 +291,7 @@ void launch_scatter(int bits, dim3 grid, dim3 block, hipStream_t s, const KeyT* 
 // (key - key_base) & (2^end_bit - 1): the caller guarantees key >= key_base.
 template <typename KeyT, int IPT>
 hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
-                      uint32_t key_base, int end_bit, int max_bits, hipStream_t s) {
+                      uint32_t key_base, int end_bit, int max_bits, hipStream_t s, const SortPayload* payload = nullptr) {
     selector = 0;
     if (n == 0) return hipSuccess;
     const SortPlan p = plan_sort(n, end_bit, max_bits, IPT);
@@ -267,8 +304,13 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
         const int bits = p.bits[i];
         hipLaunchKernelGGL((radix_histogram_kernel<KeyT, IPT>), grid, block, 0, s, keys[selector], n, n_ptr, key_base, shift, bits, table, p.n_blocks);
         hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), block, 0, s, table, totals, p.n_blocks);
+        SortPayload pl{};                                   // with a payload: the values are the input positions (first pass) and become the rows' primitives (last pass)
+        if (payload != nullptr) {
+            pl.iota_values = i == 0 ? 1 : 0;
+            if (i == p.n_passes - 1) { pl.rows_in = payload->rows_in; pl.rows_out = payload->rows_out; pl.count_out = payload->count_out; }
+        }
         launch_scatter<KeyT, IPT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, key_base, shift,
-                                  table, totals, p.n_blocks);
+                                  table, totals, p.n_blocks, pl);
         selector ^= 1;
         shift += bits;
     }
@@ -278,7 +320,6 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
 }  // namespace sortimpl
 using namespace sortimpl;
 
-std::atomic<int> g_sort_implementation{3};          // bit 0: tile sort here, bit 1: depth sort here; cleared bit = rocPRIM onesweep (fgs_debug_set_option key 6)
 std::atomic<int> g_depth_sort_mode{1};              // fgs_debug_set_option(9, m) -- bit 0: sort key - bits(near) in ceil(bits / 9) passes (near 0.2, far 1e4: 27 bits
                                                     // = 3 passes instead of 4); bit 1: 2048-item workgroups (8 items per thread); 0 = round 1 (4 x 8 bits, 4096 items).
                                                     // tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
@@ -321,12 +362,12 @@ DepthKeyRange depth_key_range(float near_plane, float far_plane) {
 
 // `n` = visible count, or with n_ptr != nullptr a bound of the count stored at n_ptr on the device
 hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
-                          DepthKeyRange range, hipStream_t s) {
+                          DepthKeyRange range, hipStream_t s, const SortPayload* payload) {
     const int mode = g_depth_sort_mode;
     const uint32_t base = (mode & 1) ? range.base : 0u;
     const int end_bit = (mode & 1) ? range.bits : 32, max_bits = (mode & 1) ? kMaxBits : kGenericMaxBits;
-    if (mode & 2) return sort_pairs<uint32_t, kDepthSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
-    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
+    if ((mode & 2) && payload == nullptr) return sort_pairs<uint32_t, kDepthSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
+    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s, payload);
 }
 
 }  // namespace fgs

@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t record_of_slot(const uint32_t d, const Shard
 // Also K0 (clears the per-tile ranges, which K1 does on the single-GPU path).
 __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_t* __restrict__ records, uint32_t n, PrimRec* __restrict__ rec,
                                                                    uint32_t* __restrict__ n_touched, uint32_t* __restrict__ depth_keys,
-                                                                   uint32_t* __restrict__ prim_idx, uint2* __restrict__ ranges, uint32_t n_tiles,
+                                                                   uint32_t* __restrict__ prim_idx, uint4* __restrict__ foot, uint2* __restrict__ ranges, uint32_t n_tiles,
                                                                    uint32_t* __restrict__ hot_list, uint32_t* __restrict__ hot_count, const ShardOrder order) {
     const uint32_t dst = blockIdx.x * 256u + threadIdx.x;                     // thread = primitive slot; its record is gathered
     for (uint32_t t = dst; t < n_tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
     r[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
     r[2] = make_uint4(w4.x, w4.y, w5.x, slot_word);
     depth_keys[dst] = w6.x; prim_idx[dst] = dst; n_touched[dst] = w6.y;   // the visible list in slot order: equal depth keys keep that order through the stable sort
+    // footprint row (fgs_math.h): a record carries the 32-bit overlap bitmap of boxes of <= 32 candidates; larger boxes are re-tested by the instance kernel
+    const bool bitmap = n_max <= 32u && footprint_box_fits(tx0, ty0, tx1 - tx0, n_max);
+    foot[dst] = bitmap ? make_uint4(dst, footprint_box(tx0, ty0, tx1 - tx0, ty1 - ty0), w5.y, 0u) : make_uint4(dst, kFootprintEscape, w6.y, 0u);
 }
 
 // K11's accumulator records [n][9] (by primitive slot) -> the same 36-byte records in the order of the concatenation (record j), ready to be cut
@@ -163,10 +166,10 @@ hipError_t launch_pack_splat_records(const PackRecordsBatch& b, hipStream_t s) {
 }
 
 hipError_t launch_unpack_splat_records(const uint32_t* records, uint32_t n, PrimRec* rec, uint32_t* n_touched, uint32_t* depth_keys,
-                                       uint32_t* prim_idx, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
+                                       uint32_t* prim_idx, uint4* foot, uint2* ranges, uint32_t n_tiles, uint32_t* hot_list, uint32_t* hot_count, const ShardOrder& order,
                                        hipStream_t s) {
     const dim3 grid(n == 0 ? 1u : (n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, ranges, n_tiles, hot_list, hot_count, order);
+    hipLaunchKernelGGL(unpack_splat_records_kernel, grid, block, 0, s, records, n, rec, n_touched, depth_keys, prim_idx, foot, ranges, n_tiles, hot_list, hot_count, order);
     return hipGetLastError();
 }
 

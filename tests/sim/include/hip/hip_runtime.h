@@ -214,6 +214,7 @@ inline int __ffsll(unsigned long long v) { return __builtin_ffsll(static_cast<lo
 inline int __clz(int v) { return v ? __builtin_clz(static_cast<unsigned>(v)) : 32; }
 inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline unsigned atomicOr(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 inline float unsafeAtomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
