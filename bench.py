@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='skip the inference / fused side measurements')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the oracle (no GPU needed)')
     ap.add_argument('--async-forward', action='store_true', help='training forward without the host read of the visible / instance counts (fgs_forward_async)')
+    ap.add_argument('--no-trained-like', action='store_true', help='skip the extra that trains a small model from scratch inside the run (~5 s) before benching it')
     ap.add_argument('--no-pmc', action='store_true', help='skip the live rocprofv3 counter passes (HBM traffic, VALU instructions)')
     ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps iterations: the first is the contract\'s timed region (value), '
                                                          'the others show its repeatability (median / min / max in `repeatability`)')
@@ -470,10 +471,12 @@ def main():
     # algorithmic bytes per stage (DESIGN.md 'Measurement'). N Gaussians, V visible, I instances,
     # B buckets(64), P pixels, T tiles, K active SH bases -- all realised values of the timed views.
     stage_bytes = {
-        'preprocess': 48.0 * n + (12 * K_ + 56.0) * V,
-        'depth_sort': 68.0 * V,
-        'offsets_scan': 20.0 * V,
-        'create_instances': 40.0 * V + 6.0 * I,
+        # round 5 data flow: K1 also writes a 16-B footprint row per visible Gaussian; the depth sort's last scatter pass gathers
+        # it and writes row + tile count in depth order (+ 16 + 16 + 4 B); the scan reads the counts and writes the offsets; K5 streams row + offset
+        'preprocess': 48.0 * n + (12 * K_ + 56.0 + 16.0) * V,
+        'depth_sort': (68.0 + 36.0) * V,
+        'offsets_scan': 8.0 * V,
+        'create_instances': 20.0 * V + 6.0 * I,
         'tile_sort': 26.0 * I,
         'extract_ranges': 2.0 * I + 8.0 * T_,
         'bucket_scan': 12.0 * T_,
@@ -505,7 +508,7 @@ def main():
     per_launch = {k: v_[0] / n_prof for k, v_ in prof.items() if v_[1] > 0}   # ms per step, from the untimed stage-profile pass
     dom = dom_stage
     dom_s = prof_dom[dom][0] / max(prof_dom[dom][1], 1) * 1e-3            # average launch duration over the TIMED steps (HIP events on the launch stream)
-    achieved = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
+    achieved_algorithmic = stage_bytes[dom] / dom_s / 1e9 if dom_s > 0 else 0.0
     # bytes of one iteration: the stages that ran, with THIS build's counts (walked instances / buckets for the blend kernels); SURVEY.md 8d's
     # closed form for the reference's data flow (every instance and bucket) is reported beside it
     bytes_iter = float(sum(stage_bytes[k] for k, v_ in prof.items() if v_[1] > 0 and k in stage_bytes))
@@ -518,6 +521,10 @@ def main():
         # 'HBM', calibrated in round 1 on the Adam kernel: 2 x FETCH_SIZE + WRITE_SIZE = 4.956 GB = its algorithmic bytes)
         traffic = (2.0 * pmc[dom]['FETCH_SIZE'] + pmc[dom]['WRITE_SIZE']) * 1024.0
         traffic_note = 'live: rocprofv3 --pmc passes of a 3-step child run of this command; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch'
+    # `achieved` credits the kernel with the SMALLER of the algorithmic bytes and the bytes the counters saw it move (Adam skips
+    # READING the gradient rows of dead 64-Gaussian blocks, so it moves ~4 % less than 1652 N and must not be credited with bytes it never touched)
+    achieved_counter = traffic / dom_s / 1e9 if (traffic is not None and dom_s > 0) else None
+    achieved = min(achieved_algorithmic, achieved_counter) if achieved_counter is not None else achieved_algorithmic
     # Secondary ceiling: VALU issue. Measured on this chip (tools/valu_rate.hip, profiles/r02_valu_rate.txt): a wave64
     # v_fma/v_mul/v_add issues every 2.9 cycles of a 2.4 GHz clock per SIMD with 8 waves resident (MI355X_MICROARCH.md quotes 2), compares /
     # selects / conversions / DPP moves 4.3, v_exp / v_rcp 8.3. frac = the kernel's VALU instructions (SQ_INSTS_VALU, all shader engines)
@@ -554,6 +561,8 @@ def main():
         'roofline': {'bound': 'hbm', 'kernel': kernel_of.get(dom, dom), 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_note, 'avg_kernel_ms': dom_s * 1e3,
                      'algorithmic_bytes_per_launch': stage_bytes[dom],
+                     'achieved_algorithmic_GBps': achieved_algorithmic, 'achieved_counter_GBps': achieved_counter,
+                     'achieved_is': 'min(algorithmic bytes, counter bytes) / average launch duration',
                      'note': 'dominant = longest kernel of the timed region (HIP events on the launch stream)',
                      'secondary': secondary,
                      'iteration_algorithmic_GB': bytes_iter / 1e9, 'iteration_survey_formula_GB': bytes_iter_survey / 1e9,
@@ -585,6 +594,35 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         out['render_mpix_per_sec'] = P_ / 1e6 / dt
         out['render_ms_per_frame'] = dt * 1e3
+        # configs[1] gets its own roofline (VERDICT r4 missing #3): stage times of the inference path (untimed pass, HIP events around every stage),
+        # the algorithmic bytes of the frame -- SURVEY.md 8d's inference total with the realised V / I of this view (every instance, as the
+        # reference's data flow moves it), and this build's own count (the blend walks only the instances in front of each tile's last
+        # processed Gaussian, and there is no bucket scan) -- over the frame time measured above
+        be.profile_enable(True)
+        try:
+            be.profile_read()
+            for _ in range(PROFILE_STEPS):
+                T.render_image_benchmark(g, v)
+            torch.cuda.synchronize(device)
+            pr_r = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
+        finally:
+            be.profile_enable(False)
+        Vr, Ir, Ipr = float(stats[id(v)]['V']), float(stats[id(v)]['I']), float(stats[id(v)]['Ip'])
+        r_bytes = {'preprocess': 44.0 * n + (12 * K_ + 56.0 + 16.0) * Vr, 'depth_sort': 104.0 * Vr, 'offsets_scan': 8.0 * Vr,
+                   'create_instances': 20.0 * Vr + 6.0 * Ir, 'tile_sort': 26.0 * Ir, 'extract_ranges': 2.0 * Ir + 8.0 * T_,
+                   'blend_forward': 52.0 * Ipr + 8.0 * T_ + 12.0 * P_}
+        r_survey = 44.0 * n + (12 * K_ + 184.0) * Vr + 82.0 * Ir + 16.0 * T_ + 12.0 * P_
+        r_own = float(sum(r_bytes[k] for k in pr_r if k in r_bytes))
+        binning = ('depth_sort', 'offsets_scan', 'create_instances', 'tile_sort', 'extract_ranges', 'bucket_scan')
+        out['render'] = {'what': 'BASELINE.json configs[1]: forward-only render of view 0 (rasterize -> fgs_inference), frame time from 20 back-to-back frames',
+                         'ms_per_frame': dt * 1e3, 'mpix_per_sec': P_ / 1e6 / dt, 'visible': Vr, 'instances': Ir, 'instances_walked': Ipr,
+                         'stage_ms': pr_r, 'binning_ms': float(sum(pr_r.get(k, 0.0) for k in binning)),
+                         'stage_algorithmic_GBps': {k: r_bytes[k] / (pr_r[k] * 1e-3) / 1e9 for k in pr_r if k in r_bytes and pr_r[k] > 0},
+                         'roofline': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'algorithmic_bytes_survey_inference_formula': r_survey, 'achieved': r_survey / dt / 1e9, 'frac': r_survey / dt / 1e9 / HBM_PEAK_GBS,
+                                      'algorithmic_bytes_this_build': r_own, 'achieved_this_build': r_own / dt / 1e9, 'frac_this_build': r_own / dt / 1e9 / HBM_PEAK_GBS,
+                                      'note': 'survey formula = 44 N + (12 K + 184) V + 82 I + 16 T + 12 P (every instance); this build = the per-stage bytes it moves '
+                                              '(blend: walked instances only); both over the measured frame time, peak 8 TB/s'}}
         # BASELINE.json configs[3]: fused backward + Adam
         fo = FusedRasterizerOptimizer([getattr(g, k).detach() for k in T.PARAM_ORDER],
                                       [1.6e-4 * 5.0, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3])
@@ -631,6 +669,15 @@ def main():
         torch.cuda.synchronize(device)
         out['fused_stage_ms_per_step'] = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
         out['fused_vs_unfused'] = out['fused_train_iters_per_sec'] / out['repeatability']['median_iters_per_sec']
+        f_stage = out['fused_stage_ms_per_step']
+        f_iter_bytes = float(sum(stage_bytes[k] for k in f_stage if k in stage_bytes))
+        out['fused']['roofline']['iteration_algorithmic_GB'] = f_iter_bytes / 1e9
+        out['fused']['roofline']['iteration_frac_of_hbm_peak'] = f_iter_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if f_traffic is not None and fk_ms > 0:      # credit the smaller of the two byte counts, as for the headline kernel
+            fr = out['fused']['roofline']
+            fr['achieved_algorithmic_GBps'], fr['achieved_counter_GBps'] = fr['achieved'], f_traffic / (fk_ms * 1e-3) / 1e9
+            fr['achieved'] = min(fr['achieved_algorithmic_GBps'], fr['achieved_counter_GBps'])
+            fr['frac'] = fr['achieved'] / HBM_PEAK_GBS
         be.profile_enable(False)
         del fo
         # A "trained-like" regime beside S2: S2's random opacities saturate a pixel after ~2 buckets; lowering every
@@ -680,6 +727,8 @@ def main():
             # scratch here -- random initialisation, the garden schedule compressed to a tenth (3 000 iterations incl. density control, opacity resets,
             # Morton order, SH schedule; harness.densify.train_from_scratch) on a structured mosaic scene (harness.scenes.make_surface_scene) seen from
             # 16 cameras -- and then benched like the headline: the same full training iteration, 20 steps per block, on what the training produced.
+            if args.no_trained_like:
+                raise RuntimeError('skipped (--no-trained-like)')
             import math as _math
             from harness import densify as D
             from harness.scenes import look_at_view, make_surface_scene
@@ -706,12 +755,14 @@ def main():
                 torch.cuda.synchronize(device)
                 tl_blocks.append((time.perf_counter() - t0) / args.steps * 1e3)
             be.profile_enable(True)
-            be.profile_read()
-            for i in range(PROFILE_STEPS):
-                T.training_iteration(g3, tl_views[i % 16], tl_targets[i % 16], 3100 + i, densification_end=0)
-            torch.cuda.synchronize(device)
-            pr3 = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
-            be.profile_enable(False)
+            try:
+                be.profile_read()
+                for i in range(PROFILE_STEPS):
+                    T.training_iteration(g3, tl_views[i % 16], tl_targets[i % 16], 3100 + i, densification_end=0)
+                torch.cuda.synchronize(device)
+                pr3 = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
+            finally:
+                be.profile_enable(False)
             blend_ms = sum(pr3.get(k, 0.0) for k in ('blend_forward', 'stage_pixels', 'blend_backward'))
             tl_ms = float(np.median(tl_blocks))
             out['trained_like'] = {'what': 'a model trained FROM SCRATCH in this run (100 k random points, garden schedule compressed to 3 000 iterations, structured mosaic ground truth of '
@@ -723,6 +774,50 @@ def main():
             del g3, tl_targets
         except Exception as exc:
             out['trained_like'] = {'what': 'failed', 'error': f'{type(exc).__name__}: {exc}'}
+        try:
+            # A second, LARGER trained-like point that costs no training: harness.scenes.make_surface_scene -- thin, nearly opaque
+            # disks lying ON surfaces, the geometry a trained model converges to -- used directly as the model at 2 M Gaussians, eight look-at cameras,
+            # the same full training iteration. Deterministic (seeded), so the driver line carries a blend-bound number at N >= 1.5 M beside the layered proxy.
+            import math as _math
+            from harness.scenes import look_at_view, make_surface_scene
+            sp = make_surface_scene(2_000_000)
+            sv = [look_at_view((6.4 * _math.cos(2 * _math.pi * k / 8), -(1.0 + 1.6 * (k % 3)), 6.4 * _math.sin(2 * _math.pi * k / 8)), (0.0, 1.3, 0.0), W_, H_, 1420.0).to(device)
+                  for k in range(8)]
+            g4 = T.Gaussians(sp, device)
+            g4.training_setup(training_cameras_extent=5.0)
+            st4 = [(T.render_image_benchmark(g4, v_) * 0.9).clone() for v_ in sv]
+            for i in range(3):
+                T.training_iteration(g4, sv[i], st4[i], i)
+            s_blocks = []
+            for _b in range(max(min(args.blocks, 3), 1)):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    T.training_iteration(g4, sv[i % 8], st4[i % 8], 3 + i)
+                torch.cuda.synchronize(device)
+                s_blocks.append((time.perf_counter() - t0) / args.steps * 1e3)
+            be.profile_enable(True)
+            try:
+                be.profile_read()
+                for i in range(PROFILE_STEPS):
+                    T.training_iteration(g4, sv[i % 8], st4[i % 8], 100 + i)
+                torch.cuda.synchronize(device)
+                pr4 = {k: v_[0] / PROFILE_STEPS for k, v_ in be.profile_read().items() if v_[1] > 0}
+            finally:
+                be.profile_enable(False)
+            res4 = be.forward(*g4.tensors(), T.extract_settings(sv[0], g4.active_sh_bases, sv[0].background_color))
+            lay4 = be.blob_layout(1, 2_000_000, W_, H_, res4.state[1], res4.state[2])
+            mx4 = be.view(res4.buffers[1], lay4, 'max_n_processed', torch.int32)[:T_].long()
+            s_ms = float(np.median(s_blocks))
+            out['surface_scene'] = {'what': 'make_surface_scene(2 M): thin opaque disks on a ground and 12 ellipsoids (the geometry of a TRAINED model, no training run), used as the model; '
+                                            '8 look-at cameras at 1920x1080, full training iteration', 'gaussians': 2_000_000,
+                                    'train_iters_per_sec': 1e3 / s_ms, 'ms_per_step': s_ms, 'ms_per_step_blocks': s_blocks,
+                                    'visible_view0': res4.state[0], 'instances_view0': res4.state[1], 'blended_buckets_per_tile': float(((mx4 + 63) // 64).float().mean()),
+                                    'stage_ms_per_step': pr4,
+                                    'blend_share_of_step': sum(pr4.get(k, 0.0) for k in ('blend_forward', 'stage_pixels', 'blend_backward')) / max(sum(pr4.values()), 1e-9)}
+            del g4, st4, res4, sp
+        except Exception as exc:
+            out['surface_scene'] = {'what': 'failed', 'error': f'{type(exc).__name__}: {exc}'}
         try:
             # the blend-bound regime's own secondary ceilings: vector instructions of K10 / K11 from two more counter passes over a child run of the layered scene
             if not args.no_pmc:

@@ -1097,7 +1097,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         case 13: if (value < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "K11 variant 4 needs at least one workgroup"); fgs::g_k11m_max_blocks = value; return FGS_OK;
         case 8: fgs::g_adam_reverse = value ? 1 : 0; return FGS_OK;
         case 9: fgs::g_depth_sort_mode = value & 3; return FGS_OK;
-        case 10: if (value < 0 || (value > 64 && (value < 251 || value > 255))) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
+        case 10: if (value < 0 || (value > 64 && (value < 251 || value > 255))) return fail(FGS_ERR_INVALID_ARGUMENT, "tile mapping must be 252 (one strip of tile columns per XCD, default), 254 (device-side block plan), 0 (bands), 255 (bands, bottom first) or 1..64 (row groups)");
                  fgs::g_tile_row_group = value; return FGS_OK;
         case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
         case 12: fgs::g_plan_experiment = value & 3; return FGS_OK;

@@ -87,6 +87,12 @@ __device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, cons
     const unsigned row = (kk / row_group) * (kXcds * row_group) + xcd * row_group + kk % row_group;
     return row < n_rows ? row * grid_w + col : n_tiles;
 }
+// Round 5 tried the strips as per-XCD QUEUES with stealing (a workgroup pops the next tile of the strip of the XCD it runs on, hardware XCC_ID, and takes
+// from the fullest other strip once its own is empty) for object-centric scenes, whose outer strips are nearly empty (bench.py's surface scene: 5.8 ms of
+// summed tile time on XCD 0 against 108 ms on XCD 3). Measured (tools/ab_k10_mapping.py at the commit that had it): the one returning atomic per workgroup
+// costs S2 0.145 -> 0.176 ms (10 800 pops onto eight words), a device-scope snapshot of the queue heads in front of it 0.73 ms; and the scene that
+// motivated it gains nothing from balance alone -- the device-side block plan, which balances it, measures 0.366 against 0.387 ms -- because its span is
+// the serial walk of single tiles with lists of thousands (389 us for one tile of 3 860 walked entries). Removed.
 static unsigned blend_grid(const BlendArgs& a) {
     if (a.row_group == kColumnsTopDown || a.row_group == kColumnsBottomUp) return kXcds * ((a.grid_w + kXcds - 1) / kXcds) * a.grid_h;
     if (a.row_group == kBandsThroughPlan) return ((a.n_tiles + kXcds - 1) / kXcds) * kXcds;
@@ -208,27 +214,57 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
                 const uint32_t not_mine = __brev(~static_cast<uint32_t>(word ? mine >> 32 : mine));
                 const unsigned j0 = chunk + 32u * word;
                 const unsigned row0 = in_vector_register(j0 * 16u);                     // byte offset of entry j0, kept out of the scalar unit
+                // Two list entries per trip, their six LDS reads issued together in front of the first use: left to itself the compiler reads the
+                // colours inside the blend branch -- a second LDS round trip per blended entry on the serial path of a long list. The two alphas are
+                // independent chains, only the conditional blends are serial. Measured (tools/ab_k10_mapping.py, one box): S2 0.144 -> 0.140 ms,
+                // layered 0.600 -> 0.590, bench.py's surface scene (lists of thousands walked by a few tiles at the end of the kernel) 0.387 -> 0.357;
+                // three or four entries per trip are slower everywhere (0.156 / 0.162 ms at S2: the control flow, not the LDS, is what a trip pays).
                 while (pend != 0) {                                                    // wave-uniform scalar loop
                     const unsigned k = static_cast<unsigned>(__clz(static_cast<int>(pend)));
                     pend &= ~(0x80000000u >> k);
+                    const bool second = pend != 0u;                                    // wave-uniform
+                    const unsigned k2 = second ? static_cast<unsigned>(__clz(static_cast<int>(pend))) : k;
+                    pend &= ~(0x80000000u >> k2);
                     const float4* const entry = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k << 4)));
-                    const float4 ga = entry[0], gb = entry[kBlendBlock];
+                    const float4* const entry2 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + (row0 + (k2 << 4)));
+                    float4 ga = entry[0], gb = entry[kBlendBlock];
+                    float4 ha = entry2[0], hb = entry2[kBlendBlock];
+                    float blue = entry[2 * kBlendBlock].x, blue2 = entry2[2 * kBlendBlock].x;
+                    asm volatile("" : "+v"(gb.z), "+v"(gb.w), "+v"(blue), "+v"(hb.z), "+v"(hb.w), "+v"(blue2), "+v"(ha.x), "+v"(hb.x));
                     const float dx = ga.x - pxf, dy = ga.y - pyf;
+                    const float ex = ha.x - pxf, ey = ha.y - pyf;
                     const float power = -0.5f * (ga.z * dx * dx + gb.x * dy * dy) - ga.w * dx * dy;
+                    const float power2 = -0.5f * (ha.z * ex * ex + hb.x * ey * ey) - ha.w * ex * ey;
                     const float gauss = __expf(fminf(power, 0.0f));
+                    const float gauss2 = __expf(fminf(power2, 0.0f));
                     const float alpha = gb.y * gauss;
+                    const float alpha2 = hb.y * gauss2;
                     const float tested = __uint_as_float(((not_mine << k) & 0x80000000u) | __float_as_uint(alpha));
+                    const float tested2 = __uint_as_float(((not_mine << k2) & 0x80000000u) | __float_as_uint(alpha2));
 #ifdef FGS_PAIR_STATS
-                    st_pairs += 1u;
+                    st_pairs += second ? 2u : 1u;
                     st_mine += static_cast<unsigned>(__popcll(wave_ballot(((not_mine << k) & 0x80000000u) == 0u && gate < 1.0f)));
                     st_pass += static_cast<unsigned>(__popcll(wave_ballot(tested >= gate)));
 #endif
                     if (tested >= gate) {
                         const float w = T * alpha;
-                        cr += w * gb.z; cg += w * gb.w; cb += w * entry[2 * kBlendBlock].x;
+                        cr += w * gb.z; cg += w * gb.w; cb += w * blue;
                         T *= 1.0f - alpha;
                         gate = T < kTransmittanceThreshold ? __builtin_inff() : gate;
                         n_used = batch_start + j0 + k + 1;                             // kf:474
+                    }
+                    if (second) {
+#ifdef FGS_PAIR_STATS
+                        st_mine += static_cast<unsigned>(__popcll(wave_ballot(((not_mine << k2) & 0x80000000u) == 0u && gate < 1.0f)));
+                        st_pass += static_cast<unsigned>(__popcll(wave_ballot(tested2 >= gate)));
+#endif
+                        if (tested2 >= gate) {
+                            const float w = T * alpha2;
+                            cr += w * hb.z; cg += w * hb.w; cb += w * blue2;
+                            T *= 1.0f - alpha2;
+                            gate = T < kTransmittanceThreshold ? __builtin_inff() : gate;
+                            n_used = batch_start + j0 + k2 + 1;
+                        }
                     }
                 }
             }

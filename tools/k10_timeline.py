@@ -9,6 +9,11 @@ from harness import trainer as T
 sys.argv = ['bench.py'] + (['--ply', os.environ['FGS_PLY']] if os.environ.get('FGS_PLY') else [])     # FGS_PLY: a trained scene instead of S2
 params, views, _ = bench.build_scene(bench.parse())
 params['opacities'] = params['opacities'] + shift
+if os.environ.get('FGS_SCENE') == 'surface':          # bench.py's `surface_scene` extra: 2 M thin opaque disks on surfaces, look-at cameras
+    import math
+    from harness.scenes import look_at_view, make_surface_scene
+    params = make_surface_scene(2_000_000)
+    views = [look_at_view((6.4 * math.cos(2 * math.pi * k / 8), -(1.0 + 1.6 * (k % 3)), 6.4 * math.sin(2 * math.pi * k / 8)), (0.0, 1.3, 0.0), 1920, 1080, 1420.0) for k in range(8)]
 dev = torch.device('cuda:0'); be = default_backend()
 raw = C.CDLL(os.environ['FGS_HIP_LIBRARY'])
 raw.fgs_debug_k10_timeline.argtypes = [C.c_void_p, C.c_uint, C.c_int]
@@ -39,3 +44,14 @@ print(f'  tiles still running in the last 20 % of the span: {int(late.sum())}; t
       f'correlation(duration, start) {np.corrcoef(dur, start - t0)[0, 1]:.2f}')
 print('  end of the last tile per XCD (share of span):', [round(float((end[xcc == x].max() - t0) / span), 2) for x in range(8) if (xcc == x).any()])
 print('  sum of tile durations per XCD (us):', [int(dur[xcc == x].sum() / 100) for x in range(8) if (xcc == x).any()])
+
+# how far the lists are walked (max_n_processed of the training forward) against their length, for the tiles that set the span
+lay = be.blob_layout(1, g.means.shape[0], v.width, v.height, res.state[1], res.state[2])
+mx = be.view(res.buffers[1], lay, 'max_n_processed', torch.int32)[:n_tiles].cpu().numpy().astype(np.int64)
+rng = be.view(res.buffers[1], lay, 'ranges', torch.int32).reshape(-1, 2)[:n_tiles].cpu().numpy().astype(np.int64)
+ln = rng[:, 1] - rng[:, 0]
+print(f'  lists: total instances {ln.sum()}, walked {mx.sum()} ({mx.sum() / max(ln.sum(), 1):.2f}); walked per tile median {np.median(mx):.0f}, p99 {np.percentile(mx, 99):.0f}, max {mx.max()}')
+top = np.argsort(-dur)[:10]
+tile_of = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+print('  ten longest tiles: duration us / list length:', [(round(float(dur[i]) / 100, 1), int(n_list[i])) for i in top])
+print(f'  ns per walked Gaussian (sum of tile durations / walked instances): {dur.sum() * 10 / max(mx.sum(), 1):.1f}; tiles with lists >= 1024: {(ln >= 1024).sum()}, >= 2048: {(ln >= 2048).sum()}; walked >= 1024: {(mx >= 1024).sum()}')
