@@ -177,6 +177,22 @@ def cpu_baseline(params, views, stats: dict, budget_s: float = 12.0) -> dict:
             'render_mpix_per_s': view.width * view.height / 1e6 / (t_f / done)}
 
 
+def preflight(args, world: int, local_rank) -> None:
+    """Fail fast, with a message a person can act on, before any process group exists: too few visible GPUs for the ranks, or a rank whose
+    LOCAL_RANK has no device of its own (two ranks on one GPU make RCCL fail much later with 'invalid device ordinal' or a hang in the first
+    collective). --shared-device (all ranks on cuda:0, gloo) and --sim (CPU) are the two deliberate exceptions."""
+    if args.sim or args.shared_device or args.cpu_baseline_only or world <= 1:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < world:
+        raise SystemExit(f'bench.py --gpus {world}: only {n_dev} GPU(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = '
+                         f'{os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "unset"))}). One process per GPU is required; '
+                         f'use --shared-device to run the multi-rank branch on one GPU through gloo (a test, not a measurement), or --sim on CPU.')
+    if local_rank is not None and not (0 <= local_rank < n_dev):
+        raise SystemExit(f'bench.py: LOCAL_RANK={local_rank} has no device of its own ({n_dev} visible): two ranks would share a GPU. '
+                         f'Launch with --nproc-per-node {world} on a node with {world} GPUs, or pass --shared-device.')
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -184,6 +200,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if args.gpus > 1 and 'RANK' not in os.environ and not args.cpu_baseline_only:
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, RCCL over xGMI) and relay rank 0's line
+        preflight(args, world=args.gpus, local_rank=None)
         import socket
         import subprocess
         with socket.socket() as sock:
@@ -239,6 +256,7 @@ def main():
     sim = args.sim
     if not torch.cuda.is_available() and not sim:
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+    preflight(args, world=world, local_rank=local_rank)
     shared = args.shared_device and not sim
     device = torch.device('cpu') if sim else torch.device('cuda', 0 if shared else local_rank)
     if not sim:
@@ -263,7 +281,7 @@ def main():
     # Default: fgs_forward with its ONE host read of the counts -- the depth sort is enqueued behind the copy, so the wait costs nothing at
     # this size (measured: 2.66 ms vs 2.70 ms per iteration for the synchronisation-free form, whose launches are sized by bounds).
     FGS.set_async_forward(args.async_forward)
-    if 'FGS_BACKWARD_VARIANT' in os.environ:      # A/B switch of the blend-backward formulation (debug)
+    if 'FGS_BACKWARD_VARIANT' in os.environ:      # A/B of the blend-backward formulation: needs the dev library (FGS_HIP_LIBRARY=.../libfgs_hip_dev.so)
         be.lib.fgs_debug_set_backward_variant(int(os.environ['FGS_BACKWARD_VARIANT']))
 
     g = T.Gaussians(params, device)

@@ -94,11 +94,15 @@ _SIGNATURES = {
     'fgs_debug_radix_sort_temp_bytes': (C.c_size_t, [_I32, _I32]),
     'fgs_debug_radix_sort': (C.c_int32, [_P, _P, _P, _P, _I32, _I32, _I32, _P, C.c_size_t, _P]),
     'fgs_debug_depth_sort': (C.c_int32, [_P, _P, _P, _P, _I32, C.c_float, C.c_float, _P, C.c_size_t, _P]),
+}
+# libfgs_hip_dev.so only (-DFGS_DEV_SWITCHES): the A/B switchboard of tools/ and of the variant tests; bound when the library has them
+_DEV_SIGNATURES = {
     'fgs_debug_set_backward_variant': (C.c_int32, [_I32]),
     'fgs_debug_set_option': (C.c_int32, [_I32, _I32]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+DEV_LIBRARY = PACKAGE_ROOT / 'libfgs_hip_dev.so'
 
 
 def bind(path: os.PathLike | str) -> C.CDLL:
@@ -107,6 +111,10 @@ def bind(path: os.PathLike | str) -> C.CDLL:
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == the library does not export the declared ABI
         fn.restype, fn.argtypes = restype, argtypes
+    for name, (restype, argtypes) in _DEV_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = restype, argtypes
     return lib
 
 

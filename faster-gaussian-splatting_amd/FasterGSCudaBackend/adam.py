@@ -58,9 +58,10 @@ class FusedAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self) -> None:
-        if take_async_overflow():
+        if take_async_overflow([p for group in self.param_groups for p in group['params']]):
             # the rasterizer's backward pass returned zeros because its (asynchronously sized) forward pass was truncated: stepping on them would
-            # decay the moments, advance the step counts and move every parameter on momentum for a loss that was never evaluated
+            # decay the moments, advance the step counts and move every parameter on momentum for a loss that was never evaluated. The mark names
+            # the parameters of that pass: only the optimizer that owns them skips (and consumes the mark), any other FusedAdam steps normally
             clear_live_blocks()
             return
         launches: dict[tuple, list[_Update]] = {}

@@ -119,12 +119,28 @@ def async_forward_stats() -> dict:
             'views': len(_ASYNC['per_view']), 'unchecked_passes': len(_ASYNC['pending'])}
 
 
-def take_async_overflow() -> bool:
+def take_async_overflow(owned=None) -> bool:
     """True once after a backward pass had to return zero gradients because its forward pass overflowed its capacity: the optimizer step that
-    would consume them must be skipped (FusedAdam.step does)."""
-    flag = _ASYNC['step_invalid']
+    would consume them must be skipped (FusedAdam.step does). The mark names the parameter tensors of that pass (their storage addresses): with
+    `owned` (an iterable of tensors) only an optimizer that owns one of them takes it -- a second FusedAdam over other parameters neither
+    consumes the mark nor skips its own step; without arguments any pending mark is taken. The next forward pass over the same parameters
+    drops a mark nobody took (no optimizer step followed: another optimizer, an exception), so it cannot skip a later, valid step."""
+    marked = _ASYNC['step_invalid']
+    if not marked:
+        return False
+    if owned is not None and not any(t.data_ptr() in marked for t in owned):
+        return False
     _ASYNC['step_invalid'] = False
-    return flag
+    return True
+
+
+def _tensor_version(t: torch.Tensor) -> int:
+    """The autograd version counter, or None for tensors created under torch.inference_mode() (they have none, reading it raises): such a view
+    is never cached -- every pass over it is a synchronous one."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
 
 
 def _view_key(settings: RasterizerSettings):
@@ -138,7 +154,7 @@ def _view_ratio(key, w2c: torch.Tensor) -> float:
     if entry is None:
         return 0.0
     ratio, ref, version = entry
-    if ref() is not w2c or w2c._version != version:
+    if ref() is not w2c or version is None or _tensor_version(w2c) != version:
         del _ASYNC['per_view'][key]
         return 0.0
     _ASYNC['per_view'][key] = _ASYNC['per_view'].pop(key)          # most recently used last
@@ -149,7 +165,7 @@ def _record_ratio(key, w2c: torch.Tensor, ratio: float) -> None:
     import weakref
     table = _ASYNC['per_view']
     table.pop(key, None)
-    table[key] = (ratio, weakref.ref(w2c), w2c._version)
+    table[key] = (ratio, weakref.ref(w2c), _tensor_version(w2c))
     while len(table) > _ASYNC_MAX_VIEWS:
         del table[next(iter(table))]
     _ASYNC['ratio'] = max(_ASYNC['ratio'], ratio)
@@ -188,6 +204,8 @@ class _Rasterize(torch.autograd.Function):
         _require_gpu(means)
         be, n = default_backend(), means.shape[0]
         capacity, key = None, None
+        if _ASYNC['step_invalid'] and means.data_ptr() in _ASYNC['step_invalid']:
+            _ASYNC['step_invalid'] = False          # the step of that overflowed pass never came: a stale mark must not skip a later one
         if _ASYNC['enabled'] and n > 0:
             if _ASYNC['pending']:
                 _check_abandoned_passes()
@@ -232,7 +250,7 @@ class _Rasterize(torch.autograd.Function):
                               f'incomplete, so this backward pass returns zero gradients and FusedAdam.step skips the step (the view is rendered with the '
                               f'right capacity next time)', RuntimeWarning)
                 clear_live_blocks()
-                _ASYNC['step_invalid'] = True
+                _ASYNC['step_invalid'] = frozenset(t.data_ptr() for t in (means, scales, rotations, opacities, sh_rest) if t.numel())
                 if _GRAD_OUT is not None:          # a consumer that reads the provider's arena directly must not see the previous step's gradients
                     zeros = tuple(_GRAD_OUT())
                     for z in zeros:

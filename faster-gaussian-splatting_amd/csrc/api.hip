@@ -430,6 +430,7 @@ int run_blend_backward(const BackwardPlan& P, const float* grad_image, const flo
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
+    a.variant = blend_backward_variant();           // once per pass: the planning pass and the kernel see the same formulation
     { StageScope t(ST_STAGE_PIXELS, stream); FGS_HIP(launch_stage_pixels(a, stream)); }
     { StageScope t(ST_BLEND_BACKWARD, stream); FGS_HIP(launch_blend_backward(a, stream)); }     // K11 (bwd:56)
     return FGS_OK;
@@ -442,7 +443,11 @@ extern "C" {
 
 int32_t fgs_abi_version(void) { return FGS_ABI_VERSION; }
 const char* fgs_last_error(void) { return g_error; }
+#ifdef FGS_DEV_SWITCHES
+const char* fgs_build_info(void) { return "libfgs_hip_dev gfx950 wave64 tile16x12 bucket64 radix-sort-v1 +dev-switches"; }
+#else
 const char* fgs_build_info(void) { return "libfgs_hip gfx950 wave64 tile16x12 bucket64 radix-sort-v1"; }
+#endif
 
 int32_t fgs_forward(const float* means, const float* scales, const float* rotations, const float* opacities,
                     const float* sh_coefficients_0, const float* sh_coefficients_rest, int32_t n_primitives,
@@ -1080,6 +1085,7 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
     return n;
 }
 
+#ifdef FGS_DEV_SWITCHES      // the A/B switchboard exists in libfgs_hip_dev.so only (tools/, the variant tests); the product library has no process-wide knobs
 int32_t fgs_debug_set_backward_variant(int32_t variant) {
     if (variant < 0 || variant > 4) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC), 3 (live list + compacted pixels) or 4 (lane = pixel, matrix-core reduction)");
     fgs::g_backward_variant = variant;
@@ -1106,6 +1112,8 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }
+
+#endif  // FGS_DEV_SWITCHES
 
 size_t fgs_debug_radix_sort_temp_bytes(int32_t n, int32_t end_bit) {
     return n < 0 ? 0 : own_sort_temp_bytes(static_cast<uint32_t>(n), end_bit);

@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
     }
 }
 
+#ifdef FGS_DEV_SWITCHES   // A/B exhibits (variants 0 / 2 systolic, 1 strip): built into libfgs_hip_dev.so only, see docs/history.md
 template <bool GLOBAL_GRAD>
 __global__ void __launch_bounds__(kBackwardWavesPerBlock * kWave) blend_backward_kernel(const BlendBackwardArgs a) {
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -302,6 +303,13 @@ __global__ void __launch_bounds__(kTilePixels) blend_backward_strip_kernel(const
     }
 }
 
+#endif  // FGS_DEV_SWITCHES
+
+#ifdef FGS_DEV_SWITCHES
+#define FGS_ABLATE(a) ((a).ablate)      // timing experiments of the dev build (fgs_debug_set_option key 7)
+#else
+#define FGS_ABLATE(a) 0
+#endif
 // ---- variant 3 (default): work list of live buckets + compacted live pixels + two-value pipeline state -----------------
 // Three observations about the systolic form above (rocprofv3 PMC, round 1: VALU-issue bound, ~70 instructions per step):
 //  (1) 91 % of the launched buckets lie behind their tile's max_n_processed (kb:295) and exit after four dependent loads.
@@ -541,7 +549,7 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         // lane sees the sentinel
         float2 inj_a = read_inj(), inj_b;
         PixRead pix_a = read_pix(), pix_b;
-        const int n_steps = (a.ablate & 2) ? 0 : static_cast<int>(n_px) + kWave - 1;
+        const int n_steps = (FGS_ABLATE(a) & 2) ? 0 : static_cast<int>(n_px) + kWave - 1;
         for (int i = 0; i < n_steps; i += 2) {
             inj_b = read_inj(); pix_b = read_pix();
             step(inj_a, pix_a);
@@ -553,7 +561,7 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         // image gradient).
         const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
                             && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
-        if (!(a.ablate & 1)) {                                                                   // kb:459-470
+        if (!(FGS_ABLATE(a) & 1)) {                                                              // kb:459-470
             // The nine sums of a Gaussian leave as its RECORD of nine consecutive floats, SEVEN Gaussians per atomic instruction (lane l of
             // instruction k adds word 63 k + l of the bucket's 64 x 9 block, transposed through the LDS the rings no longer need). Round 4: the
             // memory pipeline merges the lanes of one atomic instruction that fall into one 128-byte line and is bound by LINE requests, about
@@ -625,6 +633,7 @@ namespace fgs {
 #endif
 
 
+#ifdef FGS_DEV_SWITCHES   // A/B exhibit (variant 4): libfgs_hip_dev.so only
 // ---- variant 4: lane = PIXEL, reduction over the pixels on the matrix cores ----------------------------------------------------------------
 // Measured in round 4 (tools/pair_stats.sh, profiles/r04_k11_pair_efficiency.txt): of the (pixel, Gaussian) lane-steps the systolic kernel above
 // issues, 33-41 % pass the alpha test (S2, the layered scene, a trained export alike); a quarter of its steps is pipeline fill, and it evaluates
@@ -935,6 +944,8 @@ extern "C" __attribute__((visibility("default"))) int fgs_debug_k11m_phases(unsi
 namespace fgs {
 #endif
 
+#endif  // FGS_DEV_SWITCHES
+
 #ifdef FGS_PAIR_STATS
 }  // namespace fgs
 extern "C" __attribute__((visibility("default"))) int fgs_debug_k11_pair_stats(unsigned long long* out, int reset) {
@@ -960,49 +971,54 @@ __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendB
     if (sum != 0.0f) a.acc[(size_t)a.hot_list[slot] * kAccRecordWords + k] += sum;      // one slot per primitive: no other writer at this point
 }
 
+#ifdef FGS_DEV_SWITCHES
 std::atomic<int> g_k11m_max_blocks{FGS_K11M_MAX_BLOCKS};   // variant 4: upper bound of its grid (fgs_debug_set_option(13, n)); items beyond it are walked grid-stride
 std::atomic<int> g_backward_ablate{0};    // fgs_debug_set_option(7, bits): timing experiments only -- 1: no atomics, 2: no step loop (results are wrong)
 std::atomic<int> g_backward_variant{3};   // 3 (default): work list + compacted pixels + two-value state; 2: systolic over all buckets / all 192 pixels, dL/dC from
                               // global memory (round 1: 0.70 ms at S2); 0: same with dL/dC in LDS (0.74); 1: strip (lane = pixel, 0.85 ms);
                               // fgs_debug_set_backward_variant()
+int blend_backward_variant() { return g_backward_variant.load(); }
+#else
+int blend_backward_variant() { return 3; }     // the product build has one formulation
+#endif
 
+// a.variant: read ONCE per backward pass by the caller (api.hip: run_blend_backward) -- the planning pass and the kernel must agree on it
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a_in, hipStream_t s) {
     BlendBackwardArgs a = a_in;
-    if (g_backward_variant >= 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(kTileScanThreads), 0, s, a);
+    if (a.variant >= 3 && a.n_buckets_cap != 0) hipLaunchKernelGGL(plan_blend_backward_kernel, dim3(1), dim3(kTileScanThreads), 0, s, a);
     else a.live_offsets = nullptr;                            // the other variants walk all buckets: no list
     hipLaunchKernelGGL(stage_pixels_kernel, dim3(a.n_tiles), dim3(kTilePixels), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
-    const BlendBackwardArgs& a = a_in;
-    if (a.n_buckets_cap == 0) return hipSuccess;
-    if (g_backward_variant == 4) {
-        BlendBackwardArgs a = a_in;
-        a.ablate = g_backward_ablate;
+    if (a_in.n_buckets_cap == 0) return hipSuccess;
+    BlendBackwardArgs a = a_in;
+#ifdef FGS_DEV_SWITCHES
+    a.ablate = g_backward_ablate;
+    if (a.variant == 4) {
         const unsigned cap_blocks = static_cast<unsigned>(g_k11m_max_blocks.load());
         const unsigned blocks = a.n_buckets_cap < cap_blocks ? a.n_buckets_cap : cap_blocks;
         hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(blocks), dim3(kWave), 0, s, a);
         hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    if (g_backward_variant == 3) {
-        BlendBackwardArgs a = a_in;
-        a.ablate = g_backward_ablate;
-        // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
-        // for the launch of a quarter of a million empty ones
-        const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;
-        hipLaunchKernelGGL(blend_backward_compact_kernel, dim3((blocks + kCompactWaves - 1) / kCompactWaves), dim3(kWave * kCompactWaves), 0, s, a);
-        hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
-        return hipGetLastError();
-    }
-    if (g_backward_variant == 1) {
+    if (a.variant == 1) {
         hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(a.n_buckets_cap), dim3(kTilePixels), 0, s, a);
         return hipGetLastError();
     }
-    const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
-    if (g_backward_variant == 2) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, a);
+    if (a.variant != 3) {
+        const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
+        if (a.variant == 2) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+#endif
+    // grid-stride over the live list: at most 64 Ki single-wave workgroups, so a scene with few live buckets does not pay
+    // for the launch of a quarter of a million empty ones
+    const unsigned blocks = a.n_buckets_cap < kBackwardMaxBlocks ? a.n_buckets_cap : kBackwardMaxBlocks;
+    hipLaunchKernelGGL(blend_backward_compact_kernel, dim3((blocks + kCompactWaves - 1) / kCompactWaves), dim3(kWave * kCompactWaves), 0, s, a);
+    hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

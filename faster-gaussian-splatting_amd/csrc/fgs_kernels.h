@@ -115,7 +115,8 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     uint32_t* live_offsets;                   // [T] first list slot of each tile (planning pass -> stage_pixels_kernel)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
     int proper_aa;
-    int ablate;                           // debug timing experiments (fgs_debug_set_option key 7); 0 in production
+    int ablate;                           // dev build only: timing experiments (fgs_debug_set_option key 7)
+    int variant;                          // K11 formulation, read once per backward pass (blend_backward_variant(); 3 in the product build)
 };
 hipError_t launch_stage_pixels(const BlendBackwardArgs& a, hipStream_t s);      // per-pixel staging pass
 hipError_t launch_blend_backward(const BlendBackwardArgs& a, hipStream_t s);    // K11 proper
@@ -230,9 +231,12 @@ hipError_t run_morton_order(const float* means, const float* lo, const float* hi
 extern std::atomic<int> g_adam_reverse;
 extern std::atomic<int> g_adam_nontemporal;                                  // 0 | 1
 extern std::atomic<int> g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
+#ifdef FGS_DEV_SWITCHES
 extern std::atomic<int> g_backward_ablate;
 extern std::atomic<int> g_k11m_max_blocks;
-extern std::atomic<int> g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip (blend_backward.hip)
+extern std::atomic<int> g_backward_variant;                                  // 3 compact (default), 0 / 2 systolic, 1 strip, 4 lane = pixel (blend_backward.hip)
+#endif
+int blend_backward_variant();                                                // the K11 formulation of this pass (always 3 in the product build)
 hipError_t launch_wave_selftest(uint32_t* out /*[4*64]*/, hipStream_t s);
 
 }  // namespace fgs

@@ -39,9 +39,10 @@ def l1_grad(image: torch.Tensor, target: torch.Tensor, scale: float) -> torch.Te
 
 class ViewParallelTrainer:
     def __init__(self, backend: Backend, params: dict, lrs: dict, *, mode: str = 'allreduce', group=None,
-                 betas=(0.9, 0.999), eps: float = 1e-15, loss: str = 'l1_dssim') -> None:
+                 betas=(0.9, 0.999), eps: float = 1e-15, loss: str = 'l1_dssim', emulate_reduce_scatter: bool = False) -> None:
         assert mode in ('allreduce', 'zero1') and loss in ('l1', 'l1_dssim')
         self.be, self.mode, self.group, self.betas, self.eps, self.loss = backend, mode, group, betas, eps, loss
+        self.emulate_reduce_scatter = bool(emulate_reduce_scatter)      # tests only: zero1's reduce-scatter as a full all-reduce
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         device = params['means'].device
@@ -101,8 +102,12 @@ class ViewParallelTrainer:
         self.be.adam_step_multi(g, p, m, v, [self.step_count] * len(segs), [self.lrs[k] for k, _, _ in segs], self.betas[0], self.betas[1], self.eps)
 
     def _reduce_scatter(self) -> torch.Tensor:
+        """This rank's slice of the summed gradient arena, in place (output = a view of the input: the in-place form of the collective). The SAME
+        call on every backend -- RCCL on the GPUs, gloo in the CPU tests (torch's gloo backend implements reduce_scatter_tensor) -- so the CPU tests
+        execute the call path the hardware run takes. `emulate_reduce_scatter` (tests only) forces the all-reduce form a backend without the
+        collective would need; the two are compared in tests/test_distributed.py."""
         mine = self.grad_arena[self.rank * self.chunk:(self.rank + 1) * self.chunk]
-        if dist.get_backend(self.group) == 'gloo':      # gloo has no reduce_scatter: emulate (CPU tests only)
+        if self.emulate_reduce_scatter:
             dist.all_reduce(self.grad_arena, group=self.group)
         else:
             dist.reduce_scatter_tensor(mine, self.grad_arena, group=self.group)
@@ -130,7 +135,8 @@ class ViewParallelTrainer:
             self._reduce_scatter()
             lo = self.rank * self.chunk
             self._adam(lo, lo + self.chunk, lo)
-            dist.all_gather_into_tensor(self.param_arena, self.param_arena[lo:lo + self.chunk].clone(), group=self.group)
+            # in place: the input is this rank's slice of the output arena (the in-place form of all-gather; no 1/G-arena copy per step)
+            dist.all_gather_into_tensor(self.param_arena, self.param_arena[lo:lo + self.chunk], group=self.group)
         return image
 
     def gather_densification_info(self) -> torch.Tensor:

@@ -129,6 +129,10 @@ class ShardedTrainer:
         """pieces[j] goes to rank j; returns the concatenation of what ranks 0..G-1 sent here (rows along dim 0)."""
         if self.world == 1:
             return pieces[0]
+        # an uneven all_to_all_single with wrong split lists fails deep inside the backend (or hangs a peer): check them here, readably
+        if len(pieces) != self.world or len(recv_rows) != self.world or any(int(x) < 0 for x in recv_rows):
+            raise ValueError(f'rank {self.rank}: all-to-all over {self.world} ranks got {len(pieces)} pieces to send and {len(recv_rows)} receive counts '
+                             f'{[int(x) for x in recv_rows]}: one (non-negative) entry per rank is required')
 
         def run():
             send = torch.cat(list(pieces), dim=0)

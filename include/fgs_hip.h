@@ -326,6 +326,9 @@ int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t
  * needs (fgs_debug_set_option(9, m) selects the variants). temp as for fgs_debug_radix_sort with end_bit 32. */
 int32_t fgs_debug_depth_sort(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, float near_plane, float far_plane,
                              void* temp, size_t temp_bytes, void* stream);
+/* ---- libfgs_hip_dev.so only (built with -DFGS_DEV_SWITCHES: `make -C faster-gaussian-splatting_amd/csrc dev`). The product library has ONE formulation
+ * of every kernel and no process-wide switches; the A/B tools under tools/ and the variant tests load the dev library. ---- */
+#ifdef FGS_DEV_SWITCHES
 /* Selects the blend-backward formulation: 3 (default) = live-bucket list + compacted pixels + two-value pipeline state, 2 / 0 =
  * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel, DPP reductions), 4 = lane = pixel walk with the
  * per-Gaussian sums reduced on the matrix cores (round 4; measured against 3 in profiles/r04_k11m_closeout.txt). A/B switch for tests and
@@ -345,6 +348,8 @@ int32_t fgs_debug_set_backward_variant(int32_t variant);
  * block plan without sorting (XCD x = block column x), 13 = upper bound of the grid of blend-backward variant 4.
  * Apart from key 7, results never depend on them. */
 int32_t fgs_debug_set_option(int32_t key, int32_t value);
+
+#endif /* FGS_DEV_SWITCHES */
 
 #ifdef __cplusplus
 }

@@ -44,3 +44,18 @@ def hip_backend():
     import FasterGSCudaBackend  # noqa: F401  (fails loudly if libfgs_hip.so is missing)
     from FasterGSCudaBackend._backend import default_backend
     return default_backend()
+
+
+@pytest.fixture(scope='session')
+def hip_dev_backend():
+    """Backend bound to libfgs_hip_dev.so: the product sources built with -DFGS_DEV_SWITCHES (K11's A/B variants, fgs_debug_set_option). Only the
+    tests that compare formulations use it; everything else runs on the product library."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    import helpers
+    _lib, _backend = helpers.backend_modules()
+    if not _lib.DEV_LIBRARY.exists():
+        import subprocess
+        subprocess.run(['make', '-C', str(_lib.DEV_LIBRARY.parent / 'csrc'), '-j8', 'dev'], check=True, capture_output=True)
+    return _backend.Backend(_lib.bind(_lib.DEV_LIBRARY))

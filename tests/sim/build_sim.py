@@ -16,6 +16,7 @@ FLAGS = ['-std=c++17', '-O2', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unuse
 # FGS_SIM_SANITIZE=undefined: an occasional deep check -- the kernels' integer / shift / alignment / bounds-of-static-array behaviour under UBSan
 # (reports go to stderr, the run continues); rebuild with `python tests/sim/build_sim.py` afterwards to get the plain library back
 # FGS_SIM_DEFINES="-DFGS_PREPROCESS_ITEMS=2 ...": compile-time experiments of the product sources, checked on the simulation before a GPU A/B
+FLAGS += ['-DFGS_DEV_SWITCHES']      # the simulation carries the dev build's A/B variants and switches (the sim tests compare formulations)
 FLAGS += os.environ.get('FGS_SIM_DEFINES', '').split()
 SAN = [f'-fsanitize={os.environ["FGS_SIM_SANITIZE"]}', '-fsanitize-recover=all', '-g'] if os.environ.get('FGS_SIM_SANITIZE') else []
 

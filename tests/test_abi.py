@@ -25,11 +25,25 @@ def hip_lib():
 
 def test_header_symbols_are_exported_and_bound(hip_lib):
     header = (REPO / 'include' / 'fgs_hip.h').read_text()
-    declared = set(re.findall(r'\b(fgs_[a-z0-9_]+)\s*\(', header)) - {'fgs_resize_fn'}
+    dev_block = re.search(r'#ifdef FGS_DEV_SWITCHES\n(.*?)#endif /\* FGS_DEV_SWITCHES \*/', header, re.S)
+    product_header = header.replace(dev_block.group(0), '')
+    find = lambda text: set(re.findall(r'^(?:int32_t|size_t|const char\*)\s+(fgs_[a-z0-9_]+)\s*\(', text, re.M))
+    declared, dev_declared = find(product_header), find(dev_block.group(1))
     _lib, _ = helpers.backend_modules()
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert dev_declared == set(_lib._DEV_SIGNATURES) == {'fgs_debug_set_backward_variant', 'fgs_debug_set_option'}
     for name in declared:
         assert getattr(hip_lib, name) is not None
+    # the product library has no process-wide switches; the dev library (same sources, -DFGS_DEV_SWITCHES) has everything
+    for name in dev_declared:
+        assert not hasattr(hip_lib, name), name
+    dev = _lib.DEV_LIBRARY
+    if not dev.exists():
+        subprocess.run(['make', '-C', str(dev.parent / 'csrc'), '-j8', 'dev'], check=True)
+    dev_lib = _lib.bind(dev)
+    for name in declared | dev_declared:
+        assert getattr(dev_lib, name) is not None
+    assert b'dev-switches' in dev_lib.fgs_build_info() and b'dev' not in hip_lib.fgs_build_info()
     assert hip_lib.fgs_abi_version() == 2
     assert b'gfx950' in hip_lib.fgs_build_info()
 

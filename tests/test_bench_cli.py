@@ -22,3 +22,14 @@ def test_cpu_baseline_only_prints_exactly_one_json_line_whatever_the_libraries_p
     assert len(lines) == 1, r.stdout[:500]
     d = json.loads(lines[0])
     assert d['kind'] == 'port' and d['unit'] == 'iters/s' and d['value'] > 0 and d['cores'] >= 1
+
+
+def test_multi_rank_preflight_fails_fast_and_readably():
+    """`bench.py --gpus N` on a node with fewer than N visible GPUs (here: none) stops before any rank is launched, with a message that names the
+    remedy -- not a torchrun traceback or a hang in the first collective."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / 'bench.py'), '--gpus', '2', '--no-extras', '--no-cpu-baseline'], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'GPU(s) visible' in r.stderr and '--shared-device' in r.stderr and r.stdout.strip() == ''

@@ -43,7 +43,7 @@ def _worker(rank, world, mode, port, out_dir):
         import helpers
         from harness.distributed import ViewParallelTrainer
         params, settings, targets = _scene()
-        tr = ViewParallelTrainer(helpers.sim_backend(), params, LRS, mode=mode)
+        tr = ViewParallelTrainer(helpers.sim_backend(), params, LRS, mode=mode.split('+')[0], emulate_reduce_scatter=mode.endswith('+emulated'))
         for _ in range(2):
             tr.step(settings[rank], targets[rank])
         info = tr.gather_densification_info()
@@ -71,9 +71,11 @@ def _single_process_reference():
     return {k: tr.params[k].clone() for k in SEGMENTS}, tr.densification_info.clone()
 
 
-@pytest.mark.parametrize('mode', ['allreduce', 'zero1'])
+@pytest.mark.parametrize('mode', ['allreduce', 'zero1', 'zero1+emulated'])
 def test_view_parallel_world2_gloo(tmp_path, mode):
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == 'allreduce' else 1)
+    """zero1 runs dist.reduce_scatter_tensor and the in-place dist.all_gather_into_tensor -- the calls RCCL gets on the GPUs (torch's gloo backend
+    implements both); 'zero1+emulated' is the all-reduce form of the reduce-scatter, which must give the same parameters."""
+    port = 29500 + (os.getpid() % 2000) + ('allreduce', 'zero1', 'zero1+emulated').index(mode)
     mp.spawn(_worker, args=(2, mode, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / f'{mode}_0.pt')
     r1 = torch.load(tmp_path / f'{mode}_1.pt')

@@ -45,7 +45,8 @@ def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, l
     dens_dev, dens_o = torch.zeros(2, n, device=DEV), np.zeros((2, n), np.float32)
     masked = np.zeros(n, bool)
     ever_visible = np.zeros(n, bool)
-    hip_backend.lib.fgs_debug_set_option(3, 1 if single_kernel else 0)
+    if not single_kernel:                      # the round-1 two-kernel form exists in the dev library only (fgs_debug_set_option)
+        assert hip_backend.lib.fgs_debug_set_option(3, 0) == 0
     try:
         for step in range(1, steps + 1):
             res = hip_backend.forward(*[dP[k] for k in helpers.NAMES], RS)
@@ -61,7 +62,8 @@ def _run(hip_backend, oracle, params, view, K=16, aa=False, steps=3, tol=1e-4, l
                 oracle.adam_step(np.ascontiguousarray(g[GRAD_OF[k]].reshape(oP[k].shape)), oP[k], oM[k], oV[k], step, lr)
             del res
     finally:
-        hip_backend.lib.fgs_debug_set_option(3, 1)
+        if not single_kernel:
+            hip_backend.lib.fgs_debug_set_option(3, 1)
     if DEV != 'cpu':
         torch.cuda.synchronize()
     assert masked.mean() < (1e-3 * steps + 2.0 / n if masked_budget is None else masked_budget), (label, 'masked Gaussians', float(masked.mean()))
@@ -120,8 +122,9 @@ def test_fused_unaligned_parameters_and_moments(hip_backend, oracle):
     _run(hip_backend, oracle, p, v, steps=2, label='unaligned', unaligned=True)
 
 
-def test_fused_two_kernel_form_s0(hip_backend, oracle):
-    """The round-1 two-kernel form (fgs_debug_set_option(3, 0)) stays selectable for A/B and must meet the same bar."""
+def test_fused_two_kernel_form_s0(hip_dev_backend, oracle):
+    """The round-1 two-kernel form (fgs_debug_set_option(3, 0), libfgs_hip_dev.so) stays selectable for A/B and must meet the same bar."""
+    hip_backend = hip_dev_backend
     params, view = make_s0()
     params['means'][:100, 2] = -10.0
     _run(hip_backend, oracle, params, view, steps=2, label='S0 two-kernel', single_kernel=False)

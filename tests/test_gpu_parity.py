@@ -131,8 +131,10 @@ def test_partial_tiles_sh_degrees_antialiasing(hip_backend, oracle, w, h, K, aa)
 
 
 @pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
-def test_blend_backward_variants_agree_with_oracle(hip_backend, oracle, variant):
-    """Both formulations of K11 (0 systolic lane=Gaussian, 1 strip lane=pixel) against the oracle on a deep scene."""
+def test_blend_backward_variants_agree_with_oracle(hip_dev_backend, oracle, variant):
+    """All formulations of K11 (0 / 2 systolic lane = Gaussian, 1 strip lane = pixel, 3 the product's, 4 lane = pixel + matrix cores) against the oracle
+    on a deep scene -- on libfgs_hip_dev.so: the product library carries variant 3 only."""
+    hip_backend = hip_dev_backend
     p, v = make_s0(seed=11, n=1500)
     p['means'][:, :2] *= 0.3
     hip_backend.lib.fgs_debug_set_backward_variant(variant)
@@ -162,8 +164,10 @@ def test_equal_depth_keys_keep_every_order_independent_quantity(hip_backend, ora
     assert float(np.abs(res.image.cpu().numpy() - f['image']).max()) < 0.5          # a different order of tied layers, not a different scene
 
 
-def test_uninitialised_scratch_is_harmless(hip_backend, oracle):
-    """Same as the simulation test: 0xFF-poisoned scratch must not reach any output (NaN checkpoints of finished pixels)."""
+def test_uninitialised_scratch_is_harmless(hip_dev_backend, oracle):
+    """Same as the simulation test: 0xFF-poisoned scratch must not reach any output (NaN checkpoints of finished pixels); every K11 formulation
+    of the dev library (variant 3 = the product's kernel, same source)."""
+    hip_backend = hip_dev_backend
     p, v = make_s0(seed=11, n=1500)
     p['means'][:, :2] *= 0.15
     p['opacities'] -= 2.5
@@ -561,15 +565,36 @@ def test_async_forward_through_the_public_operators(hip_backend, oracle):
             _, grads = step()
         assert any('exceeded the capacity' in str(x.message) for x in w) and async_forward_stats()['overflows'] == 1
         assert all(float(t.abs().max()) == 0.0 for t in grads)
-        # ... and the optimizer step that would consume those zeros is SKIPPED: no step count, no motion on momentum (round-3 advisor finding)
+        # ... and the optimizer step that would consume those zeros is SKIPPED: no step count, no motion on momentum (round-3 advisor finding) -- by the
+        # optimizer that OWNS the parameters of the overflowed pass, and only by it (round-4 advisor finding: the mark names those parameters)
         from FasterGSCudaBackend import FusedAdam, take_async_overflow
+        assert take_async_overflow()                                             # the mark of the pass above (its parameters are gone): taken here
+        P = [torch.nn.Parameter(params[k].to(DEV)) for k in helpers.NAMES]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (diff_rasterize(*P, torch.empty(0, device=DEV), RS) * gi.to(DEV)).sum().backward()      # overflows again (headroom 0.4): zero gradients, mark set
         q = torch.nn.Parameter(torch.ones(64, 3, device=DEV))
-        opt = FusedAdam([{'params': [q], 'lr': 1e-2}], lr=0.0, eps=1e-15)
+        other = FusedAdam([{'params': [q], 'lr': 1e-2}], lr=0.0, eps=1e-15)
         q.grad = torch.ones_like(q)
-        opt.step()                                                               # consumes the mark: nothing happens
-        assert float((q.detach() - 1.0).abs().max()) == 0.0 and not opt.state[q] and not take_async_overflow()
-        opt.step()                                                               # the next step is an ordinary one
-        assert float((q.detach() - 1.0).abs().max()) > 0.0 and opt.state[q]['step'] == 1
+        other.step()                                                             # an unrelated optimizer neither skips nor consumes the mark
+        assert float((q.detach() - 1.0).abs().max()) > 0.0 and other.state[q]['step'] == 1
+        owner = FusedAdam([{'params': [p], 'lr': 1e-2} for p in P], lr=0.0, eps=1e-15)
+        before = [p.detach().clone() for p in P]
+        owner.step()                                                             # the owner consumes the mark: nothing happens
+        assert all(torch.equal(a, p.detach()) for a, p in zip(before, P)) and not owner.state[P[0]] and not take_async_overflow()
+        for p in P:
+            p.grad = torch.ones_like(p)
+        owner.step()                                                             # the next step is an ordinary one
+        assert float((P[0].detach() - before[0]).abs().max()) > 0.0 and owner.state[P[0]]['step'] == 1
+        # a mark nobody took is dropped by the next forward pass over the same parameters (it must not skip a later, valid step)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (diff_rasterize(*P, torch.empty(0, device=DEV), RS) * gi.to(DEV)).sum().backward()
+        set_async_forward(True)
+        with torch.no_grad():
+            diff_rasterize(*P, torch.empty(0, device=DEV), RS)
+        assert not take_async_overflow()
+        set_async_forward(True, headroom=0.4)
         set_async_forward(True)                  # default headroom again: the refreshed ratio renders the view completely
         image, grads = step()
         assert torch.equal(image, ref_image)

@@ -127,9 +127,21 @@ def test_depth_sort_many_workgroups_sim():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [3, 2, 1, 0])
 @pytest.mark.parametrize('n', [4097, 2_049_194, 17_000_000])
-def test_depth_sort_on_device(hip_backend, n, mode):
+def test_depth_sort_on_device_product(hip_backend, n):
+    """The product library's depth sort (key - bits(near) in 9-bit passes, 4096-item workgroups)."""
+    _check_depth(hip_backend, n, 0.2, 1e4, 'cuda', n + 1)
+    if n == 2_049_194:
+        _check_depth(hip_backend, n, 0.2, 1e4, 'cuda', 3, n_distinct=1000)   # heavy duplicates: stability
+        _check_depth(hip_backend, n, 0.0, 1e4, 'cuda', 4)                    # base 0: 31 bits, four passes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [3, 2, 0])
+@pytest.mark.parametrize('n', [4097, 2_049_194, 17_000_000])
+def test_depth_sort_on_device(hip_dev_backend, n, mode):
+    """The A/B modes of the dev library (fgs_debug_set_option(9, mode))."""
+    hip_backend = hip_dev_backend
     assert hip_backend.lib.fgs_debug_set_option(9, mode) == 0
     try:
         _check_depth(hip_backend, n, 0.2, 1e4, 'cuda', n + mode)
