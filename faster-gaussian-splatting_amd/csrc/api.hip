@@ -106,6 +106,7 @@ Geometry geometry_of(int width, int height) {
 struct PrimitiveBuffers {             // cf. bu:45-94
     PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters; uint32_t* hot_list;
     uint4* foot[2]; uint32_t* tile_counts;      // footprint rows in compaction / depth order, tile counts in depth order (fgs_math.h, radix_sort.hip)
+    uint32_t* wave_sums; uint32_t* block_sums;  // their sums per 64-Gaussian wave segment / per 4096-Gaussian block (binning.hip)
     char* temp; size_t temp_bytes;
     static PrimitiveBuffers carve(Carver& c, uint32_t n) {
         PrimitiveBuffers b;
@@ -118,6 +119,8 @@ struct PrimitiveBuffers {             // cf. bu:45-94
         b.hot_list = c.take<uint32_t>("hot_list", kMaxHot);
         b.foot[0] = c.take<uint4>("foot0", n); b.foot[1] = c.take<uint4>("foot1", n);
         b.tile_counts = c.take<uint32_t>("tile_counts", n);
+        b.wave_sums = c.take<uint32_t>("wave_sums", (static_cast<size_t>(n) + 63) / 64 + 64);
+        b.block_sums = c.take<uint32_t>("block_sums", (static_cast<size_t>(n) + 4095) / 4096 + 1);
         b.temp_bytes = depth_sort_temp_bytes(n);
         b.temp = c.take<char>("sort_temp", b.temp_bytes);
         return b;
@@ -138,7 +141,11 @@ struct TileBuffers {                  // cf. bu:126-152; final_T / n_processed a
             b.max_n_processed = c.take<uint32_t>("max_n_processed", t);
             b.final_T = c.take<float>("final_T", (size_t)t * kTilePixels);
             b.n_processed = c.take<uint32_t>("n_processed", (size_t)t * kTilePixels);
-            b.temp_bytes = bucket_scan_temp_bytes(t);
+#ifdef FGS_DEV_SWITCHES
+            b.temp_bytes = bucket_scan_temp_bytes(t);      // the library scan, an A/B option of the dev build
+#else
+            b.temp_bytes = 0;
+#endif
             b.temp = c.take<char>("scan_temp", b.temp_bytes);
             b.live_count = c.take<uint32_t>("live_count", 4);
             b.live_offsets = c.take<uint32_t>("live_offsets", t);
@@ -181,7 +188,9 @@ struct BackwardScratch {
 };
 
 std::atomic<int> g_seq_tiles{kSeqTiles};           // fgs_debug_set_option key 5
+#ifdef FGS_DEV_SWITCHES
 std::atomic<int> g_library_bucket_scan{0};         // fgs_debug_set_option key 11: 1 = rocPRIM scan for K8+K9 and no tile plan (round-2 form, A/B)
+#endif
 std::atomic<int> g_fused_single_kernel{1};         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
@@ -334,7 +343,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     // K2-K4 (fwd:104-127)
     if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, visible_ptr, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream)); }
     const uint32_t* sorted_prims = pb.prims[depth_sel];
-    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(run_offsets_scan(pb.temp, pb.temp_bytes, pb.tile_counts, pb.offsets, n_visible, visible_ptr, stream)); }
+    { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(launch_tile_count_sums(pb.tile_counts, pb.wave_sums, pb.block_sums, n_visible, visible_ptr, stream)); }
 
     // K5-K7 (fwd:179-216)
     Carver inst_size(nullptr);
@@ -343,7 +352,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
-    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, pb.foot[1], sorted_prims, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
+    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, pb.foot[1], sorted_prims, pb.wave_sums, pb.block_sums, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
                                                                                  visible_ptr, device_counts ? n_instances : 0xffffffffu, pb.counters,
                                                                                  pb.keys[depth_sel ^ 1], pb.counters + 2, stream)); }
     int tile_sel = 0;
@@ -364,9 +373,12 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     ba.row_group = row_group;
     if (need_scan) {
         StageScope t(ST_BUCKET_SCAN, stream);
+#ifdef FGS_DEV_SWITCHES
         if (g_library_bucket_scan && training) {
             FGS_HIP(run_bucket_scan(tb.temp, tb.temp_bytes, tb.ranges, tb.bucket_offsets, geo.n_tiles, stream));      // (A/B: rocPRIM scan, no plan)
-        } else {
+        } else
+#endif
+        {
             FGS_HIP(launch_plan_tiles(tb.ranges, tb.bucket_offsets, need_plan ? tb.tile_plan : nullptr, geo.n_tiles, geo.grid_w, geo.grid_h, stream));
             ba.tile_plan = need_plan ? tb.tile_plan : nullptr;
         }

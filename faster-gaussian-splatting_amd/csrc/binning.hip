@@ -12,19 +12,15 @@
 #include <fgs_wave.h>
 #include "fgs_tile_scan.h"
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
+#ifdef FGS_DEV_SWITCHES
+#include <rocprim/device/device_scan.hpp>            // the library scan of the per-tile bucket counts: an A/B option of the dev build only
 #include <rocprim/iterator/transform_iterator.hpp>
+#endif
 
 namespace fgs {
 
 // ---- K2-K4 -------------------------------------------------------------------------------------------------
-size_t depth_sort_temp_bytes(uint32_t n) {
-    size_t scan_bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, n, rocprim::plus<uint32_t>());
-    const size_t sort_bytes = own_sort_temp_bytes(n, 32);
-    return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-}
+size_t depth_sort_temp_bytes(uint32_t n) { return own_sort_temp_bytes(n, 32); }
 
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
                           const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s) {
@@ -34,20 +30,47 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
     return own_depth_sort(temp, temp_bytes, keys, vals, selector, n_visible, n_visible_ptr, range, s, &payload);
 }
 
-// the scan input when the host does not know the visible count: entries at and beyond *count contribute nothing
-struct CountGuarded {
-    const uint32_t* tile_counts; const uint32_t* count;
-    __host__ __device__ uint32_t operator()(uint32_t i) const { return i < *count ? tile_counts[i] : 0u; }
-};
-
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* tile_counts, uint32_t* offsets,
-                            uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s) {
-    if (n_visible == 0) return hipSuccess;
-    if (n_visible_ptr != nullptr) {       // n_visible is a bound (the primitive count), the exact count lives on the device
-        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), CountGuarded{tile_counts, n_visible_ptr});
-        return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
+// K3 + K4 (apply_depth_ordering_cu + ExclusiveSum, kf:211-221, fwd:104-127) without a device-wide scan. The offsets K5 needs are the exclusive
+// prefix sums of the tile counts in depth order. Until round 4 this was rocPRIM's look-back scan: two launches, 0.020 ms for an 8 MB stream (0.032 with
+// the gather it had then). A wave of K5 only needs the offset of ITS first Gaussian -- inside the wave a DPP scan does the rest -- so ONE small kernel
+// reduces the counts to a sum per 64-Gaussian wave segment and per 4096-Gaussian block, and a K5 wave adds up the block sums in front of its block
+// (500 words at S2: eight L2-resident loads per lane) and the <= 63 segment sums in front of it inside its block. No prefix over the block sums is
+// formed: a "last workgroup" doing it behind a ticket needs a device-scope release fence per workgroup, and on this chip that fence writes back the
+// XCD's L2 -- measured 0.016 ms for the kernel against 0.020 for the library scan it replaced (profiles/r05_ab_scan_sums.txt). K5 writes the
+// per-Gaussian offsets on its way (the second instance kernel and the tests read them).
+constexpr int kSumBlock = 4096, kSumThreads = 256, kSumPerThread = kSumBlock / kSumThreads;      // 16 consecutive counts per thread = a quarter wave segment
+__global__ void __launch_bounds__(kSumThreads) tile_count_sums_kernel(const uint32_t* __restrict__ tile_counts, const uint32_t n_value,
+                                                                      const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ wave_sums,
+                                                                      uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_part[kSumThreads / kWave];
+    const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
+    if (blockIdx.x * static_cast<uint32_t>(kSumBlock) >= n) return;         // workgroup-uniform (grid sized by a bound in the synchronisation-free forward)
+    const uint32_t first = blockIdx.x * kSumBlock + threadIdx.x * kSumPerThread;
+    uint32_t sum = 0;
+    if (first + kSumPerThread <= n) {
+        const uint4* q = reinterpret_cast<const uint4*>(tile_counts + first);
+#pragma unroll
+        for (int k = 0; k < kSumPerThread / 4; ++k) { const uint4 v = q[k]; sum += v.x + v.y + v.z + v.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSumPerThread; ++k) sum += first + k < n ? tile_counts[first + k] : 0u;
     }
-    return rocprim::exclusive_scan(temp, temp_bytes, tile_counts, offsets, 0u, n_visible, rocprim::plus<uint32_t>(), s);
+    // a 64-Gaussian wave segment of K5 = 4 consecutive threads here
+    const uint32_t incl = wave_inclusive_sum(sum);
+    const unsigned lane = lane_id();
+    const uint32_t before = wave_shuffle(incl, (lane & ~3u) - 1u);                                   // inclusive sum of the lane in front of this group of four (all lanes shuffle)
+    if ((lane & 3u) == 3u) wave_sums[(first - 3u * kSumPerThread) / kWave] = incl - (lane >= 4u ? before : 0u);
+    if (lane == kWave - 1) s_part[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+hipError_t launch_tile_count_sums(const uint32_t* tile_counts, uint32_t* wave_sums, uint32_t* block_sums,
+                                  uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s) {
+    if (n_visible == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_count_sums_kernel, dim3((n_visible + kSumBlock - 1) / kSumBlock), dim3(kSumThreads), 0, s, tile_counts, n_visible, n_visible_ptr,
+                       wave_sums, block_sums);
+    return hipGetLastError();
 }
 
 // ---- K5 ----------------------------------------------------------------------------------------------------
@@ -64,7 +87,7 @@ hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* tile_
 // re-tested from the record by the whole wave, 64 candidate tiles per step, with ballot-prefix write slots (also consecutive).
 template <typename KeyT>
 __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
-    const uint4* __restrict__ foot, const uint32_t* __restrict__ offsets,
+    const uint4* __restrict__ foot, const uint32_t* __restrict__ wave_sums, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets,
     const PrimRec* __restrict__ rec, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w,
     const uint32_t n_visible_value, const uint32_t* __restrict__ n_visible_ptr, const uint32_t capacity, uint32_t* __restrict__ counters,
     uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
@@ -90,7 +113,14 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     const unsigned i = active ? gid : n_visible - 1;
     const uint4 row = foot[i];
     const uint32_t prim = row.x;
-    const uint32_t my_off = offsets[i];
+    // this Gaussian's first output slot (tile_count_sums_kernel above): the instances of the 4096-Gaussian blocks in front of the wave's block, of
+    // the wave segments in front of it inside the block, and of the lanes in front of it inside the wave
+    const unsigned segment = gid >> 6, block_of_wave = segment >> 6, in_block = segment & 63u;
+    uint32_t before_wave = lane < in_block ? wave_sums[(segment & ~63u) + lane] : 0u;
+    for (unsigned j = lane; j < block_of_wave; j += kWave) before_wave += block_sums[j];
+    const uint32_t n_tiles_mine = active ? footprint_tile_count(row) : 0u;
+    const uint32_t my_off = wave_sum(before_wave) + wave_exclusive_sum(n_tiles_mine);
+    if (active) offsets[i] = my_off;                   // bu:60 -- read by the second instance kernel (and by the tests)
     const bool small = active && row.y != kFootprintEscape;
 
     // ---- bitmap footprints: their candidates end to end, 64 per step ----
@@ -235,7 +265,8 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
     }
 }
 
-hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* offsets,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* wave_sums,
+                                   const uint32_t* block_sums, uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s) {
@@ -243,12 +274,12 @@ hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, cons
     const dim3 grid((n_visible + kInstanceBlock - 1) / kInstanceBlock), block(kInstanceBlock);
     const dim3 big_grid(n_visible < 1024u ? n_visible : 1024u);       // grid-stride over the (short) device-side work list
     if (key_bytes == 2) {
-        hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, foot_sorted, offsets, rec,
+        hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, foot_sorted, wave_sums, block_sums, offsets, rec,
                            static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint16_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
                            static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, capacity);
     } else {
-        hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, foot_sorted, offsets, rec,
+        hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, foot_sorted, wave_sums, block_sums, offsets, rec,
                            static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
         hipLaunchKernelGGL(create_instances_big_kernel<uint32_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
                            static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, capacity);
@@ -423,6 +454,7 @@ hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint
     return hipGetLastError();
 }
 
+#ifdef FGS_DEV_SWITCHES
 // the library scan (rocPRIM): kept for A/B runs (fgs_debug_set_option(11, 1))
 struct BucketsOfRange {
     __host__ __device__ uint32_t operator()(const uint2& r) const { return (r.y - r.x + kBucket - 1) / kBucket; }
@@ -437,5 +469,7 @@ hipError_t run_bucket_scan(void* temp, size_t temp_bytes, const uint2* ranges, u
     auto in = rocprim::make_transform_iterator(ranges, BucketsOfRange{});
     return rocprim::inclusive_scan(temp, temp_bytes, in, bucket_offsets, n_tiles, rocprim::plus<uint32_t>(), s);
 }
+
+#endif  // FGS_DEV_SWITCHES
 
 }  // namespace fgs

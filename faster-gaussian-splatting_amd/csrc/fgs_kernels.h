@@ -42,15 +42,18 @@ size_t depth_sort_temp_bytes(uint32_t n);
 // tile_counts their tile counts in depth order; vals[selector] = the primitives in depth order.
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
                           const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s);
+// K3 + K4: sums of the depth-ordered tile counts per 64-Gaussian wave segment (wave_sums[ceil(n / 64)]) and per 4096-Gaussian block
+// (block_sums[ceil(n / 4096)]). K5 derives every Gaussian's first output slot from them.
 // n_visible_ptr != nullptr: n_visible is a bound (the primitive count) and the exact count is read on the device
-hipError_t run_offsets_scan(void* temp, size_t temp_bytes, const uint32_t* tile_counts, uint32_t* offsets,
-                            uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s);
+hipError_t launch_tile_count_sums(const uint32_t* tile_counts, uint32_t* wave_sums, uint32_t* block_sums,
+                                  uint32_t n_visible, const uint32_t* n_visible_ptr, hipStream_t s);
 
 // K5-K7: instance creation, tile sort, per-tile ranges. key_bytes is 2 (<= 65536 tiles) or 4.
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
 // The *_ptr forms serve the host-synchronisation-free forward pass: counts are bounds / capacities, the exact ones are read on the device
 // (n_visible from counters[0]; the instance count clamped to `capacity` is written to counters[5], an overflow flag to counters[6]).
-hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* offsets,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* wave_sums,
+                                   const uint32_t* block_sums, uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
                                    uint32_t* big_list, uint32_t* big_count, hipStream_t s);
@@ -84,7 +87,9 @@ hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16
 // K8+K9: inclusive scan of ceil(len/kBucket) per tile, and the tile -> workgroup plan of K10 (one single-workgroup kernel)
 hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint32_t* tile_plan, uint32_t n_tiles, uint32_t grid_w, uint32_t grid_h,
                              hipStream_t s);
+#ifdef FGS_DEV_SWITCHES
 size_t bucket_scan_temp_bytes(uint32_t n_tiles);      // the library scan, kept for A/B (fgs_debug_set_option(11, 1))
+#endif
 hipError_t run_bucket_scan(void* temp, size_t temp_bytes, const uint2* ranges, uint32_t* bucket_offsets, uint32_t n_tiles, hipStream_t s);
 
 struct BlendArgs {                      // K10 / inference blend

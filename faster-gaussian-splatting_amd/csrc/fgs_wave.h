@@ -113,6 +113,9 @@ __device__ __forceinline__ void store_float4_nt(float* p, const float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<fgs_f32x4*>(p));
 }
 
+// a load of data another XCD's workgroup wrote before a device-scope fence + atomic (the L2s of the eight XCDs are not coherent with each other)
+__device__ __forceinline__ uint32_t load_device_scope(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 // A value the compiler must keep in a vector register (and cannot fold back into scalar address arithmetic): moves the per-pair LDS address
 // of the blend walk from two scalar instructions + a copy to one vector shift-add, in a loop bound by the scalar unit.

@@ -83,6 +83,7 @@ inline float wave_shift_up1_zero(float v) {
     return lane == 0 ? 0.0f : up;
 }
 inline void wave_lds_fence() { sim::sync_scope(true); }
+inline uint32_t load_device_scope(const uint32_t* p) { return *p; }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline unsigned in_vector_register(unsigned x) { return x; }

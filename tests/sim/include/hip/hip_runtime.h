@@ -189,6 +189,7 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStrea
 }
 
 inline void __syncthreads() { sim::sync_scope(false); }
+inline void __threadfence() {}
 inline int __syncthreads_and(int p) {
     const int par = sim::next_parity(false);
     sim::me().block_slot[par] = p ? 1 : 0;
