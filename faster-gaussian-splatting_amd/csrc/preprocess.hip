@@ -262,8 +262,10 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         unsigned off = s_base + lanes_below(vis_mask);
         for (unsigned w = 0; w < wave; ++w) off += s_vis[w];
         a.depth_keys[off] = __float_as_uint(depth);
-        a.prim_idx[off] = idx;
+        // the visible list's primitive index travels in the footprint row (the depth sort makes up its own values and takes the primitive from the
+        // row in its last pass); the bare index list is written for the sharded owner only, whose record packing reads it
         if (a.foot != nullptr) a.foot[off] = foot_box == kFootprintEscape ? make_uint4(idx, kFootprintEscape, cnt, 0u) : make_uint4(idx, foot_box, foot_lo, foot_hi);
+        else a.prim_idx[off] = idx;
     }
     FGS_K1_MARK(5);                                             // tile-count store, workgroup barrier + compaction atomic, key / index store
     FGS_K1_FLUSH;
@@ -315,8 +317,8 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
                 const unsigned off = static_cast<unsigned>(atomicAdd(reinterpret_cast<unsigned long long*>(a.counters), packed));
                 const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
                 a.depth_keys[off] = __float_as_uint(depth);
-                a.prim_idx[off] = idx;
                 if (a.foot != nullptr) a.foot[off] = make_uint4(idx, kFootprintEscape, cnt, 0u);
+                else a.prim_idx[off] = idx;
                 if (a.count_appended) atomicAdd(&a.counters[2], 1u);     // sharded path: how many entries this kernel appended
             }
         }
