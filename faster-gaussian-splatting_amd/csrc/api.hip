@@ -107,6 +107,7 @@ struct PrimitiveBuffers {             // cf. bu:45-94
     PrimRec* rec; uint32_t* n_touched; uint32_t* keys[2]; uint32_t* prims[2]; uint32_t* offsets; uint32_t* counters; uint32_t* hot_list;
     uint4* foot[2]; uint32_t* tile_counts;      // footprint rows in compaction / depth order, tile counts in depth order (fgs_math.h, radix_sort.hip)
     uint32_t* wave_sums; uint32_t* block_sums;  // their sums per 64-Gaussian wave segment / per 4096-Gaussian block (binning.hip)
+    uint32_t* big_list;                         // depth-order positions of the footprints of more than kBigInstanceFootprint candidate tiles (counters[2] of them)
     char* temp; size_t temp_bytes;
     static PrimitiveBuffers carve(Carver& c, uint32_t n) {
         PrimitiveBuffers b;
@@ -121,6 +122,7 @@ struct PrimitiveBuffers {             // cf. bu:45-94
         b.tile_counts = c.take<uint32_t>("tile_counts", n);
         b.wave_sums = c.take<uint32_t>("wave_sums", (static_cast<size_t>(n) + 63) / 64 + 64);
         b.block_sums = c.take<uint32_t>("block_sums", (static_cast<size_t>(n) + 4095) / 4096 + 1);
+        b.big_list = c.take<uint32_t>("big_list", n);
         b.temp_bytes = depth_sort_temp_bytes(n);
         b.temp = c.take<char>("sort_temp", b.temp_bytes);
         return b;
@@ -304,7 +306,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
         int depth_sel = 0;
         if (n > 0) {
             StageScope t(ST_DEPTH_SORT, stream);
-            FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream));
+            FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, pb.big_list, pb.counters + 2, stream));
         }
         return forward_tail(mode, pb, tb, geo, n, static_cast<uint32_t>(instance_capacity), depth_sel, settings, image, to_chw, clamp_output, resize, user,
                             state_out, stream, scores, true);
@@ -321,7 +323,7 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
     int depth_sel = -1;
     if (n > 0) {
         StageScope t(ST_DEPTH_SORT, stream);
-        FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream));
+        FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n, pb.counters, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, pb.big_list, pb.counters + 2, stream));
     }
     FGS_HIP(hipEventSynchronize(ready));
     const uint32_t n_visible = host[0], n_instances = host[1];
@@ -341,8 +343,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     const uint32_t* const visible_ptr = device_counts ? pb.counters : nullptr;
     const uint32_t* const instances_ptr = device_counts ? pb.counters + 5 : nullptr;
     // K2-K4 (fwd:104-127)
-    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, visible_ptr, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, stream)); }
-    const uint32_t* sorted_prims = pb.prims[depth_sel];
+    if (depth_sel < 0) { StageScope t(ST_DEPTH_SORT, stream); FGS_HIP(run_depth_sort(pb.temp, pb.temp_bytes, pb.keys, pb.prims, depth_sel, n_visible, visible_ptr, depth_key_range(settings->near_plane, settings->far_plane), pb.foot, pb.tile_counts, pb.big_list, pb.counters + 2, stream)); }
     { StageScope t(ST_OFFSETS_SCAN, stream); FGS_HIP(launch_tile_count_sums(pb.tile_counts, pb.wave_sums, pb.block_sums, n_visible, visible_ptr, stream)); }
 
     // K5-K7 (fwd:179-216)
@@ -352,9 +353,9 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     if (!inst_blob && inst_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(instance, %zu) returned NULL", inst_size.total());
     Carver inst_c(inst_blob);
     InstanceBuffers ib = InstanceBuffers::carve(inst_c, n_instances, geo.key_bytes, geo.end_bit);
-    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, pb.foot[1], sorted_prims, pb.wave_sums, pb.block_sums, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
+    { StageScope t(ST_CREATE_INSTANCES, stream); FGS_HIP(launch_create_instances(geo.key_bytes, pb.foot[1], pb.wave_sums, pb.block_sums, pb.offsets, pb.rec, ib.keys[0], ib.prims[0], geo.grid_w, n_visible,
                                                                                  visible_ptr, device_counts ? n_instances : 0xffffffffu, pb.counters,
-                                                                                 pb.keys[depth_sel ^ 1], pb.counters + 2, stream)); }
+                                                                                 pb.big_list, pb.counters + 2, stream)); }
     int tile_sel = 0;
     { StageScope t(ST_TILE_SORT, stream); FGS_HIP(run_tile_sort(ib.temp, ib.temp_bytes, geo.key_bytes, ib.keys, ib.prims, tile_sel, n_instances, instances_ptr, geo.end_bit, stream)); }
     // the key double buffer flips together with the value double buffer

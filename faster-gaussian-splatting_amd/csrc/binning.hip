@@ -23,10 +23,11 @@ namespace fgs {
 size_t depth_sort_temp_bytes(uint32_t n) { return own_sort_temp_bytes(n, 32); }
 
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
-                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s) {
+                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts,
+                          uint32_t* big_list, uint32_t* big_count, hipStream_t s) {
     selector = 0;
     if (n_visible == 0) return hipSuccess;
-    const SortPayload payload{foot[0], foot[1], tile_counts, 0};
+    const SortPayload payload{foot[0], foot[1], tile_counts, 0, big_list, big_count};
     return own_depth_sort(temp, temp_bytes, keys, vals, selector, n_visible, n_visible_ptr, range, s, &payload);
 }
 
@@ -73,6 +74,72 @@ hipError_t launch_tile_count_sums(const uint32_t* tile_counts, uint32_t* wave_su
     return hipGetLastError();
 }
 
+// ---- K5, big footprints ------------------------------------------------------------------------------------------
+// Big footprints (more than kBigInstanceFootprint candidate tiles: 0.07 % of the visible Gaussians at S2, 3 % of the instances) get a workgroup
+// each: kInstanceBlock candidate tiles per step, exact test (kf:283-326), write slots from a ballot prefix inside each wave and an LDS prefix
+// across the waves -- consecutive slots, stable row-major order. Depth order puts the nearest (largest) Gaussians next to each other, so
+// finishing them in the main walk would serialise tens of thousands of candidate tiles in a handful of waves (+0.2 ms on views with
+// screen-filling Gaussians). Until round 4 they had a launch of their own behind the main kernel (10-20 us of a 0.70 ms frame, set by the step
+// chain of the largest item); now the depth sort's last pass lists them and the first kBigBlocks workgroups of the SAME launch work the list off,
+// each item finding its own output offset from the wave-segment / block sums.
+constexpr unsigned kBigBlocks = 256;
+template <typename KeyT>
+__device__ __forceinline__ void expand_big_footprints(const uint4* __restrict__ foot, const uint32_t* __restrict__ wave_sums,
+                                                      const uint32_t* __restrict__ block_sums, const PrimRec* __restrict__ rec,
+                                                      KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w,
+                                                      const uint32_t capacity, const uint32_t* __restrict__ big_list, const unsigned n_big) {
+    constexpr int kWaves = kInstanceBlock / kWave;
+    __shared__ unsigned s_hits[2][kWaves];
+    __shared__ unsigned s_off[kWaves];
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    for (unsigned b = blockIdx.x; b < n_big; b += kBigBlocks) {             // workgroup-uniform loop
+        const uint32_t i = big_list[b];
+        // first output slot of entry i (as in the main walk): blocks in front of its block, wave segments in front of its segment inside the
+        // block, entries in front of it inside its segment
+        const unsigned segment = i >> 6, block_of = segment >> 6, in_block = segment & 63u, in_segment = i & 63u;
+        uint32_t part = 0;
+        for (unsigned j = threadIdx.x; j < block_of; j += kInstanceBlock) part += block_sums[j];
+        if (threadIdx.x < in_block) part += wave_sums[(segment & ~63u) + threadIdx.x];
+        if (threadIdx.x >= 64u && threadIdx.x - 64u < in_segment) part += footprint_tile_count(foot[(segment << 6) + threadIdx.x - 64u]);
+        const uint32_t wsum = wave_sum(part);
+        if (lane == 0) s_off[wv] = wsum;
+        const uint4 row = foot[i];
+        const uint32_t prim = row.x;
+        const float4* r = reinterpret_cast<const float4*>(rec + prim);
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+        const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
+        unsigned tx0, tx1, ty0, ty1;
+        tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
+        const unsigned tbw = tx1 - tx0;
+        const unsigned count = tbw * (ty1 - ty0);
+        __syncthreads();
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) w += s_off[k];
+        unsigned parity = 0;
+        for (unsigned base = 0; base < count; base += kInstanceBlock, parity ^= 1u) {
+            const unsigned t = base + threadIdx.x;
+            const unsigned tx = tx0 + t % tbw, ty = ty0 + t / tbw;
+            const bool hit = t < count && tile_contributes(tt, tx, ty);
+            const uint64_t hits = wave_ballot(hit);
+            if (lane == 0) s_hits[parity][wv] = static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
+            __syncthreads();                                                       // double-buffered counts: one barrier per step
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kWaves; ++k) { const unsigned c = s_hits[parity][k]; total += c; if (k < static_cast<int>(wv)) before += c; }
+            if (hit) {
+                const unsigned slot = w + before + lanes_below(hits);
+                if (slot < capacity) {
+                    inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
+                    inst_prims[slot] = prim;
+                }
+            }
+            w += total;
+        }
+        __syncthreads();                                                           // s_hits / s_off are reused by the next footprint
+    }
+}
+
 // ---- K5 ----------------------------------------------------------------------------------------------------
 // Emits (tile key, primitive) for every exactly-overlapped tile of every depth-sorted visible primitive, in row-major
 // order over its tile bounding box (kf:225-328). CDNA4 shape: a wave owns 64 consecutive primitives, whose outputs form
@@ -90,12 +157,19 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     const uint4* __restrict__ foot, const uint32_t* __restrict__ wave_sums, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets,
     const PrimRec* __restrict__ rec, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w,
     const uint32_t n_visible_value, const uint32_t* __restrict__ n_visible_ptr, const uint32_t capacity, uint32_t* __restrict__ counters,
-    uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
+    const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count) {
+    // The first kBigBlocks workgroups of the grid expand the big footprints (listed by the depth sort's last pass) while the others walk the
+    // visible list: the long poles start first and run beside the main walk instead of in a launch of their own behind it.
+    if (blockIdx.x < kBigBlocks) {
+        expand_big_footprints<KeyT>(foot, wave_sums, block_sums, rec, inst_keys, inst_prims, grid_w, capacity, big_list, *big_count);
+        return;
+    }
+    const unsigned main_block = blockIdx.x - kBigBlocks;
     // The visible count by value, or (host-synchronisation-free forward) through n_visible_ptr with the grid sized by a bound. `capacity` =
     // size of the instance arrays: exact in the first case; in the second a caller-side estimate -- stores beyond it are dropped, and
     // the clamped instance count / an overflow flag are left in counters[5] / counters[6] for the sort and for the caller to check.
     const uint32_t n_visible = n_visible_ptr != nullptr ? *n_visible_ptr : n_visible_value;
-    if (n_visible_ptr != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (n_visible_ptr != nullptr && main_block == 0 && threadIdx.x == 0) {
         const uint32_t n_instances = counters[1];
         counters[5] = n_instances < capacity ? n_instances : capacity;
         counters[6] = n_instances > capacity ? 1u : 0u;
@@ -106,7 +180,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     __shared__ uint4 s_geo[kWaves][kWave];            // primitive, box origin tx0 | ty0 << 16, box width, ceil(2^16 / width)
     __shared__ uint32_t s_head[kWaves][2 * kWave];    // the wave's 64 x 64 candidate slots: bit = a footprint starts here
 
-    const unsigned gid = blockIdx.x * kInstanceBlock + threadIdx.x;
+    const unsigned gid = main_block * kInstanceBlock + threadIdx.x;
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const bool active = gid < n_visible;
     if (wave_ballot(active) == 0) return;              // wave-uniform; waves are independent (no workgroup barrier)
@@ -159,9 +233,9 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         }
     }
 
-    // ---- escape rows (boxes of 65 .. kBigInstanceFootprint candidate tiles): re-tested by this wave from the record, 64 candidates per step,
-    // with ballot-prefix write slots (kf:283-326) ----
-    const bool recompute = active && !small;
+    // ---- escape rows (boxes of 65 .. kBigInstanceFootprint candidate tiles; larger ones belong to the leading workgroups): re-tested by this wave
+    // from the record, 64 candidates per step, with ballot-prefix write slots (kf:283-326) ----
+    const bool recompute = active && !small && row.w <= kBigInstanceFootprint;
     unsigned tx0 = 0, ty0 = 0, tbw = 1, count = 0;
     float4 r0{}, r1{};
     if (recompute) {                                   // the only lanes that touch the record
@@ -173,7 +247,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         tbw = tx1 - tx0;
         count = tbw * (ty1 - ty0);
     }
-    uint64_t pending = wave_ballot(recompute && count <= kBigInstanceFootprint);
+    uint64_t pending = wave_ballot(recompute);
     if (pending != 0) {
         const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
         while (pending != 0) {
@@ -205,85 +279,21 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
         }
     }
 
-    // ---- huge footprints go to a work list: depth order puts the nearest (largest) Gaussians next to each other, so
-    // finishing them here would serialise tens of thousands of candidate tiles in a handful of waves (measured: +0.2 ms on
-    // views with screen-filling Gaussians). A second kernel gives each of them a whole workgroup. ----
-    const bool is_big = recompute && count > kBigInstanceFootprint;
-    const uint64_t big_mask = wave_ballot(is_big);
-    if (big_mask != 0) {
-        const int leader = __ffsll(static_cast<unsigned long long>(big_mask)) - 1;
-        unsigned base = 0;
-        if (lane == static_cast<unsigned>(leader)) base = atomicAdd(big_count, static_cast<unsigned>(__popcll(static_cast<unsigned long long>(big_mask))));
-        base = wave_read(base, leader);
-        if (is_big) big_list[base + lanes_below(big_mask)] = i;
-    }
 }
 
-// One workgroup per large footprint: 256 candidate tiles per step, exact test (kf:283-326), write slots from a
-// ballot prefix inside each wave and an LDS prefix across the 4 waves -- consecutive slots, stable row-major order.
-template <typename KeyT>
-__global__ void __launch_bounds__(kInstanceBlock) create_instances_big_kernel(
-    const uint32_t* __restrict__ sorted_prims, const uint32_t* __restrict__ offsets, const PrimRec* __restrict__ rec,
-    const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count,
-    KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_prims, const uint32_t grid_w, const uint32_t capacity) {
-    constexpr int kWaves = kInstanceBlock / kWave;
-    __shared__ unsigned s_hits[2][kWaves];
-    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
-    const unsigned n_big = *big_count;
-    for (unsigned b = blockIdx.x; b < n_big; b += gridDim.x) {            // workgroup-uniform loop
-        const uint32_t i = big_list[b];
-        const uint32_t prim = sorted_prims[i];
-        const float4* r = reinterpret_cast<const float4*>(rec + prim);
-        const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-        const TileTest tt = make_tile_test(r0.x - 0.5f, r0.y - 0.5f, r0.z, r0.w, r1.x, logf(r1.y * kMinAlphaThresholdRcp));   // kf:267
-        unsigned tx0, tx1, ty0, ty1;
-        tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
-        const unsigned tbw = tx1 - tx0;
-        const unsigned count = tbw * (ty1 - ty0);
-        unsigned w = offsets[i];
-        unsigned parity = 0;
-        for (unsigned base = 0; base < count; base += kInstanceBlock, parity ^= 1u) {
-            const unsigned t = base + threadIdx.x;
-            const unsigned tx = tx0 + t % tbw, ty = ty0 + t / tbw;
-            const bool hit = t < count && tile_contributes(tt, tx, ty);
-            const uint64_t hits = wave_ballot(hit);
-            if (lane == 0) s_hits[parity][wv] = static_cast<unsigned>(__popcll(static_cast<unsigned long long>(hits)));
-            __syncthreads();                                                       // double-buffered counts: one barrier per step
-            unsigned before = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < kWaves; ++k) { const unsigned c = s_hits[parity][k]; total += c; if (k < static_cast<int>(wv)) before += c; }
-            if (hit) {
-                const unsigned slot = w + before + lanes_below(hits);
-                if (slot < capacity) {
-                    inst_keys[slot] = static_cast<KeyT>(ty * grid_w + tx);
-                    inst_prims[slot] = prim;
-                }
-            }
-            w += total;
-        }
-        __syncthreads();                                                           // s_hits is reused by the next footprint
-    }
-}
-
-hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* wave_sums,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* wave_sums,
                                    const uint32_t* block_sums, uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
-                                   uint32_t* big_list, uint32_t* big_count, hipStream_t s) {
+                                   const uint32_t* big_list, const uint32_t* big_count, hipStream_t s) {
     if (n_visible == 0) return hipSuccess;
-    const dim3 grid((n_visible + kInstanceBlock - 1) / kInstanceBlock), block(kInstanceBlock);
-    const dim3 big_grid(n_visible < 1024u ? n_visible : 1024u);       // grid-stride over the (short) device-side work list
-    if (key_bytes == 2) {
+    const dim3 grid(kBigBlocks + (n_visible + kInstanceBlock - 1) / kInstanceBlock), block(kInstanceBlock);
+    if (key_bytes == 2)
         hipLaunchKernelGGL(create_instances_kernel<uint16_t>, grid, block, 0, s, foot_sorted, wave_sums, block_sums, offsets, rec,
                            static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
-        hipLaunchKernelGGL(create_instances_big_kernel<uint16_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
-                           static_cast<uint16_t*>(inst_keys), inst_prims, grid_w, capacity);
-    } else {
+    else
         hipLaunchKernelGGL(create_instances_kernel<uint32_t>, grid, block, 0, s, foot_sorted, wave_sums, block_sums, offsets, rec,
                            static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, n_visible, n_visible_ptr, capacity, counters, big_list, big_count);
-        hipLaunchKernelGGL(create_instances_big_kernel<uint32_t>, big_grid, block, 0, s, sorted_prims, offsets, rec, big_list, big_count,
-                           static_cast<uint32_t*>(inst_keys), inst_prims, grid_w, capacity);
-    }
     return hipGetLastError();
 }
 

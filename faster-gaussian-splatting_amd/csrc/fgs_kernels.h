@@ -41,7 +41,8 @@ size_t depth_sort_temp_bytes(uint32_t n);
 // can be enqueued before the host knows the count). foot[0] = the footprint rows in compaction order (K1), foot[1] receives them in depth order,
 // tile_counts their tile counts in depth order; vals[selector] = the primitives in depth order.
 hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n_visible,
-                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts, hipStream_t s);
+                          const uint32_t* n_visible_ptr, DepthKeyRange range, uint4* foot[2], uint32_t* tile_counts,
+                          uint32_t* big_list, uint32_t* big_count, hipStream_t s);
 // K3 + K4: sums of the depth-ordered tile counts per 64-Gaussian wave segment (wave_sums[ceil(n / 64)]) and per 4096-Gaussian block
 // (block_sums[ceil(n / 4096)]). K5 derives every Gaussian's first output slot from them.
 // n_visible_ptr != nullptr: n_visible is a bound (the primitive count) and the exact count is read on the device
@@ -52,11 +53,11 @@ hipError_t launch_tile_count_sums(const uint32_t* tile_counts, uint32_t* wave_su
 size_t tile_sort_temp_bytes(uint32_t n_instances, int key_bytes, int end_bit);
 // The *_ptr forms serve the host-synchronisation-free forward pass: counts are bounds / capacities, the exact ones are read on the device
 // (n_visible from counters[0]; the instance count clamped to `capacity` is written to counters[5], an overflow flag to counters[6]).
-hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* sorted_prims, const uint32_t* wave_sums,
+hipError_t launch_create_instances(int key_bytes, const uint4* foot_sorted, const uint32_t* wave_sums,
                                    const uint32_t* block_sums, uint32_t* offsets,
                                    const PrimRec* rec, void* inst_keys, uint32_t* inst_prims, uint32_t grid_w, uint32_t n_visible,
                                    const uint32_t* n_visible_ptr, uint32_t capacity, uint32_t* counters,
-                                   uint32_t* big_list, uint32_t* big_count, hipStream_t s);
+                                   const uint32_t* big_list, const uint32_t* big_count, hipStream_t s);
 hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* keys[2], uint32_t* vals[2], int& selector,
                          uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s);
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s);
@@ -73,7 +74,8 @@ extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 k
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
 // Side table carried out of the depth sort's LAST scatter pass (radix_sort.hip): the sort's values start as the input positions (the first pass
 // makes them up), the last pass gathers rows_in[value] and writes the row, its first word as the sorted value, and the row's tile count in sorted order.
-struct SortPayload { const uint4* rows_in; uint4* rows_out; uint32_t* count_out; int iota_values; };
+struct SortPayload { const uint4* rows_in; uint4* rows_out; uint32_t* count_out; int iota_values;
+                     uint32_t* big_list; uint32_t* big_count; };      // depth-order positions of the rows whose boxes exceed kBigInstanceFootprint candidates
 hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
                           DepthKeyRange range, hipStream_t s, const SortPayload* payload = nullptr);
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s);

@@ -256,7 +256,8 @@ __device__ __forceinline__ void tile_rect(uint32_t bx, uint32_t by, unsigned& tx
 // scatter pass (radix_sort.hip), so that the offsets scan and the instance kernel stream what they need instead of gathering a record line per
 // Gaussian:  x = primitive index,  y = tile box (tx0 | ty0 << 10 | (width - 1) << 20 | (height - 1) << 26),  z, w = exact-overlap bitmap of the
 // box's <= 64 candidate tiles, row-major. Boxes of more than 64 candidates, or beyond 1024 tiles in x or y, are ESCAPE rows: y = kFootprintEscape,
-// z = the tile count -- the instance kernel re-tests those from the record.
+// z = the tile count, w = the number of candidate tiles of the box -- the instance kernel re-tests those from the record (boxes above
+// kBigInstanceFootprint candidates by a workgroup each: the depth sort's last pass lists them).
 constexpr uint32_t kFootprintEscape = 0xffffffffu;          // width - 1 = height - 1 = 63 is no box of <= 64 candidates
 constexpr unsigned kFootprintBitmapTiles = 64;
 __device__ __forceinline__ bool footprint_box_fits(unsigned tx0, unsigned ty0, unsigned tbw, unsigned n_max) {

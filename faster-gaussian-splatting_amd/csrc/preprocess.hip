@@ -57,7 +57,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 
     bool visible = false;
     unsigned cnt = 0;
-    uint32_t foot_box = kFootprintEscape, foot_lo = 0, foot_hi = 0;        // the Gaussian's footprint row (fgs_math.h)
+    uint32_t foot_box = kFootprintEscape, foot_lo = 0, foot_hi = 0, foot_n_max = 0;        // the Gaussian's footprint row (fgs_math.h)
     if (wave_ballot(active) != 0) {                                                    // wave-uniform: skip culled waves (kf:70)
         float opacity = sigmoid_f(a.opacities[idx]);
         if (opacity < kMinAlphaThreshold) active = false;                              // kf:75
@@ -196,6 +196,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 
             FGS_K1_MARK(3);                                                            // footprints of > 64 candidates
             visible = active && cnt > 0;                                               // kf:190
+            foot_n_max = n_max;
             if (footprint_box_fits(tx0, ty0, tbw, n_max)) {                            // every candidate of the box was tested above: the bitmap is exact
                 foot_box = footprint_box(tx0, ty0, tbw, ty1 - ty0);
                 foot_lo = static_cast<uint32_t>(hit_mask); foot_hi = static_cast<uint32_t>(hit_mask >> 32);
@@ -264,7 +265,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
         a.depth_keys[off] = __float_as_uint(depth);
         // the visible list's primitive index travels in the footprint row (the depth sort makes up its own values and takes the primitive from the
         // row in its last pass); the bare index list is written for the sharded owner only, whose record packing reads it
-        if (a.foot != nullptr) a.foot[off] = foot_box == kFootprintEscape ? make_uint4(idx, kFootprintEscape, cnt, 0u) : make_uint4(idx, foot_box, foot_lo, foot_hi);
+        if (a.foot != nullptr) a.foot[off] = foot_box == kFootprintEscape ? make_uint4(idx, kFootprintEscape, cnt, foot_n_max) : make_uint4(idx, foot_box, foot_lo, foot_hi);
         else a.prim_idx[off] = idx;
     }
     FGS_K1_MARK(5);                                             // tile-count store, workgroup barrier + compaction atomic, key / index store
@@ -288,10 +289,12 @@ template <bool INFERENCE>
 __global__ void FGS_K1_BOUNDS preprocess_kernel(const PreprocessArgs a) { preprocess_body<INFERENCE>(a); }
 __global__ void __launch_bounds__(kPreprocessBlock) preprocess_batch_kernel(const PreprocessBatch b) { preprocess_body<false>(b.v[blockIdx.y]); }
 
-// Exact tile count + compaction for the few screen-filling footprints: one 256-thread workgroup per Gaussian, 256 candidate
-// tiles per step (kernel_utils.cuh:117-180 with the whole workgroup cooperating instead of one warp).
+// Exact tile count + compaction for the few screen-filling footprints: one kHugeBlock-thread workgroup per Gaussian, kHugeBlock candidate
+// tiles per step (kernel_utils.cuh:117-180 with the whole workgroup cooperating instead of one warp). 1024 threads (round 5; 256 before): the
+// kernel's span is the step chain of its largest footprint (10 800 candidates at 1080p: 11 steps instead of 43).
+constexpr unsigned kHugeBlock = 1024;
 __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
-    __shared__ unsigned s_cnt[4];
+    __shared__ unsigned s_cnt[kHugeBlock / kWave];
     const Camera cam = load_camera(a.cam);
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const unsigned n_huge = a.counters[3];
@@ -304,20 +307,21 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
         tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
         const unsigned tbw = tx1 - tx0, count = tbw * (ty1 - ty0);
         unsigned mine = 0;
-        for (unsigned t = threadIdx.x; t < count; t += 256u)
+        for (unsigned t = threadIdx.x; t < count; t += kHugeBlock)
             mine += tile_contributes(tt, tx0 + t % tbw, ty0 + t / tbw) ? 1u : 0u;
         const unsigned wsum = wave_sum(mine);
         if (lane == 0) s_cnt[wv] = wsum;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            unsigned cnt = 0;
+            for (unsigned k = 0; k < kHugeBlock / kWave; ++k) cnt += s_cnt[k];
             a.n_touched[idx] = cnt;
             if (cnt != 0) {
                 const unsigned long long packed = (static_cast<unsigned long long>(cnt) << 32) | 1ull;
                 const unsigned off = static_cast<unsigned>(atomicAdd(reinterpret_cast<unsigned long long*>(a.counters), packed));
                 const float depth = view_depth(cam, a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]);
                 a.depth_keys[off] = __float_as_uint(depth);
-                if (a.foot != nullptr) a.foot[off] = make_uint4(idx, kFootprintEscape, cnt, 0u);
+                if (a.foot != nullptr) a.foot[off] = make_uint4(idx, kFootprintEscape, cnt, count);
                 else a.prim_idx[off] = idx;
                 if (a.count_appended) atomicAdd(&a.counters[2], 1u);     // sharded path: how many entries this kernel appended
             }
@@ -325,15 +329,15 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) preprocess_huge_kernel(const PreprocessArgs a) { preprocess_huge_body(a); }
-__global__ void __launch_bounds__(256) preprocess_huge_batch_kernel(const PreprocessBatch b) { preprocess_huge_body(b.v[blockIdx.y]); }
+__global__ void __launch_bounds__(kHugeBlock) preprocess_huge_kernel(const PreprocessArgs a) { preprocess_huge_body(a); }
+__global__ void __launch_bounds__(kHugeBlock) preprocess_huge_batch_kernel(const PreprocessBatch b) { preprocess_huge_body(b.v[blockIdx.y]); }
 
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);
     if (inference) hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, 0, s, a);
-    hipLaunchKernelGGL(preprocess_huge_kernel, dim3(a.n < 1024u ? a.n : 1024u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(preprocess_huge_kernel, dim3(a.n < 512u ? a.n : 512u), dim3(kHugeBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -342,7 +346,7 @@ hipError_t launch_preprocess_batch(const PreprocessBatch& b, hipStream_t s) {
     if (n == 0 || b.n_views <= 0) return hipSuccess;
     const dim3 grid((n + kPreprocessBlock - 1) / kPreprocessBlock, static_cast<unsigned>(b.n_views)), block(kPreprocessBlock);
     hipLaunchKernelGGL(preprocess_batch_kernel, grid, block, 0, s, b);
-    hipLaunchKernelGGL(preprocess_huge_batch_kernel, dim3(n < 256u ? n : 256u, static_cast<unsigned>(b.n_views)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(preprocess_huge_batch_kernel, dim3(n < 256u ? n : 256u, static_cast<unsigned>(b.n_views)), dim3(kHugeBlock), 0, s, b);
     return hipGetLastError();
 }
 

@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
     __shared__ uint32_t s_part[kSortWaves];
     __shared__ KeyT s_key[kBlockItems];
     __shared__ uint32_t s_val[kBlockItems];
+    constexpr uint32_t kBigPerBlock = 256;              // payload pass only: big footprints found by this workgroup (see the end of the kernel)
+    __shared__ uint32_t s_big[kBigPerBlock];
+    __shared__ uint32_t s_n_big, s_big_base;
+    if (threadIdx.x == 0) s_n_big = 0u;                 // several workgroup barriers lie between this and the first append
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t d0 = threadIdx.x * DPT;                          // this thread's first digit
     // global base of every digit: exclusive scan of the digit totals (requested now, used after the ranking)
@@ -259,8 +263,21 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
             vals_out[dst[j]] = row[j].x;
             pl.rows_out[dst[j]] = row[j];
             pl.count_out[dst[j]] = footprint_tile_count(row[j]);
+            // boxes the instance kernel gives a workgroup each: listed by their depth-order position (a few hundred to a few thousand per view),
+            // collected per workgroup so that the list's counter sees one atomic per workgroup (a same-address atomic retires at ~88 / us)
+            if (row[j].y == kFootprintEscape && row[j].w > kBigInstanceFootprint) {
+                const uint32_t k = atomicAdd(&s_n_big, 1u);
+                if (k < kBigPerBlock) s_big[k] = dst[j];
+                else pl.big_list[atomicAdd(pl.big_count, 1u)] = dst[j];
+            }
         }
     }
+    __syncthreads();
+    const uint32_t n_big = s_n_big < kBigPerBlock ? s_n_big : kBigPerBlock;
+    if (n_big == 0u) return;                            // workgroup-uniform
+    if (threadIdx.x == 0) s_big_base = atomicAdd(pl.big_count, n_big);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_big; k += kSortThreads) pl.big_list[s_big_base + k] = s_big[k];
 }
 
 struct SortPlan { int n_passes; int bits[8]; uint32_t n_blocks; size_t table_bytes, totals_bytes; };
@@ -307,7 +324,8 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
         SortPayload pl{};                                   // with a payload: the values are the input positions (first pass) and become the rows' primitives (last pass)
         if (payload != nullptr) {
             pl.iota_values = i == 0 ? 1 : 0;
-            if (i == p.n_passes - 1) { pl.rows_in = payload->rows_in; pl.rows_out = payload->rows_out; pl.count_out = payload->count_out; }
+            if (i == p.n_passes - 1) { pl.rows_in = payload->rows_in; pl.rows_out = payload->rows_out; pl.count_out = payload->count_out;
+                                       pl.big_list = payload->big_list; pl.big_count = payload->big_count; }
         }
         launch_scatter<KeyT, IPT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, key_base, shift,
                                   table, totals, p.n_blocks, pl);

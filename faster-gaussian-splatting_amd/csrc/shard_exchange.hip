@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) unpack_splat_records_kernel(const uint32_
     depth_keys[dst] = w6.x; prim_idx[dst] = dst; n_touched[dst] = w6.y;   // the visible list in slot order: equal depth keys keep that order through the stable sort
     // footprint row (fgs_math.h): a record carries the 32-bit overlap bitmap of boxes of <= 32 candidates; larger boxes are re-tested by the instance kernel
     const bool bitmap = n_max <= 32u && footprint_box_fits(tx0, ty0, tx1 - tx0, n_max);
-    foot[dst] = bitmap ? make_uint4(dst, footprint_box(tx0, ty0, tx1 - tx0, ty1 - ty0), w5.y, 0u) : make_uint4(dst, kFootprintEscape, w6.y, 0u);
+    foot[dst] = bitmap ? make_uint4(dst, footprint_box(tx0, ty0, tx1 - tx0, ty1 - ty0), w5.y, 0u) : make_uint4(dst, kFootprintEscape, w6.y, n_max);
 }
 
 // K11's accumulator records [n][9] (by primitive slot) -> the same 36-byte records in the order of the concatenation (record j), ready to be cut
