@@ -543,7 +543,7 @@ def main():
     # READING the gradient rows of dead 64-Gaussian blocks, so it moves ~4 % less than 1652 N and must not be credited with bytes it never touched)
     achieved_counter = traffic / dom_s / 1e9 if (traffic is not None and dom_s > 0) else None
     achieved = min(achieved_algorithmic, achieved_counter) if achieved_counter is not None else achieved_algorithmic
-    # Secondary ceiling: VALU issue. Measured on this chip (tools/valu_rate.hip, profiles/r02_valu_rate.txt): a wave64
+    # Secondary ceiling: VALU issue. Measured on this chip (tools/valu_rate.hip, profiles/archive/r02_valu_rate.txt): a wave64
     # v_fma/v_mul/v_add issues every 2.9 cycles of a 2.4 GHz clock per SIMD with 8 waves resident (MI355X_MICROARCH.md quotes 2), compares /
     # selects / conversions / DPP moves 4.3, v_exp / v_rcp 8.3. frac = the kernel's VALU instructions (SQ_INSTS_VALU, all shader engines)
     # over what 1024 SIMDs could issue in its run time at the plain-FMA rate -- a lower bound of how VALU-bound the kernel is.

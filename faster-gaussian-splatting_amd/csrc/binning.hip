@@ -364,7 +364,7 @@ hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* 
 // Gaussian's record is re-read by every tile it overlaps -- so an XCD should own compact pieces of the image. Round 1/2 gave every
 // XCD one contiguous band of tile rows: good locality, but the bands differ in work (at S2 the top band has 30 ms of summed tile time
 // against 44-47 ms for the others; on a layered scene 47 against 210-220: XCD 0 idles for two thirds of the kernel) and the heaviest
-// rows came last in every band (profiles/r02_k10_timeline_before.txt). Interleaving single rows balances but gives up vertical
+// rows came last in every band (profiles/archive/r02_k10_timeline_before.txt). Interleaving single rows balances but gives up vertical
 // locality (+10 % layered, -9..16 % S2). The plan keeps both: the image is cut into 8 x 10 rectangular blocks of tiles (15 x 9 tiles
 // at 1080p: every XCD gets exactly 10 blocks, i.e. the same number of workgroups, which the round-robin deal requires); a block's
 // weight is its number of 64-Gaussian buckets (+ 1 per tile) -- known here, on the device, from the scan itself: no host read; the

@@ -389,8 +389,8 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
     // adds of the tile origin per (pixel, Gaussian) step -- 14 % of the loop's instructions. The centre is x0 + small integer either way
     // (exact), so dx, dy and every result are bit-identical. TWO dense arrays, not one 32-byte slot: lane l reads slot (step - l), and with a
     // 32-byte lane stride the 16-byte read conflicts every 8 lanes and the 8-byte read four-fold -- SQ_LDS_BANK_CONFLICT 2.3 M -> 42.6 M
-    // cycles per launch at S2, LDS busy 34 M -> 86 M, which ate the whole gain (profiles/r02_pmc_k11_lds.txt). 6.7 KB of LDS per wave
-    // instead of 5.1: no effect on this kernel up to 8.2 KB (profiles/r02_k11_occupancy.txt).
+    // cycles per launch at S2, LDS busy 34 M -> 86 M, which ate the whole gain (profiles/archive/r02_pmc_k11_lds.txt). 6.7 KB of LDS per wave
+    // instead of 5.1: no effect on this kernel up to 8.2 KB (profiles/archive/r02_k11_occupancy.txt).
     // Round 3: the two arrays are RINGS of kRing = 256 slots (live pixels in [0, n_px), sentinels with rel 0 behind them): lane l reads slot
     // (step - l) mod 256, which is a sentinel both before the lane's first pixel arrives (negative -> 193..255) and after its last one has
     // passed (n_px .. n_px + 62 <= 254). The per-step index arithmetic was five vector instructions (step - lane, + look-ahead, unsigned min

@@ -20,17 +20,17 @@ namespace fgs {
 
 // Which tile does workgroup `block` blend? The hardware deals workgroups to the 8 XCDs round-robin (XCD = block % 8), and a Gaussian's
 // records are re-read by every tile it overlaps -- from the XCD's own L2 if the neighbouring tiles run there. Round 1 gave every XCD one
-// contiguous band of tile rows. A per-tile timeline (tools/k10_timeline.sh, profiles/r02_k10_timeline_before.txt) showed what that costs: the
+// contiguous band of tile rows. A per-tile timeline (tools/k10_timeline.sh, profiles/archive/r02_k10_timeline_before.txt) showed what that costs: the
 // top band of the image is nearly empty (XCD 0 had 30 ms of summed tile time against 44-47 ms for the others at S2, 47 against 210-220 ms on the
 // layered scene, and idled for a third / two thirds of the kernel), and the heaviest rows -- the bottom of the image, nearest to the camera --
 // came LAST in every band. Alternative mapping (row_group >= 1): groups of `row_group` consecutive tile rows are dealt to the XCDs in turn over
 // the whole image and every XCD walks its rows from the bottom of the image upwards (heaviest first). Measured (tools/ab_tile_rows.py,
-// profiles/r02_ab_tile_rows.txt; training / inference blend): S2 bands 0.163 / 0.157 ms, g = 1 0.177 / 0.171, g = 2 0.189 / 0.182 -- at two
+// profiles/archive/r02_ab_tile_rows.txt; training / inference blend): S2 bands 0.163 / 0.157 ms, g = 1 0.177 / 0.171, g = 2 0.189 / 0.182 -- at two
 // blended buckets per tile the kernel lives on the L2 locality of vertical neighbours; layered scene (11 buckets per tile) bands 0.725 / 0.700,
 // g = 1 0.663 / 0.646, g = 2 0.654 / 0.633 -- there balance wins 10 %. Bands walked bottom-up (255): no difference. Which of the two a scene
 // wants depends on how deep its tiles blend, which the host does not know at launch: the DEFAULT stays the bands (the benchmark workload),
 // fgs_debug_set_option(10, g) selects the other. Returns n_tiles for padding workgroups.
-// Round 3, measured on one box (tools/ab_tile_plan.py, profiles/r03_ab_tile_plan.txt; training blend S2 / layered scene, ms):
+// Round 3, measured on one box (tools/ab_tile_plan.py, profiles/archive/r03_ab_tile_plan.txt; training blend S2 / layered scene, ms):
 //   bands (round 1/2 default)                          0.168 / 0.765
 //   single rows interleaved                            0.179 / 0.657
 //   8 x 10 blocks weighed on the device by their bucket counts, sorted, dealt heaviest-first to the least-loaded XCD

@@ -32,12 +32,12 @@ constexpr unsigned kHugeFootprint = FGS_HUGE_FOOTPRINT;   // candidate tiles abo
 #ifndef FGS_K5_BIG_FOOTPRINT
 #define FGS_K5_BIG_FOOTPRINT 256
 #endif
-constexpr unsigned kBigInstanceFootprint = FGS_K5_BIG_FOOTPRINT;   // K5: candidate tiles above which a footprint is expanded by a workgroup of the second kernel instead of by its wave
+constexpr unsigned kBigInstanceFootprint = FGS_K5_BIG_FOOTPRINT;   // K5: candidate tiles above which a footprint is expanded by one of the launch's leading workgroups instead of by its wave
 constexpr int kSeqTiles = 0;           // 0 (default): K1 counts small footprints in flattened (Gaussian, candidate) order (preprocess.hip); n > 0: A/B reference,
 // the reference's scheme with n sequential candidates per lane --          // candidate tiles each lane tests itself before the wave cooperates (reference: 4, cfg:54; measured 4: 0.355 ms, 8: 0.300, 12: 0.252, 16: 0.248, 24: 0.256, 32: 0.269 on S2)
 // One packed counter atomic per workgroup (see preprocess.hip). Round 3: 256 instead of 512 threads -- a quarter of K1's wave time was spent
 // parked at the compaction barrier waiting for slower siblings, and four waves wait less for each other than eight: 0.214 -> 0.199 ms at S2
-// (profiles/r03_ab_k1_lookback.txt). The atomics double to 11.7 k per launch at 3 M Gaussians (a same-address atomic retires at ~88 / us:
+// (profiles/archive/r03_ab_k1_lookback.txt). The atomics double to 11.7 k per launch at 3 M Gaussians (a same-address atomic retires at ~88 / us:
 // 0.13 ms of the counter's time, still below the kernel's); 128 threads would put the counter in front.
 #ifndef FGS_PREPROCESS_BLOCK
 #define FGS_PREPROCESS_BLOCK 256

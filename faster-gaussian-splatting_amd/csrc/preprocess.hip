@@ -20,10 +20,10 @@ __device__ __forceinline__ int float_to_int_ceil(float x) { return static_cast<i
 // Debug-only phase timer (tools/k1_phase_timer.sh builds a separate library with -DFGS_K1_PHASE_TIMER; the product build has none of it):
 // every wave keeps the cycles it spent between two marks in (scalar) registers and stores them ONCE, to its own slot of g_k1_phase, at the
 // end -- a first version with one atomic per mark onto eight shared words slowed the kernel 9x and measured only itself. A wave's memory
-// waits land in the phase that first uses the data, i.e. where the wave stalls. Result at S2 (profiles/r02_k1_phases.txt): loads +
+// waits land in the phase that first uses the data, i.e. where the wave stalls. Result at S2 (profiles/archive/r02_k1_phases.txt): loads +
 // projection 20 %, flattened tile count 26 %, SH colour + record 23 %, and 24 % in the last phase -- waves waiting at the workgroup
 // barrier of the compaction for slower siblings, not the counter's round trip: requesting the counter before the colour phase so that
-// the round trip overlaps with it made the kernel 6.5 % SLOWER (profiles/r02_ab_k1_early_counter.txt) and was reverted.
+// the round trip overlaps with it made the kernel 6.5 % SLOWER (profiles/archive/r02_ab_k1_early_counter.txt) and was reverted.
 #ifdef FGS_K1_PHASE_TIMER
 constexpr unsigned kK1TimerWaves = 1u << 17;
 __device__ unsigned long long g_k1_phase[kK1TimerWaves * 8];
@@ -274,7 +274,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 
 // The register budget is capped for FGS_K1_WAVES waves per SIMD. History: with packed fp32 instructions and 512-thread workgroups the uncapped
 // kernel took 116 VGPRs (two workgroups per CU) and was latency-bound: 0.216 ms uncapped, 0.196 at 6 waves (80 VGPRs, 43 spilled), 0.215 at 5,
-// 0.222 at 8 (profiles/r03_ab_k1_occupancy.txt). Built without packed fp32 (Makefile) it needs 63 VGPRs and no scratch at any cap, and its
+// 0.222 at 8 (profiles/archive/r03_ab_k1_occupancy.txt). Built without packed fp32 (Makefile) it needs 63 VGPRs and no scratch at any cap, and its
 // time does not depend on the instruction count; MORE than 6 waves per SIMD measures slower (0.226 vs 0.213 ms, r03_ab_nopk.txt: the lanes'
 // 180-byte-stride coefficient reads thrash the 32 KB L1 sooner), so the cap stays. 0 = no cap.
 #ifndef FGS_K1_WAVES

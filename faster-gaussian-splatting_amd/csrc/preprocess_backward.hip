@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(kPreprocessBackwardBlock) preprocess_backward_
 // a 16-byte piece of the [N, R, 3] block is assembled -- the same single multiplication, so the result is bit-identical. A float4 piece
 // starting at element e0 of the wave's block covers exactly the (Gaussian, basis) pairs e0/3 and e0/3 + 1. Used by the fused kernel, where
 // the slice is also the staging area of phase A (one 14 x 64 array at a time); the unfused K12 keeps the block of products (measured: the
-// piece assembly costs it 0.003 ms and it gains nothing from the LDS, profiles/r03_ab_fused_factored.txt).
+// piece assembly costs it 0.003 ms and it gains nothing from the LDS, profiles/archive/r03_ab_fused_factored.txt).
 constexpr uint32_t kShFactorStride = 18;                 // floats per Gaussian: colour gradient 3, basis values 15
 constexpr uint32_t kShFactorFloats = kWave * kShFactorStride;
 
@@ -318,7 +318,7 @@ fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) 
     // 42 loads + 42 stores per lane before, more memory instructions than phase B issues for three times the data. ----
     // The parameters come first (the gradient needs them); the moments are requested after the gradient is formed, so 28 registers are not
     // held across gaussian_backward, and every array passes through the same 3.5 KB of the slice. Round 3, one box: 0.850 -> 0.812 ms
-    // (profiles/r03_ab_fused_factored.txt; 3 or 4 waves per SIMD measure the same, 5 spills; requesting phase B's first pieces before the
+    // (profiles/archive/r03_ab_fused_factored.txt; 3 or 4 waves per SIMD measure the same, 5 spills; requesting phase B's first pieces before the
     // gradient, or double-buffering phase B, measured slower at every depth tried).
     constexpr int kLanes[5] = {48, 48, 16, 48, 64};                   // 64 w / 4 float4 pieces
     float st_p[14], st_m[14], st_v[14];
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
         visible = gaussian_backward<false, false, true>(a, i, unused, grad, dir, gcol);
         // scalar stores at a stride of 4 w bytes: the write path combines them. Staging the wave's 64 x w block in LDS and storing it as one
         // coalesced 16-byte access per lane -- what pays in the fused kernel, where the same floats are also LOADED three times -- measured
-        // 0.261 vs 0.252 ms here (profiles/r02_ab_k12_coalesced_stores.txt)
+        // 0.261 vs 0.252 ms here (profiles/archive/r02_ab_k12_coalesced_stores.txt)
         float* const outs[5] = {a.grad_means, a.grad_sh0, a.grad_opacities, a.grad_scales, a.grad_rotations};
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)

@@ -34,7 +34,7 @@ from FasterGSCudaBackend._backend import Backend, RasterizerSettings
 from .distributed import SEGMENTS, _ALIGN, _BACKWARD_ORDER, l1_grad
 
 
-INTERLEAVE_SHARDS = True      # A/B switch (tools/ab_sharded_order.py, tests): False = the renderer keeps the records in the order they arrive
+INTERLEAVE_SHARDS = True      # A/B switch (tools/archive/ab_sharded_order.py, tests): False = the renderer keeps the records in the order they arrive
 
 
 def shard_of(params: dict, rank: int, world: int) -> dict:

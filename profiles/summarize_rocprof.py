@@ -1,7 +1,7 @@
 """Turns rocprofv3 (ROCm 7.2, rocpd sqlite output) results into the small text summaries committed under profiles/.
 
-  python profiles/summarize_rocprof.py stats gpurun_out/prof_s2/bench_results.db  > profiles/r01_s2_kernel_stats.txt
-  python profiles/summarize_rocprof.py pmc   gpurun_out/pmc_fetch/bench_results.db > profiles/r01_s2_pmc_fetch.txt
+  python profiles/summarize_rocprof.py stats gpurun_out/prof_s2/bench_results.db  > profiles/archive/r01_s2_kernel_stats.txt
+  python profiles/summarize_rocprof.py pmc   gpurun_out/pmc_fetch/bench_results.db > profiles/archive/r01_s2_pmc_fetch.txt
 """
 import re
 import sqlite3

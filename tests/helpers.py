@@ -170,7 +170,7 @@ def elementwise_fraction(a: np.ndarray, ref: np.ndarray, keep: np.ndarray | None
 
 
 # The HIP path may miss the element-wise bar (against the fp64 evaluation) at most this often relative to the fp32 oracle. Measured on MI355X:
-# 0.98-1.03 at every site with >= 60 k Gaussians (profiles/r03_gpu_tolerance_slack.txt), so those are held to 1.10 (round 4); the small scenes, where the
+# 0.98-1.03 at every site with >= 60 k Gaussians (profiles/archive/r03_gpu_tolerance_slack.txt), so those are held to 1.10 (round 4); the small scenes, where the
 # counts are a handful of entries, keep 1.25 beside their 4-sigma term.
 THREE_WAY_FACTOR = 1.25
 THREE_WAY_FACTOR_LARGE = 1.10
@@ -297,7 +297,7 @@ def flip_masks(oracle, f, S, dec=None, eps=5e-6, eps_T=1e-5):
     `eps_T` of the termination test (oracle.threshold_risk), plus -- if the decoded HIP intermediates are given -- Gaussians whose integer
     screen bounds / tile count differ (a floor / ceil / cull input within an ULP of its threshold in preprocess).
     eps: v_exp_f32 (1 ulp) after the x * log2(e) rounding at |x| <= 5.6, plus FMA contraction of the three-term exponent, move alpha
-    by <= ~2e-6 relative against glibc expf without contraction; 5e-6 leaves a margin of 2.5. Measured on MI355X (tools/diag_flip.py,
+    by <= ~2e-6 relative against glibc expf without contraction; 5e-6 leaves a margin of 2.5. Measured on MI355X (tools/archive/diag_flip.py,
     S1 / S2 at 1080p): every pixel that differs by more than 1e-4 lies inside this mask, and outside it the image agrees to 5e-5 and
     all six gradients to 3e-5 of their max-abs value."""
     r = oracle.threshold_risk(f, S, eps, eps_T)

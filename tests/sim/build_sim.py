@@ -22,6 +22,19 @@ SAN = [f'-fsanitize={os.environ["FGS_SIM_SANITIZE"]}', '-fsanitize-recover=all',
 
 
 def build(force: bool = False) -> Path:
+    """(Re)builds the library if a source or header is newer; safe under pytest-xdist: concurrent callers serialise on a lock file, so no worker
+    ever dlopens a half-linked library."""
+    import fcntl
+    OUT.parent.mkdir(exist_ok=True)
+    with open(OUT.parent / '.build.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool) -> Path:
     srcs = sorted(CSRC.glob('*.hip'))
     headers = sorted(CSRC.glob('*.h')) + sorted(SIM.glob('include/**/*.h*')) + [REPO / 'include' / 'fgs_hip.h']
     newest_header = max(h.stat().st_mtime for h in headers)
@@ -36,7 +49,9 @@ def build(force: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
         objs = list(pool.map(compile_one, srcs))
     if force or not OUT.exists() or any(OUT.stat().st_mtime < o.stat().st_mtime for o in objs):
-        subprocess.run(['g++', '-shared', '-fPIC', *SAN, '-o', str(OUT), *[str(o) for o in objs]], check=True)
+        tmp = OUT.with_suffix('.so.tmp')
+        subprocess.run(['g++', '-shared', '-fPIC', *SAN, '-o', str(tmp), *[str(o) for o in objs]], check=True)
+        os.replace(tmp, OUT)                # atomic: a process that already mapped the old file keeps it
     return OUT
 
 

@@ -63,7 +63,7 @@ def test_training_iteration_captures_into_a_graph(hip_backend):
     assert int(host[2]) == 0 and int(host[1]) > 0
     # Two eager runs of these two iterations already differ: the gradients carry last-bit noise from the order of K11's float atomics, and a
     # parameter whose update lands on a rounding tie comes out one ulp apart after the first step, up to three after the second
-    # (tools/eager_repeat.py: means of ONE Gaussian, 1.8e-7 = 3 ulp at 0.5, is the whole difference in 24 runs). So: the step each tensor took
+    # (tools/archive/eager_repeat.py: means of ONE Gaussian, 1.8e-7 = 3 ulp at 0.5, is the whole difference in 24 runs). So: the step each tensor took
     # agrees to 1e-4 of its largest step, plus four ulp of the parameter itself.
     for k in ORDER:
         moved = (ref[k] - start[k]).abs().max().item()

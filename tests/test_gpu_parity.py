@@ -11,7 +11,7 @@ Two facts bound what "bit-exact" can mean on real hardware ('fast-m
    (and Gaussians) that own such a pair (oracle.threshold_risk -> helpers.flip_masks); per-pixel outputs (image, final_T,
    n_processed) and gradients are held to 1e-4 / exact OUTSIDE that mask, the mask is bounded to 1e-3 of all entries and masked
    pixels to 5e-3. No test compares against a count of unexplained outliers; achieved errors per assert site on an MI355X are in
-   profiles/r02_gpu_tolerance_slack.txt (FGS_TOL_LOG=<file> regenerates it).
+   profiles/archive/r02_gpu_tolerance_slack.txt (FGS_TOL_LOG=<file> regenerates it).
 """
 from pathlib import Path
 
@@ -60,7 +60,7 @@ def test_wave_primitives_selftest(hip_backend):
 def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None, int_budget=False):
     """Every forward intermediate against the oracle. The integer ones (screen bounds, tile counts and everything derived from them) are
     compared bit for bit: on the fixed scenes of this file no primitive's bounds differ from the oracle's on an MI355X (logged per call under
-    FGS_TOL_LOG, `profiles/r03_gpu_tolerance_slack.txt` part 3: 16 of 16), so the libm-ULP budget of rounds 1-2 -- up to max(1, n / 1000)
+    FGS_TOL_LOG, `profiles/archive/r03_gpu_tolerance_slack.txt` part 3: 16 of 16), so the libm-ULP budget of rounds 1-2 -- up to max(1, n / 1000)
     primitives, after which the downstream exact comparisons were dropped -- is now opt-in (`int_budget`) and used by no fixed scene."""
     S, RS = helpers.settings_pair(view, K, aa, bg, device=DEV)
     dp = _to(params)

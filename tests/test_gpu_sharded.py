@@ -146,7 +146,7 @@ def test_local_shard_group_equals_replicated_trainer(hip_backend, fused, steps):
     for k in SEGMENTS:
         d_ref, d_got = (tr.params[k] - start[k]).cpu().numpy(), (got[k] - start[k]).cpu().numpy()
         assert np.abs(d_ref).max() > 0
-        # Two correct pipelines whose gradients differ by summation order (1e-7, tools/diag_shard_interleave.py) do not stay within 1e-4 entry by entry
+        # Two correct pipelines whose gradients differ by summation order (1e-7, tools/archive/diag_shard_interleave.py) do not stay within 1e-4 entry by entry
         # over THREE steps: a parameter moved by 1e-7 flips an alpha >= 1/255 decision somewhere in the next render, and the Gaussians of that pixel then
         # differ at the 1e-4 level (which entries do depends on the noise: the interleaved record placement of round 4 moved the worst one from below to
         # above 1e-4). So: all but 1e-4 of the entries within 1e-4 of the largest update, none beyond 2e-3.

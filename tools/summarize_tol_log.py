@@ -2,7 +2,7 @@
 """FGS_TOL_LOG (tests/helpers.py) -> profiles/rNN_gpu_tolerance_slack.txt: per assert site the worst achieved error of `pytest -m gpu`.
 Two tables: (1) the max-norm metric of every site (rel_inf / outlier_fraction), (2) the element-wise 1e-4 criterion, three-way: the fraction
 of entries beyond 1e-4 |x| + 1e-4 median|x| for the HIP path and for the fp32 oracle, both against the fp64 evaluation of the same formulas,
-and directly HIP vs oracle32. usage: python tools/summarize_tol_log.py gpurun_out/tol.log > profiles/r03_gpu_tolerance_slack.txt"""
+and directly HIP vs oracle32. usage: python tools/summarize_tol_log.py gpurun_out/tol.log > profiles/archive/r03_gpu_tolerance_slack.txt"""
 import collections
 import re
 import sys
