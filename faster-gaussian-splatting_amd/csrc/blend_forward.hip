@@ -162,13 +162,24 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
     // conditional update (three scalar instructions per merge), and this loop is bound by the ONE scalar unit of the CU.
 #define FGS_PIXEL_DONE (!inside || T < kTransmittanceThreshold)
 
+    // Deep tiles fetch ahead: from its second batch on (a tile that needs one has proved to be deep; at S2 a tile walks ~100 of its ~1 500 entries and
+    // never gets here) the records of the NEXT batch are loaded into registers while this batch is walked, and the primitive indices of the one after
+    // that, so that the two dependent global round trips of the staging (index -> record, ~3 us per batch with the SIMD to itself) leave the serial
+    // path of a long list -- the tail of K10 on object-centric / trained scenes (tools/k10_timeline.py).
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;      // records of the next batch (have_next)
+    uint32_t prim_ahead = 0;                                           // primitive of the batch after next (have_ahead)
+    bool have_next = false, have_ahead = false;                        // workgroup-uniform
     for (unsigned batch_start = 0; batch_start < n_total; batch_start += kBlendBlock) {
         if (__syncthreads_and(FGS_PIXEL_DONE ? 1 : 0)) break;                          // kf:424
         const unsigned batch = min(static_cast<unsigned>(kBlendBlock), n_total - batch_start);
         if (tid < batch) {
-            const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
-            const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            float4 r0, r1, r2;
+            if (have_next) { r0 = n0; r1 = n1; r2 = n2; }
+            else {
+                const uint32_t prim = a.inst_prims[range.x + batch_start + tid];
+                const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+                r0 = r[0]; r1 = r[1]; r2 = r[2];
+            }
             s_a[tid] = r0;
             if (TRAINING) {                                                            // kf:430 (inference clamps at store, ki:200)
                 s_b[tid] = make_float4(r1.x, r1.y, fmaxf(r1.z, 0.0f), fmaxf(r1.w, 0.0f));
@@ -179,6 +190,18 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
             }
         }
         __syncthreads();
+        {
+            const unsigned next_start = batch_start + kBlendBlock, after_start = next_start + kBlendBlock;
+            const bool had_ahead = have_ahead;
+            have_next = batch_start >= static_cast<unsigned>(kBlendBlock) && next_start < n_total;
+            have_ahead = have_next && after_start < n_total;
+            if (have_next && next_start + tid < n_total) {
+                const uint32_t prim = had_ahead ? prim_ahead : a.inst_prims[range.x + next_start + tid];
+                const float4* r = reinterpret_cast<const float4*>(a.rec + prim);
+                n0 = r[0]; n1 = r[1]; n2 = r[2];
+            }
+            if (have_ahead && after_start + tid < n_total) prim_ahead = a.inst_prims[range.x + after_start + tid];
+        }
         for (unsigned chunk = 0; chunk < batch; chunk += kBucket) {
             const bool done = FGS_PIXEL_DONE;
             if (TRAINING && !done)                                                     // kf:436-442, every 64 instead of 32

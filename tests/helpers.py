@@ -509,3 +509,13 @@ def check_order_independent_quantities(dec: dict, f: dict, width: int, height: i
         fT = tiles_to_image(dec['final_T_tiles'], width, height)
         assert float(f['final_T'].min()) > 1e-3                                            # the scene's premise: nobody terminated
         assert np.abs(fT.reshape(-1) - f['final_T']).max() < 1e-5
+
+
+def wide_image_scene(n: int = 3000, seed: int = 19):
+    """3 000 Gaussians spread over a 20 000 x 36 px image (1 250 x 3 tiles): a fifth of them start at tile column >= 1024, beyond what a footprint row's
+    10-bit box origin holds (csrc/fgs_math.h) -- they travel as escape rows and are re-tested by the instance kernel from the record."""
+    from harness.scenes import View, make_s0
+    p, v = make_s0(seed=seed, n=n)
+    p['means'][:, 0] = p['means'][:, 0] * 60.0
+    p['means'][:, 1] = p['means'][:, 1] * 0.02
+    return p, View(v.w2c, v.position, 20000, 36, 660.0, 660.0, 10000.0, 18.0, 0.2, 1e4, torch.zeros(3))

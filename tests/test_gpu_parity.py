@@ -271,6 +271,21 @@ def test_more_than_65536_tiles_uses_32_bit_keys(hip_backend, oracle):
     _grads_close(grads, g, tol=2e-4, truth=oracle.forward_backward_f64(f, S, gi))
 
 
+def test_tile_columns_beyond_1024_use_escape_rows(hip_backend, oracle):
+    """Footprint rows (fgs_math.h) hold the tile box origin in 10 bits per axis: Gaussians whose boxes start at tile column >= 1024 (image wider than
+    16 384 px) travel as ESCAPE rows and are re-tested by the instance kernel from the record. 20 000 x 36 px = 1 250 x 3 tiles, Gaussians spread over the
+    whole width: every forward intermediate bit-exact against the oracle, gradients to 1e-4."""
+    p, v = helpers.wide_image_scene()
+    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+    sb = f['screen_bounds'].astype(np.int64)
+    assert ((sb[:, 0] // 16 >= 1024) & (f['n_touched'] > 0)).sum() > 100 and ((sb[:, 0] // 16 < 1024) & (f['n_touched'] > 0)).sum() > 100
+    gi = np.random.default_rng(2).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g = oracle.backward(f, S, gi)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                 dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    _grads_close(grads, g, truth=oracle.forward_backward_f64(f, S, gi))
+
+
 def test_public_operators_autograd_and_fused_adam(hip_backend, oracle):
     """diff_rasterize -> loss.backward() -> FusedAdam.step(): the call sequence of Trainer.py:170-199."""
     from FasterGSCudaBackend import FusedAdam, diff_rasterize

@@ -333,3 +333,17 @@ def test_equal_depth_keys_keep_every_order_independent_quantity(sim_backend, ora
     f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
     dec = helpers.decode_forward(sim_backend, res, p['means'].shape[0], view.width, view.height)
     helpers.check_order_independent_quantities(dec, f, view.width, view.height)
+
+
+def test_tile_columns_beyond_1024_use_escape_rows_sim(sim_backend, oracle):
+    """The CPU half of tests/test_gpu_parity.py::test_tile_columns_beyond_1024_use_escape_rows: instance lists, ranges and image bit for bit."""
+    p, v = helpers.wide_image_scene()
+    S, RS = helpers.settings_pair(v)
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    sb = f['screen_bounds'].astype(np.int64)
+    assert ((sb[:, 0] // 16 >= 1024) & (f['n_touched'] > 0)).sum() > 100 and ((sb[:, 0] // 16 < 1024) & (f['n_touched'] > 0)).sum() > 100
+    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(sim_backend, res, 3000, v.width, v.height)
+    assert dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
+    assert np.array_equal(dec['ranges'], f['ranges']) and np.array_equal(dec['offsets'], f['offsets'])
+    assert float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6

@@ -15,7 +15,7 @@ sviews = [look_at_view((6.4 * math.cos(2 * math.pi * k / 8), -(1.0 + 1.6 * (k % 
 import os
 scenes = [('S2', params, views), ('layered S2', layered, views), ('surface 2 M', make_surface_scene(2_000_000), sviews)]
 if os.environ.get('FGS_SCENES'): scenes = [s for s in scenes if s[0] in os.environ['FGS_SCENES'].split(',')]
-modes = [(252, 'static strips'), (254, 'device-side block plan')]
+modes = [(252, 'static strips')] if not hasattr(be.lib, 'fgs_debug_set_option') else [(252, 'static strips'), (254, 'device-side block plan')]
 for name, p, vs in scenes:
     g = T.Gaussians(p, dev)
     vv = [v.to(dev) for v in vs[:4]]
@@ -23,7 +23,8 @@ for name, p, vs in scenes:
     P = g.tensors()
     ref = None
     for m, label in modes:
-        assert be.lib.fgs_debug_set_option(10, m) == 0
+        if hasattr(be.lib, 'fgs_debug_set_option'):
+            assert be.lib.fgs_debug_set_option(10, m) == 0
         best_t, best_i = 1e9, 1e9
         for rnd in range(4):
             be.profile_enable(True); be.profile_read()
@@ -37,4 +38,5 @@ for name, p, vs in scenes:
         ref = res.image.clone() if ref is None else ref
         print(f'{name:12s} {m} {label:26s} training blend {best_t:.4f} ms   inference blend {best_i:.4f} ms   image identical to the first mapping: {same}', flush=True)
     del g
-be.lib.fgs_debug_set_option(10, 252)
+if hasattr(be.lib, 'fgs_debug_set_option'):
+    be.lib.fgs_debug_set_option(10, 252)
