@@ -519,3 +519,13 @@ def wide_image_scene(n: int = 3000, seed: int = 19):
     p['means'][:, 0] = p['means'][:, 0] * 60.0
     p['means'][:, 1] = p['means'][:, 1] * 0.02
     return p, View(v.w2c, v.position, 20000, 36, 660.0, 660.0, 10000.0, 18.0, 0.2, 1e4, torch.zeros(3))
+
+
+def many_big_footprints_scene(n: int = 700, seed: int = 23):
+    """700 large, faint Gaussians at 480 x 270 (690 tiles): ~450 of them have boxes of more than 256 candidate tiles, all inside ONE workgroup of the depth
+    sort's last pass -- more than the 256 big footprints such a workgroup collects in LDS before it appends to the list directly (radix_sort.hip)."""
+    from harness.scenes import View, make_s0
+    p, v = make_s0(seed=seed, n=n)
+    p['scales'] = p['scales'] + 2.6
+    p['opacities'] = p['opacities'] - 3.0
+    return p, View(v.w2c, v.position, 480, 270, 300.0, 300.0, 240.0, 135.0, 0.2, 1e4, torch.zeros(3))

@@ -286,6 +286,18 @@ def test_tile_columns_beyond_1024_use_escape_rows(hip_backend, oracle):
     _grads_close(grads, g, truth=oracle.forward_backward_f64(f, S, gi))
 
 
+def test_more_big_footprints_than_a_sort_workgroup_collects(hip_backend, oracle):
+    """~450 footprints of more than 256 candidate tiles inside one workgroup of the depth sort's last pass (it stages 256 in LDS, the rest append
+    directly): forward intermediates bit-exact, gradients to 1e-4 (hot-accumulator replicas included: every one of them is a hot Gaussian)."""
+    p, v = helpers.many_big_footprints_scene()
+    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+    gi = np.random.default_rng(6).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g = oracle.backward(f, S, gi)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
+                                 dp['rotations'], dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    _grads_close(grads, g, truth=oracle.forward_backward_f64(f, S, gi))
+
+
 def test_public_operators_autograd_and_fused_adam(hip_backend, oracle):
     """diff_rasterize -> loss.backward() -> FusedAdam.step(): the call sequence of Trainer.py:170-199."""
     from FasterGSCudaBackend import FusedAdam, diff_rasterize

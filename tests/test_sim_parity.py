@@ -347,3 +347,17 @@ def test_tile_columns_beyond_1024_use_escape_rows_sim(sim_backend, oracle):
     assert dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
     assert np.array_equal(dec['ranges'], f['ranges']) and np.array_equal(dec['offsets'], f['offsets'])
     assert float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6
+
+
+def test_more_big_footprints_than_a_sort_workgroup_collects_sim(sim_backend, oracle):
+    """The big-footprint list built by the depth sort's last pass, beyond its per-workgroup LDS stage: instance lists and image bit for bit."""
+    p, v = helpers.many_big_footprints_scene()
+    S, RS = helpers.settings_pair(v)
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    sb = f['screen_bounds'].astype(np.int64)
+    n_max = ((sb[:, 1] + 15) // 16 - sb[:, 0] // 16) * ((sb[:, 3] + 11) // 12 - sb[:, 2] // 12)
+    assert ((n_max > 256) & (f['n_touched'] > 0)).sum() > 300
+    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(sim_backend, res, 700, v.width, v.height)
+    assert dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
+    assert np.array_equal(dec['offsets'], f['offsets']) and float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6
