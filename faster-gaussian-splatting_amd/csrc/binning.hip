@@ -2,7 +2,7 @@
 //   depth sort (32-bit keys) -> exclusive scan of tile counts in depth order -> instance creation (exact overlap)
 //   -> stable tile sort on end_bit bits -> per-tile [start,end) ranges -> inclusive scan of per-tile bucket counts.
 // Semantics: reference rasterization/src/forward.cu:104-231 + kernels_forward.cuh:211-360 (two-stage "Splatshop" sort,
-// no 64-bit tile|depth key). Both sorts are radix_sort.hip; the offsets scan is rocPRIM's (the native AMD device primitive).
+// no 64-bit tile|depth key). Both sorts are radix_sort.hip; the offsets are a reduction + per-wave sums (below), the bucket scan a single-workgroup kernel.
 // Round 5: the depth sort's last scatter pass carries a 16-byte FOOTPRINT ROW per visible Gaussian (tile box + exact-overlap
 // bitmap, fgs_math.h) into depth order and writes its tile count beside it, so the scan (K3 + K4: apply_depth_ordering_cu + ExclusiveSum)
 // and the instance kernel (K5) read streams: until round 4 both gathered a 128-byte line per Gaussian for 4 / 16 useful bytes
