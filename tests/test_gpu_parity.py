@@ -57,7 +57,7 @@ def test_wave_primitives_selftest(hip_backend):
     assert np.array_equal(o[128:192], (l + 2) // 3) and np.all(o[192:] == 2142), (o[128:192], o[192:196])
 
 
-def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None, int_budget=False):
+def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None, int_budget=False, max_masked_pixels=1e-3):
     """Every forward intermediate against the oracle. The integer ones (screen bounds, tile counts and everything derived from them) are
     compared bit for bit: on the fixed scenes of this file no primitive's bounds differ from the oracle's on an MI355X (logged per call under
     FGS_TOL_LOG, `profiles/archive/r03_gpu_tolerance_slack.txt` part 3: 16 of 16), so the libm-ULP budget of rounds 1-2 -- up to max(1, n / 1000)
@@ -76,7 +76,8 @@ def _forward_check(hip_backend, oracle, params, view, K=16, aa=False, bg=None, i
     budget = 0 if bad == 0 else max(1, n // 1000)
     pixel_mask = helpers.flip_masks(oracle, f, S, dec)['pixel']      # pixels within an ULP-scale margin of the alpha / T thresholds
     if bad == 0:
-        helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy(), pixel_mask=pixel_mask)
+        helpers.check_forward_against_oracle(dec, f, False, view.width, view.height, res.image.cpu().numpy(), pixel_mask=pixel_mask,
+                                             max_masked_pixels=max_masked_pixels)
     else:   # an ULP-level flip in a bound: V/I may differ by a few; the image is still held to 1e-4 outside the risk mask, which
         assert bad <= budget, bad                                    # then also has to cover the pixels of the differing Gaussians
         assert abs(dec['I'] - f['I']) <= 8 * budget
@@ -290,7 +291,8 @@ def test_more_big_footprints_than_a_sort_workgroup_collects(hip_backend, oracle)
     """~450 footprints of more than 256 candidate tiles inside one workgroup of the depth sort's last pass (it stages 256 in LDS, the rest append
     directly): forward intermediates bit-exact, gradients to 1e-4 (hot-accumulator replicas included: every one of them is a hot Gaussian)."""
     p, v = helpers.many_big_footprints_scene()
-    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v)
+    # 450 faint screen-sized Gaussians: their alpha = 1/255 contours cross ~155 of the 130 k pixels inside the oracle's ULP band (1.2e-3 of the image)
+    res, f, dp, RS, S = _forward_check(hip_backend, oracle, p, v, max_masked_pixels=3e-3)
     gi = np.random.default_rng(6).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
     g = oracle.backward(f, S, gi)
     grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],
