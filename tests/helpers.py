@@ -334,7 +334,7 @@ def seed_trainer_moments(trainer, names, seed: int = 11) -> None:
 
 
 def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=1e-4, max_masked=1e-3, loose=5e-2, label='', elem_fraction=ELEM_FRACTION,
-                     truth: dict | None = None, near_tol: float | None = None):
+                     truth: dict | None = None, near_tol: float | None = None, image_flip_budget: int = 0):
     """image [3,H,W]; grads / g_ref: {name: array with the Gaussian index first}. Entries outside the masks must agree to `tol`
     (max-abs error relative to the tensor's max-abs value) AND element by element: with `truth` (oracle.forward_backward_f64: the fp64
     values of 'image' and the six gradients) three-way (elementwise_three_way), without it directly against the oracle (fewer than
@@ -353,7 +353,12 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
     if image is not None:
         err = np.abs(np.asarray(image, np.float64) - f_image).max(axis=0)
         scale = max(1.0, float(np.abs(f_image).max()))
-        report['image'] = float(err[~pm].max() / scale) if (~pm).any() else 0.0
+        outside = np.sort(err[~pm].reshape(-1))[::-1] / scale if (~pm).any() else np.zeros(1)
+        # `image_flip_budget` pixels OUTSIDE the mask may hold an alpha-test flip the oracle's band did not name (each bounded by `loose`): only the
+        # 8K test uses it -- at pixel coordinates of several thousand the exponent's terms carry ~1e-6 of rounding, more than the 5e-6 relative band
+        report['image_flips_outside_mask'] = int((outside[:image_flip_budget + 1] >= tol).sum()) if image_flip_budget else 0
+        assert image_flip_budget == 0 or float(outside[0]) < loose, (label, 'image (unmasked flip)', float(outside[0]))
+        report['image'] = float(outside[min(image_flip_budget, outside.size - 1)])
         report['image_masked'] = float(err[pm].max() / scale) if pm.any() else 0.0
         hwc = lambda x: np.moveaxis(np.asarray(x), 0, -1)[~pm]
         assert report['image'] < tol, (label, 'image', report)

@@ -389,7 +389,7 @@ def test_empty_scene(hip_backend):
 
 
 def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, K=16, aa=False, max_masked=1e-3, near_tol=None,
-                                 last_contributor_budget=1e-4):
+                                 last_contributor_budget=1e-4, image_flip_budget=0):
     """Forward + backward (+ FusedAdam-style steps with the same gradients) against the oracle; entries on a hard threshold are
     counted and excluded (helpers.check_flip_aware), everything else is held to 1e-4 -- image, six gradients, densification_info,
     and after `adam_steps` Adam steps the parameters and both moments."""
@@ -412,7 +412,7 @@ def _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_
     ref = {k: g[k] for k in helpers.GRAD_KEYS}
     ref['densification_info'] = dens_o.T
     truth = oracle.forward_backward_f64(f, S, gi)              # the same formulas in double: the element-wise bar is applied three-way
-    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, max_masked=max_masked, label=label, truth=truth, near_tol=near_tol)
+    report = helpers.check_flip_aware(res.image.cpu().numpy(), f['image'], got, ref, masks, max_masked=max_masked, label=label, truth=truth, near_tol=near_tol, image_flip_budget=image_flip_budget)
     # integer intermediates away from the thresholds: the pixel's last contributor
     npr = helpers.tiles_to_image(dec['n_processed_tiles'], view.width, view.height)
     if dec['I'] == f['I']:
@@ -508,6 +508,21 @@ def test_inference_at_s2_against_oracle(hip_backend, oracle, to_chw, clamp):
         assert float(img.max()) <= 1.0 and float(img.min()) >= 0.0
     else:
         assert float(f_inf['image'].max()) > 1.0                               # the scene does exceed 1 where nothing clamps the output
+
+
+@pytest.mark.parametrize('label,n,width,height,focal,max_masked,flips', [('S1 at 4K', 1_000_000, 3840, 2160, 2840.0, 4e-3, 0),
+                                                                          ('300k at 8K (32-bit tile keys)', 300_000, 7680, 4320, 5680.0, 2e-2, 4)])
+def test_large_images_against_oracle(hip_backend, oracle, label, n, width, height, focal, max_masked, flips):
+    """Sizes beyond the benchmark's 1080p: 3840 x 2160 (43 200 tiles: 16-bit keys sorted in two 8-bit passes, four times the instances per Gaussian) and
+    7680 x 4320 (172 800 tiles: the 32-bit key path of fwd:152-153 at scale, 18 bits in three passes) -- forward, six gradients and densification_info
+    flip-aware to 1e-4, the instance count against the oracle's. The share of Gaussians that own a (pixel, Gaussian) pair inside the oracle's ULP band
+    around the alpha threshold grows with the pixels a Gaussian covers (4.3e-4 at 1080p, 1.6e-3 at 4K: the contour AND the band widen), so the mask
+    bound is scaled with the image. At 8K up to four of the 33 M pixels may hold an alpha-test flip outside the oracle's band (measured: one, 2.8e-3 --
+    identical tile lists, tools/archive/diag_8k.py): at pixel coordinates of several thousand the exponent's three terms are ~1e1 with 1e-6 of rounding each,
+    and the HIP blend contracts them into FMAs."""
+    params = make_garden_like(n)
+    view = orbit_views(8, width=width, height=height, focal=focal)[4]
+    _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, max_masked=max_masked, image_flip_budget=flips)
 
 
 def test_full_size_properties(hip_backend):
