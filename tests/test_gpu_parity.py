@@ -525,6 +525,38 @@ def test_large_images_against_oracle(hip_backend, oracle, label, n, width, heigh
     _flip_aware_forward_backward(hip_backend, oracle, params, view, label, adam_steps=0, max_masked=max_masked, image_flip_budget=flips)
 
 
+def test_twenty_million_gaussians_forward_properties(hip_backend):
+    """Beyond north_star's '~1-6 M' range: 20 M Gaussians at 1080p (13 M visible, ~10^8 instances; the footprint rows, their sums per wave segment / block
+    and the big-footprint list at their largest sizes in the suite). No oracle run at this size: the size-independent properties -- checksum of checksums,
+    sorted keys, consistent ranges and bucket offsets, depth order inside sampled tiles, a finite image whose final transmittance lies in [0, 1]."""
+    n = 20_000_000
+    params = make_garden_like(n)
+    v = orbit_views(8)[6]
+    _, RS = helpers.settings_pair(v, device=DEV)
+    dp = _to(params)
+    res = hip_backend.forward(*[dp[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(hip_backend, res, n, v.width, v.height)
+    assert dec['V'] == int((dec['n_touched'] > 0).sum()) and dec['I'] == int(dec['n_touched'].sum()) and dec['V'] > n // 2
+    sel = 1 if np.all(np.diff(dec['depth_keys1'].astype(np.int64)) >= 0) else 0                         # which half holds the depth-sorted list
+    assert np.all(np.diff(dec[f'depth_keys{sel}'].astype(np.int64)) >= 0)
+    counts = dec['n_touched'][dec[f'prim_idx{sel}']].astype(np.int64)                                   # tile counts in depth order
+    assert np.array_equal(dec['offsets'].astype(np.int64), np.cumsum(counts) - counts)                  # K5's own offsets = their exclusive prefix
+    keys = dec['inst_keys'].astype(np.int64)
+    assert np.all(np.diff(keys) >= 0)
+    ranges = dec['ranges'].astype(np.int64)
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert lens.sum() == dec['I'] and ranges[:, 1].max() == dec['I'] and np.array_equal(np.cumsum((lens + 63) // 64), dec['bucket_offsets'].astype(np.int64))
+    assert np.all(keys == np.repeat(np.arange(len(ranges)), lens))
+    w2c = v.w2c.numpy()
+    depth = params['means'].numpy() @ w2c[2, :3] + w2c[2, 3]
+    for t in np.random.default_rng(1).choice(len(ranges), 100, replace=False):
+        # (lists of 12 k entries: neighbours are ~1e-4 apart, numpy's depth and the kernel's differ in the last bit -- hence the 2e-6)
+        assert np.all(np.diff(depth[dec['inst_prims'][ranges[t, 0]:ranges[t, 1]]].astype(np.float64)) >= -2e-6)
+    assert torch.isfinite(res.image).all() and float(res.image.min()) >= 0.0
+    fT = helpers.tiles_to_image(dec['final_T_tiles'], v.width, v.height)
+    assert fT.min() >= 0.0 and fT.max() <= 1.0
+
+
 def test_full_size_properties(hip_backend):
     """BASELINE.json full size (1920x1080, 1 M Gaussians): size-independent properties instead of an oracle run."""
     params = make_garden_like(1_000_000)
