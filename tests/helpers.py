@@ -534,3 +534,30 @@ def many_big_footprints_scene(n: int = 700, seed: int = 23):
     p['scales'] = p['scales'] + 2.6
     p['opacities'] = p['opacities'] - 3.0
     return p, View(v.w2c, v.position, 480, 270, 300.0, 300.0, 240.0, 135.0, 0.2, 1e4, torch.zeros(3))
+
+
+DEPTH_RANGE_CASES = [(0.0, 1e4, 1.0, 4), (0.2, 1e4, 1.0, 3), (3.99, 4.01, 0.009, 2), (4.0, 4.00001, 0.0, 1)]      # near, far, z scale of the scene, sort passes
+
+
+def depth_range_scene(near: float, far: float, zscale: float, n: int = 800, seed: int = 31):
+    """S0-like scene squeezed in depth so that every Gaussian stays inside [near, far]: the depth sort orders key - bits(near) in ceil(bits / 9)
+    passes -- 4 (near = 0: 31 bits), 3 (the default planes), 2, and ONE pass, which is the first (it makes up the values) and the last (it gathers the
+    footprint rows) at once. zscale 0 puts every Gaussian at the same depth: 799 tied keys."""
+    from harness.scenes import View, make_s0
+    p, v = make_s0(seed=seed, n=n)
+    p['means'][:, 2] = p['means'][:, 2] * zscale
+    return p, View(v.w2c, v.position, v.width, v.height, v.focal_x, v.focal_y, v.center_x, v.center_y, near, far, torch.zeros(3))
+
+
+def check_lists_up_to_ties(dec: dict, f: dict) -> None:
+    """Counts, tile counts, sorted depth keys, ranges and tile keys exactly; every tile's list as a SET, in non-decreasing depth (Gaussians with equal
+    depth keys keep K1's atomic compaction order on hardware, which is not the oracle's)."""
+    assert dec['V'] == f['V'] and dec['I'] == f['I'] and np.array_equal(dec['n_touched'], f['n_touched'])
+    sel = 1 if np.array_equal(dec['depth_keys1'], f['depth_keys']) else 0
+    assert np.array_equal(dec[f'depth_keys{sel}'], f['depth_keys']) and np.array_equal(np.sort(dec[f'prim_idx{sel}']), np.sort(f['prim_idx']))
+    assert np.array_equal(dec['ranges'], f['ranges']) and np.array_equal(dec['inst_keys'], f['inst_keys'])
+    key_of = dict(zip(f['prim_idx'].tolist(), f['depth_keys'].tolist()))
+    for t, (a, b) in enumerate(f['ranges']):
+        mine = dec['inst_prims'][a:b]
+        assert np.array_equal(np.sort(mine), np.sort(f['inst_prims'][a:b])), t
+        assert np.all(np.diff(np.array([key_of[int(x)] for x in mine], np.int64)) >= 0), t

@@ -300,6 +300,21 @@ def test_more_big_footprints_than_a_sort_workgroup_collects(hip_backend, oracle)
     _grads_close(grads, g, truth=oracle.forward_backward_f64(f, S, gi))
 
 
+@pytest.mark.parametrize('near,far,zscale,passes', helpers.DEPTH_RANGE_CASES)
+def test_depth_sort_pass_counts_through_the_forward(hip_backend, oracle, near, far, zscale, passes):
+    """4, 3, 2 and 1 passes of the depth sort through the whole forward pass on hardware (helpers.depth_range_scene): counts, sorted keys, ranges and tile
+    keys exactly, every tile's list as a set in depth order (tied keys -- all 800 of them in the one-pass case -- keep K1's compaction order)."""
+    p, v = helpers.depth_range_scene(near, far, zscale)
+    S, RS = helpers.settings_pair(v, device=DEV)
+    dp = _to(p)
+    res = hip_backend.forward(*[dp[k] for k in helpers.NAMES], RS)
+    torch.cuda.synchronize()
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    helpers.check_lists_up_to_ties(helpers.decode_forward(hip_backend, res, 800, v.width, v.height), f)
+    if len(np.unique(f['depth_keys'])) == f['V']:                                      # no ties: the image is the oracle's
+        assert helpers.rel_inf(res.image.cpu().numpy(), f['image']) < 1e-4
+
+
 def test_public_operators_autograd_and_fused_adam(hip_backend, oracle):
     """diff_rasterize -> loss.backward() -> FusedAdam.step(): the call sequence of Trainer.py:170-199."""
     from FasterGSCudaBackend import FusedAdam, diff_rasterize

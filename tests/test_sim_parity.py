@@ -361,3 +361,19 @@ def test_more_big_footprints_than_a_sort_workgroup_collects_sim(sim_backend, ora
     dec = helpers.decode_forward(sim_backend, res, 700, v.width, v.height)
     assert dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
     assert np.array_equal(dec['offsets'], f['offsets']) and float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6
+
+
+@pytest.mark.parametrize('near,far,zscale,passes', helpers.DEPTH_RANGE_CASES)
+def test_depth_sort_pass_counts_through_the_forward_sim(sim_backend, oracle, near, far, zscale, passes):
+    """The depth sort's value / footprint-row handling for 4, 3, 2 and 1 passes (the single pass makes up the values AND gathers the rows): instance
+    lists and image bit for bit against the oracle (the simulation compacts in index order, as the oracle does: ties included)."""
+    import struct
+    p, v = helpers.depth_range_scene(near, far, zscale)
+    span = struct.unpack('<I', struct.pack('<f', far))[0] - struct.unpack('<I', struct.pack('<f', near))[0]
+    assert (max(1, span.bit_length()) + 8) // 9 == passes
+    S, RS = helpers.settings_pair(v)
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    res = sim_backend.forward(*[p[k] for k in helpers.NAMES], RS)
+    dec = helpers.decode_forward(sim_backend, res, 800, v.width, v.height)
+    assert f['V'] == 800 and dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
+    assert np.array_equal(dec['offsets'], f['offsets']) and float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6
