@@ -6,6 +6,7 @@ harness/sharded.py) on the simulation backend:
 import os
 from pathlib import Path
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -348,7 +349,8 @@ def test_owner_side_densification_between_steps():
 def test_interleaved_record_placement_changes_nothing_but_the_order(n_shards):
     """fgs_forward_from_shard_records / fgs_backward_to_shard_records: the renderer places the shards' records interleaved (Morton neighbourhood of
     strided owners restored: K11 0.51 -> 0.43 ms at S2 with 8 shards, profiles/r04_ab_sharded_order.txt). With UNEQUAL segment lengths the image must
-    be bit-identical to the as-received placement (the visible list and therefore every tile's blending order are unchanged) and every accumulator
+    be bit-identical to the as-received placement (the visible list and therefore every tile's blending order are unchanged -- as long as no two
+    visible Gaussians share a depth key: tied keys sort in primitive-slot order, which the interleaving changes; this scene has no ties, asserted below) and every accumulator
     record must come back at the position its record came in."""
     params, settings, _ = _scene()
     s = settings[0]
@@ -368,6 +370,8 @@ def test_interleaved_record_placement_changes_nothing_but_the_order(n_shards):
     assert len(set(counts)) > 1                                   # the interesting case
     records = torch.cat(recs).contiguous()
     V, I = sum(counts), sum(c[1] for c in cnts)
+    depth_keys = records.numpy().view(np.uint32).reshape(-1, 14)[:, 12]        # a splat record = the 48-byte projected record + depth key + tile count
+    assert len(np.unique(depth_keys)) == V                       # the premise of the bit-identical image: no tied depth keys
     torch.manual_seed(3)
     grad_image = torch.randn(3, s.height, s.width) * 1e-2
     plain = be.forward_from_records(records.view(-1), V, I, s, K)
