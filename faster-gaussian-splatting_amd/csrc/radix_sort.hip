@@ -236,10 +236,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
     // compaction order). The row is gathered HERE and leaves in sorted order, so that the offsets scan and the instance kernel behind the sort
     // stream it -- their own per-Gaussian random gathers (a 128-byte line for 4 / 16 useful bytes each) were 3x their algorithmic traffic. Four
     // gathers per thread are in flight at a time; a row's first word is the primitive index (= the sorted value), its tile count goes to count_out.
-#ifndef FGS_SORT_GATHER_BATCH
-#define FGS_SORT_GATHER_BATCH 4
-#endif
-    constexpr int kBatch = FGS_SORT_GATHER_BATCH < IPT ? FGS_SORT_GATHER_BATCH : IPT;
+    constexpr int kBatch = 4 < IPT ? 4 : IPT;          // 8 / 16 in flight measured the same (profiles/r05_ab_sort_gather_batch.txt): HBM random access, not latency
     static_assert(IPT % kBatch == 0, "whole gather batches");
 #pragma unroll 1
     for (int b = 0; b < IPT / kBatch; ++b) {
