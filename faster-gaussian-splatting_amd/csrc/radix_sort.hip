@@ -33,9 +33,9 @@ constexpr int kScanPerThread = 16;                                              
 // (8 / 16 / 24 measured 0.193 / 0.181 / 0.188 ms). The 2 M-item depth sort runs < 2 workgroups per CU and looked latency-bound by a
 // workgroup's chain (load -> IPT ranking rounds -> reorder -> store), but halving the chain (IPT 8) measured 10 % SLOWER (0.119 vs 0.108 ms):
 // twice the workgroups pay their fixed costs twice and the table doubles. The instantiation stays as an A/B switch (g_depth_sort_mode bit 1).
-template <int IPT> struct SortShape {
-    static constexpr int kBlockItems = kSortThreads * IPT;
-    static constexpr int kWaveItems = kBlockItems / kSortWaves;                        // IPT rounds of 64 consecutive items
+template <int IPT, int TH> struct SortShape {
+    static constexpr int kBlockItems = TH * IPT;
+    static constexpr int kWaveItems = kBlockItems / (TH / kWave);                      // IPT rounds of 64 consecutive items
 };
 
 // `base` is subtracted first (0 for tile keys): depth keys are bit patterns of depths in [near, far], and key - bits(near) keeps their
@@ -43,8 +43,9 @@ template <int IPT> struct SortShape {
 template <typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, uint32_t base, int shift, uint32_t mask) { return ((static_cast<uint32_t>(key) - base) >> shift) & mask; }
 
-// exclusive prefix of one value per thread over the 256-thread workgroup; `total` = sum of all
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_part /*[kSortWaves]*/, uint32_t& total) {
+// exclusive prefix of one value per thread over a workgroup of WAVES waves; `total` = sum of all
+template <int WAVES = kSortWaves>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_part /*[WAVES]*/, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t excl = wave_exclusive_sum(v);
     __syncthreads();                                                 // s_part may still be read from a previous call
@@ -52,7 +53,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     __syncthreads();
     uint32_t base = 0, sum = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < kSortWaves; ++w) { const uint32_t p = s_part[w]; base += w < wv ? p : 0u; sum += p; }
+    for (uint32_t w = 0; w < static_cast<uint32_t>(WAVES); ++w) { const uint32_t p = s_part[w]; base += w < wv ? p : 0u; sum += p; }
     total = sum;
     return base + excl;
 }
@@ -60,15 +61,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 // per-workgroup digit histogram, written digit-major: hist[digit * n_blocks + block]
 // The item count comes by value or -- when the host does not know it yet -- through `n_ptr` (grid sized by a capacity, workgroups
 // beyond the count contribute zero rows and scatter nothing).
-template <typename KeyT, int IPT>
-__global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const KeyT* __restrict__ keys, const uint32_t n_value, const uint32_t* __restrict__ n_ptr,
+template <typename KeyT, int IPT, int TH>
+__global__ void __launch_bounds__(TH) radix_histogram_kernel(const KeyT* __restrict__ keys, const uint32_t n_value, const uint32_t* __restrict__ n_ptr,
                                                                        const uint32_t key_base, const int shift, const int bits, uint32_t* __restrict__ hist,
                                                                        const uint32_t n_blocks) {
-    constexpr int kBlockItems = SortShape<IPT>::kBlockItems;
+    constexpr int kBlockItems = SortShape<IPT, TH>::kBlockItems;
     __shared__ uint32_t s_hist[kMaxBins];
     const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     const uint32_t bins = 1u << bits, mask = bins - 1u;
-    for (uint32_t d = threadIdx.x; d < bins; d += kSortThreads) s_hist[d] = 0u;
+    for (uint32_t d = threadIdx.x; d < bins; d += TH) s_hist[d] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * kBlockItems;
     constexpr int kPerLoad = 16 / sizeof(KeyT);                                        // keys per 16-byte load
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const Key
     if (base + kBlockItems <= n) {                                                     // full workgroup: 16-byte loads (order is irrelevant here)
 #pragma unroll
         for (int i = 0; i < IPT / kPerLoad; ++i) {
-            const uint4 q = reinterpret_cast<const uint4*>(keys + base)[i * kSortThreads + threadIdx.x];
+            const uint4 q = reinterpret_cast<const uint4*>(keys + base)[i * TH + threadIdx.x];
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -87,12 +88,12 @@ __global__ void __launch_bounds__(kSortThreads) radix_histogram_kernel(const Key
     } else {
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
-            const uint32_t idx = base + i * kSortThreads + threadIdx.x;
+            const uint32_t idx = base + i * TH + threadIdx.x;
             if (idx < n) atomicAdd(&s_hist[digit_of(keys[idx], key_base, shift, mask)], 1u);
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < bins; d += kSortThreads) hist[(size_t)d * n_blocks + blockIdx.x] = s_hist[d];
+    for (uint32_t d = threadIdx.x; d < bins; d += TH) hist[(size_t)d * n_blocks + blockIdx.x] = s_hist[d];
 }
 
 // One workgroup per digit: exclusive scan of that digit's row of the table (over the workgroups of the sort), in place, and the
@@ -119,21 +120,22 @@ __global__ void __launch_bounds__(kSortThreads) radix_row_scan_kernel(uint32_t* 
 // digit d goes.
 // BITS (the digit width) is a template parameter so that the match loop is straight-line code: as a run-time loop it cost
 // 8 VALU + 4 SALU + a branch per bit and round. A thread owns DPT = max(1, 2^BITS / 256) ADJACENT digits in the per-digit steps.
-template <typename KeyT, int BITS, int IPT>
-__global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+template <typename KeyT, int BITS, int IPT, int TH>
+__global__ void __launch_bounds__(TH) radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                      KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                      const uint32_t n_value, const uint32_t* __restrict__ n_ptr, const uint32_t key_base,
                                                                      const int shift, const uint32_t* __restrict__ table,
                                                                      const uint32_t* __restrict__ totals, const uint32_t n_blocks, const SortPayload pl) {
-    constexpr int kBlockItems = SortShape<IPT>::kBlockItems, kWaveItems = SortShape<IPT>::kWaveItems;
+    constexpr int kBlockItems = SortShape<IPT, TH>::kBlockItems, kWaveItems = SortShape<IPT, TH>::kWaveItems;
+    constexpr int kWaves = TH / kWave;
     constexpr uint32_t kBins = 1u << BITS, mask = kBins - 1u;
-    constexpr int DPT = kBins > static_cast<uint32_t>(kSortThreads) ? static_cast<int>(kBins) / kSortThreads : 1;
+    constexpr int DPT = kBins > static_cast<uint32_t>(TH) ? static_cast<int>(kBins) / TH : 1;
     const uint32_t n = n_ptr != nullptr ? *n_ptr : n_value;
     if (blockIdx.x * kBlockItems >= n) return;                      // workgroup-uniform (capacity-sized grid)
-    __shared__ uint32_t s_cnt[kSortWaves][kBins];                 // per wave and digit: running count, later start inside the digit's run
+    __shared__ uint32_t s_cnt[kWaves][kBins];                 // per wave and digit: running count, later start inside the digit's run
     __shared__ uint32_t s_first[kBins];                           // first workgroup-local position of each digit
     __shared__ uint32_t s_dst[kBins];                             // global position of this workgroup's first item of each digit
-    __shared__ uint32_t s_part[kSortWaves];
+    __shared__ uint32_t s_part[kWaves];
     __shared__ KeyT s_key[kBlockItems];
     __shared__ uint32_t s_val[kBlockItems];
     constexpr uint32_t kBigPerBlock = 256;              // payload pass only: big footprints found by this workgroup (see the end of the kernel)
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         const bool own = d < kBins;
         if (own) {
 #pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) s_cnt[w][d] = 0u;
+            for (int w = 0; w < kWaves; ++w) s_cnt[w][d] = 0u;
         }
         digit_total[j] = own ? totals[d] : 0u;
         row_offset[j] = own ? table[(size_t)d * n_blocks + blockIdx.x] : 0u;
@@ -194,14 +196,14 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         count[j] = 0;
         if (d < kBins) {
 #pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = count[j]; count[j] += c; }
+            for (int w = 0; w < kWaves; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = count[j]; count[j] += c; }
         }
         count_sum += count[j];
         total_sum += digit_total[j];
     }
     uint32_t unused;
-    uint32_t first_local = block_exclusive_scan(count_sum, s_part, unused);
-    uint32_t digit_base = block_exclusive_scan(total_sum, s_part, unused);
+    uint32_t first_local = block_exclusive_scan<kWaves>(count_sum, s_part, unused);
+    uint32_t digit_base = block_exclusive_scan<kWaves>(total_sum, s_part, unused);
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
         const uint32_t d = d0 + j;
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
     const uint32_t block_first = blockIdx.x * kBlockItems;
     const uint32_t n_here = n - block_first < static_cast<uint32_t>(kBlockItems) ? n - block_first : static_cast<uint32_t>(kBlockItems);
     if (pl.rows_in == nullptr) {
-        for (uint32_t pos = threadIdx.x; pos < n_here; pos += kSortThreads) {
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += TH) {
             const KeyT k = s_key[pos];
             const uint32_t d = digit_of(k, key_base, shift, mask);
             const uint32_t dst = s_dst[d] + (pos - s_first[d]);
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
         KeyT key_b[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const uint32_t pos = (b * kBatch + j) * kSortThreads + threadIdx.x;
+            const uint32_t pos = (b * kBatch + j) * TH + threadIdx.x;
             const bool in = pos < n_here;
             const uint32_t p = in ? pos : 0u;
             key_b[j] = s_key[p];
@@ -274,57 +276,57 @@ __global__ void __launch_bounds__(kSortThreads) radix_scatter_kernel(const KeyT*
     if (n_big == 0u) return;                            // workgroup-uniform
     if (threadIdx.x == 0) s_big_base = atomicAdd(pl.big_count, n_big);
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_big; k += kSortThreads) pl.big_list[s_big_base + k] = s_big[k];
+    for (uint32_t k = threadIdx.x; k < n_big; k += TH) pl.big_list[s_big_base + k] = s_big[k];
 }
 
 struct SortPlan { int n_passes; int bits[8]; uint32_t n_blocks; size_t table_bytes, totals_bytes; };
 
-SortPlan plan_sort(uint32_t n, int end_bit, int max_bits, int items_per_thread) {
+SortPlan plan_sort(uint32_t n, int end_bit, int max_bits, int block_items_) {
     SortPlan p{};
     p.n_passes = (end_bit + max_bits - 1) / max_bits;
     if (p.n_passes < 1) p.n_passes = 1;
     int left = end_bit;
     for (int i = 0; i < p.n_passes; ++i) { p.bits[i] = (left + (p.n_passes - i) - 1) / (p.n_passes - i); left -= p.bits[i]; }   // even split
-    const uint32_t block_items = static_cast<uint32_t>(kSortThreads * items_per_thread);
+    const uint32_t block_items = static_cast<uint32_t>(block_items_);
     p.n_blocks = (n + block_items - 1) / block_items;
     p.table_bytes = ((size_t)kMaxBins * p.n_blocks * sizeof(uint32_t) + 255) / 256 * 256;
     p.totals_bytes = kMaxBins * sizeof(uint32_t);
     return p;
 }
 
-template <typename KeyT, int IPT>
+template <typename KeyT, int IPT, int TH>
 void launch_scatter(int bits, dim3 grid, dim3 block, hipStream_t s, const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out,
                     uint32_t n, const uint32_t* n_ptr, uint32_t key_base, int shift, const uint32_t* table, const uint32_t* totals, uint32_t n_blocks,
                     const SortPayload& pl) {
-#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B, IPT>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, key_base, shift, table, totals, n_blocks, pl); break;
+#define FGS_SCATTER(B) case B: hipLaunchKernelGGL((radix_scatter_kernel<KeyT, B, IPT, TH>), grid, block, 0, s, keys_in, vals_in, keys_out, vals_out, n, n_ptr, key_base, shift, table, totals, n_blocks, pl); break;
     switch (bits) { FGS_SCATTER(1) FGS_SCATTER(2) FGS_SCATTER(3) FGS_SCATTER(4) FGS_SCATTER(5) FGS_SCATTER(6) FGS_SCATTER(7) FGS_SCATTER(8) default: FGS_SCATTER(9) }
 #undef FGS_SCATTER
 }
 
 // `n` = item count, or with n_ptr != nullptr an upper bound of the count stored at n_ptr on the device. Keys are sorted by
 // (key - key_base) & (2^end_bit - 1): the caller guarantees key >= key_base.
-template <typename KeyT, int IPT>
+template <typename KeyT, int IPT, int TH = kSortThreads>
 hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* vals[2], int& selector, uint32_t n, const uint32_t* n_ptr,
                       uint32_t key_base, int end_bit, int max_bits, hipStream_t s, const SortPayload* payload = nullptr) {
     selector = 0;
     if (n == 0) return hipSuccess;
-    const SortPlan p = plan_sort(n, end_bit, max_bits, IPT);
+    const SortPlan p = plan_sort(n, end_bit, max_bits, IPT * TH);
     if (temp_bytes < p.table_bytes + p.totals_bytes) return hipErrorInvalidValue;
     uint32_t* table = static_cast<uint32_t*>(temp);
     uint32_t* totals = reinterpret_cast<uint32_t*>(static_cast<char*>(temp) + p.table_bytes);
-    const dim3 grid(p.n_blocks), block(kSortThreads);
+    const dim3 grid(p.n_blocks), block(TH);
     int shift = 0;
     for (int i = 0; i < p.n_passes; ++i) {
         const int bits = p.bits[i];
-        hipLaunchKernelGGL((radix_histogram_kernel<KeyT, IPT>), grid, block, 0, s, keys[selector], n, n_ptr, key_base, shift, bits, table, p.n_blocks);
-        hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), block, 0, s, table, totals, p.n_blocks);
+        hipLaunchKernelGGL((radix_histogram_kernel<KeyT, IPT, TH>), grid, block, 0, s, keys[selector], n, n_ptr, key_base, shift, bits, table, p.n_blocks);
+        hipLaunchKernelGGL(radix_row_scan_kernel, dim3(1u << bits), dim3(kSortThreads), 0, s, table, totals, p.n_blocks);
         SortPayload pl{};                                   // with a payload: the values are the input positions (first pass) and become the rows' primitives (last pass)
         if (payload != nullptr) {
             pl.iota_values = i == 0 ? 1 : 0;
             if (i == p.n_passes - 1) { pl.rows_in = payload->rows_in; pl.rows_out = payload->rows_out; pl.count_out = payload->count_out;
                                        pl.big_list = payload->big_list; pl.big_count = payload->big_count; }
         }
-        launch_scatter<KeyT, IPT>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, key_base, shift,
+        launch_scatter<KeyT, IPT, TH>(bits, grid, block, s, keys[selector], vals[selector], keys[selector ^ 1], vals[selector ^ 1], n, n_ptr, key_base, shift,
                                   table, totals, p.n_blocks, pl);
         selector ^= 1;
         shift += bits;
@@ -340,9 +342,13 @@ std::atomic<int> g_depth_sort_mode{1};              // fgs_debug_set_option(9, m
                                                     // tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
 
 constexpr int kTileSortItems = 16, kDepthSortItems = 8, kGenericMaxBits = 8;
+// The depth sort's workgroups (the kernels are templates on the workgroup size): 4096 items over 256 threads. Round 5 measured the same 4096 items over
+// 512 / 1024 threads -- half / a quarter of the ranking rounds per wave at an unchanged table -- at 0.1247 / 0.1254 ms against 0.1268
+// (profiles/r05_ab_depth_sort_threads.txt): the pass is not bound by a workgroup's own chain either; what is left is nine launches and the row gather.
+constexpr int kDepthSortThreads = 256, kDepthSortIpt = 4096 / kDepthSortThreads;
 
 size_t own_sort_temp_bytes(uint32_t n, int end_bit) {                                  // fits every configuration above (smallest workgroups, full table)
-    const SortPlan p = plan_sort(n, end_bit, kGenericMaxBits, kDepthSortItems);
+    const SortPlan p = plan_sort(n, end_bit, kGenericMaxBits, kDepthSortItems * kSortThreads);
     return p.table_bytes + p.totals_bytes;
 }
 
@@ -382,7 +388,7 @@ hipError_t own_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
     const uint32_t base = (mode & 1) ? range.base : 0u;
     const int end_bit = (mode & 1) ? range.bits : 32, max_bits = (mode & 1) ? kMaxBits : kGenericMaxBits;
     if ((mode & 2) && payload == nullptr) return sort_pairs<uint32_t, kDepthSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s);
-    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s, payload);
+    return sort_pairs<uint32_t, kDepthSortIpt, kDepthSortThreads>(temp, temp_bytes, keys, vals, selector, n, n_ptr, base, end_bit, max_bits, s, payload);
 }
 
 }  // namespace fgs
