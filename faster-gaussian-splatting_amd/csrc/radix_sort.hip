@@ -4,7 +4,7 @@
 // Why not rocPRIM: its onesweep sort is tuned for large inputs -- 16 384 items per 1024-thread workgroup (80 B of scratch per
 // lane), one histogram fill plus two fills per 8-bit pass. The depth sort has ~2 M items: ~125 workgroups for 256 CUs behind a
 // decoupled look-back chain, 14 launches, 0.167 ms for 32 MB of traffic; the tile sort moves 16 M items at 1.7 TB/s (0.266 ms).
-// Here a pass is three launches over 4096-item workgroups -- per-workgroup digit histogram -> one workgroup per digit scans its
+// Here a pass is three launches over 8192-item workgroups (4096 until round 4) -- per-workgroup digit histogram -> one workgroup per digit scans its
 // row of the [digit][workgroup] table -> stable scatter -- with ceil(end_bit / 8) passes of evenly split digit widths
 // (depth keys 4 x 8 bits, tile keys at 1080p 2 x 7 bits); 8 / 16 / 24 items per thread measured 0.193 / 0.181 / 0.188 ms for the tile
 // sort. Measured on MI355X (tools/ab_sort.py, S2): depth sort 0.135 ms,
@@ -29,7 +29,7 @@ namespace sortimpl {
 constexpr int kSortThreads = 256, kSortWaves = kSortThreads / kWave;
 constexpr int kMaxBits = 9, kMaxBins = 1 << kMaxBits;                                  // up to two digits per thread in the block-wide scans
 constexpr int kScanPerThread = 16;                                                     // row scan: table entries per thread and round
-// Items per thread (IPT) is a template parameter: 16 (4096-item workgroups) for both sorts. The 16 M-item tile sort is throughput-bound
+// Items per thread (IPT) and threads per workgroup (TH) are template parameters: 16 x 512 = 8192-item workgroups for both sorts since round 5 (16 x 256 before; what follows was measured then). The 16 M-item tile sort is throughput-bound
 // (8 / 16 / 24 measured 0.193 / 0.181 / 0.188 ms). The 2 M-item depth sort runs < 2 workgroups per CU and looked latency-bound by a
 // workgroup's chain (load -> IPT ranking rounds -> reorder -> store), but halving the chain (IPT 8) measured 10 % SLOWER (0.119 vs 0.108 ms):
 // twice the workgroups pay their fixed costs twice and the table doubles. The instantiation stays as an A/B switch (g_depth_sort_mode bit 1).
@@ -341,11 +341,14 @@ std::atomic<int> g_depth_sort_mode{1};              // fgs_debug_set_option(9, m
                                                     // = 3 passes instead of 4); bit 1: 2048-item workgroups (8 items per thread); 0 = round 1 (4 x 8 bits, 4096 items).
                                                     // tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
 
-constexpr int kTileSortItems = 16, kDepthSortItems = 8, kGenericMaxBits = 8;
-// The depth sort's workgroups (the kernels are templates on the workgroup size): 4096 items over 256 threads. Round 5 measured the same 4096 items over
-// 512 / 1024 threads -- half / a quarter of the ranking rounds per wave at an unchanged table -- at 0.1247 / 0.1254 ms against 0.1268
-// (profiles/r05_ab_depth_sort_threads.txt): the pass is not bound by a workgroup's own chain either; what is left is nine launches and the row gather.
-constexpr int kDepthSortThreads = 256, kDepthSortIpt = 4096 / kDepthSortThreads;
+// Workgroup shape of both sorts (the kernels are templates on it): **8192 items over 512 threads** (round 5; 4096 over 256 before). Twice the items per
+// workgroup double the length of a digit's run in the scatter (depth sort, 512 digits: 8 -> 16 items = 32 -> 64-byte stores; tile sort, 128 digits:
+// 32 -> 64 items) and halve the [digit][workgroup] table, its row scans and the histogram workgroups; twice the waves keep the ranking rounds per wave
+// at 16. Measured on one box (profiles/r05_ab_sort_blocks.txt, S2): depth sort 0.128 -> 0.115 ms, tile sort 0.164 -> 0.148. Other shapes: depth sort
+// 4096 items over 512 / 1024 threads 0.125 / 0.125, 8192 over 1024 0.117, 12288 over 1024 0.124; tile sort 4096 over 512 0.158, 8192 over 1024 0.197,
+// 12288 over 512 (24 items per thread: registers) 0.217; 16384 items do not fit the LDS with 32-bit keys.
+constexpr int kTileSortThreads = 512, kTileSortItems = 8192 / kTileSortThreads, kDepthSortItems = 8, kGenericMaxBits = 8;
+constexpr int kDepthSortThreads = 512, kDepthSortIpt = 8192 / kDepthSortThreads;
 
 size_t own_sort_temp_bytes(uint32_t n, int end_bit) {                                  // fits every configuration above (smallest workgroups, full table)
     const SortPlan p = plan_sort(n, end_bit, kGenericMaxBits, kDepthSortItems * kSortThreads);
@@ -353,18 +356,18 @@ size_t own_sort_temp_bytes(uint32_t n, int end_bit) {                           
 }
 
 hipError_t own_sort_pairs_u32(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
+    return sort_pairs<uint32_t, kTileSortItems, kTileSortThreads>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u16(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t n, int end_bit, hipStream_t s) {
-    return sort_pairs<uint16_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
+    return sort_pairs<uint16_t, kTileSortItems, kTileSortThreads>(temp, temp_bytes, keys, vals, selector, n, nullptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u32_device_count(void* temp, size_t temp_bytes, uint32_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s) {
-    return sort_pairs<uint32_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
+    return sort_pairs<uint32_t, kTileSortItems, kTileSortThreads>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
 }
 hipError_t own_sort_pairs_u16_device_count(void* temp, size_t temp_bytes, uint16_t* keys[2], uint32_t* vals[2], int& selector, uint32_t capacity,
                                            const uint32_t* n_ptr, int end_bit, hipStream_t s) {
-    return sort_pairs<uint16_t, kTileSortItems>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
+    return sort_pairs<uint16_t, kTileSortItems, kTileSortThreads>(temp, temp_bytes, keys, vals, selector, capacity, n_ptr, 0u, end_bit, kGenericMaxBits, s);
 }
 
 // Depth keys are the bit patterns of positive depths that passed the near / far cull (kf:67), i.e. values in [bits(near), bits(far)]:
