@@ -277,8 +277,10 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
 // 0.222 at 8 (profiles/archive/r03_ab_k1_occupancy.txt). Built without packed fp32 (Makefile) it needs 63 VGPRs and no scratch at any cap, and its
 // time does not depend on the instruction count; MORE than 6 waves per SIMD measures slower (0.226 vs 0.213 ms, r03_ab_nopk.txt: the lanes'
 // 180-byte-stride coefficient reads thrash the 32 KB L1 sooner), so the cap stays. 0 = no cap.
+// Round 5 (the kernel now also writes the footprint rows; 67 registers, no scratch): 5 / 6 / 7 / 8 waves 0.198 / 0.195 / 0.191 / 0.192 ms, 512-thread
+// workgroups 0.200, 128-thread ones 0.257 (profiles/r05_ab_k1_shapes.txt): 7 it is.
 #ifndef FGS_K1_WAVES
-#define FGS_K1_WAVES 6
+#define FGS_K1_WAVES 7
 #endif
 #if FGS_K1_WAVES > 0
 #define FGS_K1_BOUNDS __launch_bounds__(kPreprocessBlock) __attribute__((amdgpu_waves_per_eu(FGS_K1_WAVES, FGS_K1_WAVES)))
