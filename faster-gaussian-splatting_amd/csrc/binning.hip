@@ -82,7 +82,7 @@ hipError_t launch_tile_count_sums(const uint32_t* tile_counts, uint32_t* wave_su
 // screen-filling Gaussians). Until round 4 they had a launch of their own behind the main kernel (10-20 us of a 0.70 ms frame, set by the step
 // chain of the largest item); now the depth sort's last pass lists them and the first kBigBlocks workgroups of the SAME launch work the list off,
 // each item finding its own output offset from the wave-segment / block sums.
-constexpr unsigned kBigBlocks = 256;
+constexpr unsigned kBigBlocks = 512;      // leading workgroups of the launch: 128 / 256 / 512 / 1024 measured 0.058 / 0.045 / 0.043 / 0.044 ms (profiles/r05_ab_k5_block.txt)
 template <typename KeyT>
 __device__ __forceinline__ void expand_big_footprints(const uint4* __restrict__ foot, const uint32_t* __restrict__ wave_sums,
                                                       const uint32_t* __restrict__ block_sums, const PrimRec* __restrict__ rec,
