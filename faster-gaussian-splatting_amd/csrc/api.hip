@@ -189,11 +189,11 @@ struct BackwardScratch {
     }
 };
 
-std::atomic<int> g_seq_tiles{kSeqTiles};           // fgs_debug_set_option key 5
+FGS_SWITCH(g_seq_tiles, kSeqTiles);                // fgs_debug_set_option key 5 (dev build; a constant in the product, like every switch: fgs_kernels.h)
 #ifdef FGS_DEV_SWITCHES
 std::atomic<int> g_library_bucket_scan{0};         // fgs_debug_set_option key 11: 1 = rocPRIM scan for K8+K9 and no tile plan (round-2 form, A/B)
 #endif
-std::atomic<int> g_fused_single_kernel{1};         // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
+FGS_SWITCH(g_fused_single_kernel, 1);               // fgs_debug_set_option key 3: K12 / fused K12+K13 of the single-GPU path as one kernel (1) or as round 1's two (0)
 
 uint32_t bucket_capacity(uint32_t n_instances, uint32_t n_tiles) {   // sum_t ceil(len_t/64) <= I/64 + #non-empty tiles
     return n_instances / kBucket + (n_instances < n_tiles ? n_instances : n_tiles);
@@ -368,7 +368,7 @@ int forward_tail(ForwardMode mode, const PrimitiveBuffers& pb_in, const TileBuff
     uint32_t n_buckets_cap = 0;
     // The tile -> workgroup mapping is read ONCE per pass and travels in BlendArgs, so that planning and launch see the same value (it is a
     // process-wide A/B switch another thread may flip). K8+K9 (fwd:218-231) and K10's optional block plan are one single-workgroup kernel.
-    const uint32_t row_group = static_cast<uint32_t>(fgs::g_tile_row_group.load());
+    const uint32_t row_group = static_cast<uint32_t>(static_cast<int>(fgs::g_tile_row_group));
     const bool need_plan = row_group == kPlannedBlocks || row_group == kBandsThroughPlan;     // A/B mappings that read a device-side table
     const bool need_scan = training || need_plan;                                             // per-tile bucket offsets: the training blend's checkpoints
     ba.row_group = row_group;

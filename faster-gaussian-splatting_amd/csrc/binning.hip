@@ -38,7 +38,7 @@ hipError_t run_depth_sort(void* temp, size_t temp_bytes, uint32_t* keys[2], uint
 // (500 words at S2: eight L2-resident loads per lane) and the <= 63 segment sums in front of it inside its block. No prefix over the block sums is
 // formed: a "last workgroup" doing it behind a ticket needs a device-scope release fence per workgroup, and on this chip that fence writes back the
 // XCD's L2 -- measured 0.016 ms for the kernel against 0.020 for the library scan it replaced (profiles/r05_ab_scan_sums.txt). K5 writes the
-// per-Gaussian offsets on its way (the second instance kernel and the tests read them).
+// per-Gaussian offsets on its way (bu:60; the parity tests compare them with the reference's scan).
 constexpr int kSumBlock = 4096, kSumThreads = 256, kSumPerThread = kSumBlock / kSumThreads;      // 16 consecutive counts per thread = a quarter wave segment
 __global__ void __launch_bounds__(kSumThreads) tile_count_sums_kernel(const uint32_t* __restrict__ tile_counts, const uint32_t n_value,
                                                                       const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ wave_sums,
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(kInstanceBlock) create_instances_kernel(
     for (unsigned j = lane; j < block_of_wave; j += kWave) before_wave += block_sums[j];
     const uint32_t n_tiles_mine = active ? footprint_tile_count(row) : 0u;
     const uint32_t my_off = wave_sum(before_wave) + wave_exclusive_sum(n_tiles_mine);
-    if (active) offsets[i] = my_off;                   // bu:60 -- read by the second instance kernel (and by the tests)
+    if (active) offsets[i] = my_off;                   // bu:60 -- kept as an output of the stage: the parity tests compare it with the reference's scan
     const bool small = active && row.y != kFootprintEscape;
 
     // ---- bitmap footprints: their candidates end to end, 64 per step ----
@@ -456,11 +456,10 @@ __global__ void __launch_bounds__(kTileScanThreads) plan_tiles_kernel(const uint
     }
 }
 
-std::atomic<int> g_plan_experiment{0};     // fgs_debug_set_option(12, bits): 1 = blocks unsorted and dealt statically (A/B of the deal itself)
 hipError_t launch_plan_tiles(const uint2* ranges, uint32_t* bucket_offsets, uint32_t* tile_plan, uint32_t n_tiles, uint32_t grid_w, uint32_t grid_h,
                              hipStream_t s) {
     hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(kTileScanThreads), 0, s, ranges, bucket_offsets, tile_plan, n_tiles, grid_w, grid_h,
-                       g_plan_experiment.load());
+                       static_cast<int>(g_plan_experiment));
     return hipGetLastError();
 }
 

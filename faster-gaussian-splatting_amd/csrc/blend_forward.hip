@@ -42,7 +42,6 @@ namespace fgs {
 // construction and as compact as a band: -2 % at S2 and -12 % on the layered scene against the bands, closed form, no device data. The
 // device-side plan stays as an A/B option (it wins 3 % more on the layered scene and loses 10 % at S2).
 constexpr unsigned kBandsBottomFirst = 255u;     // row_group value: the round-1 bands, each walked from its last tile to its first
-std::atomic<int> g_tile_row_group{static_cast<int>(kColumnsTopDown)};
 __device__ __forceinline__ unsigned tile_of_workgroup(const unsigned block, const unsigned grid_w, const unsigned n_tiles, const unsigned row_group,
                                                       const uint32_t* __restrict__ plan = nullptr, const unsigned grid_h = 0u) {
     if (row_group == kPlannedBlocks) {

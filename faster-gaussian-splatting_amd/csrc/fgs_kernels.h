@@ -62,15 +62,21 @@ hipError_t run_tile_sort(void* temp, size_t temp_bytes, int key_bytes, void* key
                          uint32_t n_instances, const uint32_t* n_instances_ptr, int end_bit, hipStream_t s);
 hipError_t launch_extract_ranges(int key_bytes, const void* sorted_keys, uint2* ranges, uint32_t n_instances, const uint32_t* n_instances_ptr, hipStream_t s);
 
-// radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
-// The A/B switches behind fgs_debug_set_option are process-wide; atomics make concurrent set / launch well defined (a launch sees the
-// old or the new value, never a torn one).
-extern std::atomic<int> g_tile_row_group;            // blend_forward.hip: tile -> workgroup mapping (254: device-side block plan; 0: round-1 bands; 1..64 row groups)
+// A/B switches. In the product library every one of them is a compile-time constant (its adopted value): nothing process-wide can change what a
+// launch does. libfgs_hip_dev.so (-DFGS_DEV_SWITCHES) makes them process-wide atomics behind fgs_debug_set_option for the A/B tools; atomics make a
+// concurrent set / launch well defined (a launch sees the old or the new value, never a torn one).
+#ifdef FGS_DEV_SWITCHES
+#define FGS_SWITCH(name, value) inline std::atomic<int> name{value}
+#else
+#define FGS_SWITCH(name, value) constexpr int name = (value)
+#endif
 constexpr unsigned kPlannedBlocks = 254u;
 constexpr unsigned kColumnsTopDown = 252u, kColumnsBottomUp = 251u;   // one vertical strip of the image per XCD, walked row by row
 constexpr unsigned kBandsThroughPlan = 253u;         // A/B only: the round-1 bands, but with the plan's dependent load on every workgroup's path
-extern std::atomic<int> g_plan_experiment;
-extern std::atomic<int> g_depth_sort_mode;            // radix_sort.hip: bit 0 key range / 9-bit digits, bit 1 2048-item workgroups
+FGS_SWITCH(g_tile_row_group, static_cast<int>(kColumnsTopDown));   // blend_forward.hip: tile -> workgroup mapping (254: device-side block plan; 0: round-1 bands; 1..64 row groups)
+FGS_SWITCH(g_plan_experiment, 0);                    // binning.hip, option 12: 1 = blocks unsorted and dealt statically (A/B of the deal itself)
+// radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
+FGS_SWITCH(g_depth_sort_mode, 1);                    // option 9 -- bit 0: key range / 9-bit digits, bit 1: 2048-item workgroups (radix_sort.hip)
 size_t own_sort_temp_bytes(uint32_t n, int end_bit);
 // Side table carried out of the depth sort's LAST scatter pass (radix_sort.hip): the sort's values start as the input positions (the first pass
 // makes them up), the last pass gathers rows_in[value] and writes the row, its first word as the sorted value, and the row's tile count in sorted order.
@@ -235,9 +241,9 @@ hipError_t launch_gather_rows(const GatherArgs& a, hipStream_t s);
 size_t morton_temp_bytes(uint32_t n);
 hipError_t run_morton_order(const float* means, const float* lo, const float* hi, int64_t* order_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 
-extern std::atomic<int> g_adam_reverse;
-extern std::atomic<int> g_adam_nontemporal;                                  // 0 | 1
-extern std::atomic<int> g_adam_unroll;                                       // 1, 2 or 4 float4 pieces per thread (preprocess_backward.hip)
+FGS_SWITCH(g_adam_reverse, 1);                                               // option 8: reversed workgroup order (preprocess_backward.hip)
+FGS_SWITCH(g_adam_nontemporal, 1);                                           // option 2: non-temporal loads / stores
+FGS_SWITCH(g_adam_unroll, 1);                                                // option 1: 1, 2 or 4 float4 pieces per thread
 #ifdef FGS_DEV_SWITCHES
 extern std::atomic<int> g_backward_ablate;
 extern std::atomic<int> g_k11m_max_blocks;

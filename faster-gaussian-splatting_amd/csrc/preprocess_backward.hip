@@ -758,9 +758,9 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
 }
 
 // ---- K13: Adam for all parameter groups in one launch (adam.cu:10-34), float4-vectorised, U pieces per thread ----------
-std::atomic<int> g_adam_unroll{1};   // 16-byte pieces per thread (fgs_debug_set_option(1, u)); measured on MI355X: 1, 2 and 4 are within 2 %
-std::atomic<int> g_adam_reverse{1};       // fgs_debug_set_option(8, 0|1): reversed workgroup order (measured 0.837 vs 0.855 ms at S2, tools/ab_adam_order.py)
-std::atomic<int> g_adam_nontemporal{1};   // fgs_debug_set_option(2, 0|1): non-temporal loads / stores (state is streamed once per step: +2.3 % measured)
+// g_adam_unroll = 1: 16-byte pieces per thread (fgs_debug_set_option(1, u)); measured on MI355X: 1, 2 and 4 are within 2 %
+// g_adam_reverse = 1 (fgs_debug_set_option(8, 0|1) in the dev build): reversed workgroup order (measured 0.837 vs 0.855 ms at S2, tools/ab_adam_order.py)
+// g_adam_nontemporal = 1 (fgs_debug_set_option(2, 0|1) in the dev build): non-temporal loads / stores (state is streamed once per step: +2.3 % measured)
 
 template <bool NT> __device__ __forceinline__ float4 load4(const float* p) { return NT ? load_float4_nt(p) : *reinterpret_cast<const float4*>(p); }
 template <bool NT> __device__ __forceinline__ void store4(float* p, const float4 v) {
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
 
 hipError_t launch_adam(const AdamArgs& a_in, hipStream_t s) {
     AdamArgs a = a_in;
-    const int unroll_opt = g_adam_unroll.load(), nontemporal = g_adam_nontemporal.load();
+    const int unroll_opt = g_adam_unroll, nontemporal = g_adam_nontemporal;
     const int u = nontemporal ? 1 : (unroll_opt == 2 || unroll_opt == 4 ? unroll_opt : 1);
     uint32_t blocks = 0;                                  // first_block / total_blocks depend on the elements per workgroup
     for (int k = 0; k < a.n_groups; ++k) { a.g[k].first_block = blocks; blocks += static_cast<uint32_t>((a.g[k].n + 1024 * u - 1) / (1024 * u)); }

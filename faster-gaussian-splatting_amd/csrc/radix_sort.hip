@@ -337,9 +337,9 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, KeyT* keys[2], uint32_t* va
 }  // namespace sortimpl
 using namespace sortimpl;
 
-std::atomic<int> g_depth_sort_mode{1};              // fgs_debug_set_option(9, m) -- bit 0: sort key - bits(near) in ceil(bits / 9) passes (near 0.2, far 1e4: 27 bits
-                                                    // = 3 passes instead of 4); bit 1: 2048-item workgroups (8 items per thread); 0 = round 1 (4 x 8 bits, 4096 items).
-                                                    // tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
+// g_depth_sort_mode (fgs_kernels.h; fgs_debug_set_option(9, m) in the dev build) -- bit 0: sort key - bits(near) in ceil(bits / 9) passes (near 0.2,
+// far 1e4: 27 bits = 3 passes instead of 4); bit 1: 2048-item workgroups (8 items per thread); 0 = round 1 (4 x 8 bits, 4096 items).
+// tools/ab_depth_sort.py, S2 (2 M keys), one process: mode 0 0.108 ms, 1 0.096, 2 0.119, 3 0.117
 
 // Workgroup shape of both sorts (the kernels are templates on it): **8192 items over 512 threads** (round 5; 4096 over 256 before). Twice the items per
 // workgroup double the length of a digit's run in the scatter (depth sort, 512 digits: 8 -> 16 items = 32 -> 64-byte stores; tile sort, 128 digits:

@@ -37,6 +37,13 @@ def sim_backend():
 
 
 @pytest.fixture(scope='session')
+def sim_product_backend():
+    """The simulation of the PRODUCT flavour: the same sources without -DFGS_DEV_SWITCHES (every A/B switch a constant, one formulation per kernel)."""
+    import helpers
+    return helpers.sim_backend(product=True)
+
+
+@pytest.fixture(scope='session')
 def hip_backend():
     import torch
     if not torch.cuda.is_available():

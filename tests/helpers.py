@@ -30,10 +30,11 @@ def backend_modules():
     return _lib, _backend
 
 
-def sim_backend():
+def sim_backend(product=False):
+    """product=True: the simulation built WITHOUT -DFGS_DEV_SWITCHES, i.e. the host paths and the single formulations of libfgs_hip.so."""
     _lib, _backend = backend_modules()
     from tests.sim.build_sim import build
-    return _backend.Backend(_lib.bind(build()))
+    return _backend.Backend(_lib.bind(build(product=product)))
 
 
 def settings_pair(view, active_sh_bases=16, proper_aa=False, bg=None, device='cpu'):

@@ -46,6 +46,11 @@ def test_header_symbols_are_exported_and_bound(hip_lib):
     assert b'dev-switches' in dev_lib.fgs_build_info() and b'dev' not in hip_lib.fgs_build_info()
     assert hip_lib.fgs_abi_version() == 2
     assert b'gfx950' in hip_lib.fgs_build_info()
+    # ... and no switch variables either: every A/B switch of the sources (FGS_SWITCH, csrc/fgs_kernels.h) is a compile-time constant in the product
+    data = lambda lib: {ln.split()[-1] for ln in subprocess.run(['nm', '-C', str(lib)], check=True, capture_output=True, text=True).stdout.splitlines()
+                        if re.search(r' [bBdDuV] (fgs::|\(anonymous namespace\)::)g_', ln)}
+    assert data(LIB) <= {'(anonymous', 'namespace)::g_prof', 'namespace)::g_error'}, data(LIB)      # fgs_profile_enable's recorder, fgs_last_error's buffer
+    assert {'fgs::g_backward_variant', 'fgs::g_depth_sort_mode', 'fgs::g_tile_row_group'} <= data(dev)
 
 
 def test_argument_validation_without_gpu(hip_lib):

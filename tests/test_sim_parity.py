@@ -77,6 +77,28 @@ def test_s0_all_intermediates(sim_backend, oracle):
     _run(sim_backend, oracle, params, view)
 
 
+def test_product_flavour_of_the_sources(sim_product_backend, sim_backend, oracle):
+    """The other sim tests run the sources with -DFGS_DEV_SWITCHES (they compare formulations). libfgs_hip.so is built WITHOUT it: its switches are
+    compile-time constants (csrc/fgs_kernels.h: FGS_SWITCH) and the A/B variants are not compiled. The same suite of checks on that flavour: every
+    intermediate against the oracle, fused == backward -> Adam, Adam against the oracle, a synchronisation-free forward, and bit-identical
+    results between the two flavours."""
+    assert not hasattr(sim_product_backend.lib, 'fgs_debug_set_option') and hasattr(sim_backend.lib, 'fgs_debug_set_option')
+    assert b'dev' not in sim_product_backend.lib.fgs_build_info() and b'dev' in sim_backend.lib.fgs_build_info()
+    params, view = make_s0()
+    res, _ = _run(sim_product_backend, oracle, params, view)
+    params4, v = make_s0(seed=3, n=150)
+    view4 = View(v.w2c, v.position, 130, 25, 0.8 * 130, 0.8 * 130, 65.0, 12.5, 0.2, 1e4, torch.tensor([0.2, 0.5, 0.7]))
+    _run(sim_product_backend, oracle, params4, view4, K=9, aa=True)
+    _, RS = helpers.settings_pair(view)
+    dev = sim_backend.forward(*[params[k] for k in helpers.NAMES], RS)
+    assert torch.equal(res.image, dev.image) and res.state == dev.state
+    small, view_s = make_s0(n=400)
+    small['means'][:40, 2] = -10.0
+    fused_equals_backward_then_adam(sim_product_backend, small, view_s)
+    test_adam_single_and_multi(sim_product_backend, oracle)
+    test_forward_without_host_synchronisation(sim_product_backend, oracle)
+
+
 @pytest.mark.parametrize('w,h,K,aa', [(48, 36, 4, True), (50, 30, 16, False), (16, 12, 1, False), (130, 25, 9, True)])
 def test_partial_tiles_sh_degrees_antialiasing(sim_backend, oracle, w, h, K, aa):
     p, v = make_s0(seed=3, n=150)
