@@ -327,7 +327,8 @@ int32_t fgs_debug_radix_sort(void* keys0, void* keys1, uint32_t* vals0, uint32_t
 int32_t fgs_debug_depth_sort(uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1, int32_t n, float near_plane, float far_plane,
                              void* temp, size_t temp_bytes, void* stream);
 /* ---- libfgs_hip_dev.so only (built with -DFGS_DEV_SWITCHES: `make -C faster-gaussian-splatting_amd/csrc dev`). The product library has ONE formulation
- * of every kernel and no process-wide switches; the A/B tools under tools/ and the variant tests load the dev library. ---- */
+ * of every kernel and no process-wide switches (every switch below is a compile-time constant there, csrc/fgs_kernels.h: FGS_SWITCH); the A/B tools
+ * under tools/ and the variant tests load the dev library. ---- */
 #ifdef FGS_DEV_SWITCHES
 /* Selects the blend-backward formulation: 3 (default) = live-bucket list + compacted pixels + two-value pipeline state, 2 / 0 =
  * round-1 systolic form (dL/dC from global memory / LDS), 1 = strip (lane = pixel, DPP reductions), 4 = lane = pixel walk with the
@@ -337,7 +338,7 @@ int32_t fgs_debug_set_backward_variant(int32_t variant);
 /* Tuning switches for A/B measurements inside one process (process-wide, unsynchronised: bench / test processes only):
  * key 0 = blend-backward variant, 1 = Adam float4 pieces per thread (1, 2, 4), 2 = Adam non-temporal accesses, 3 = fused
  * backward+Adam as one kernel (1, default) or round 1's two (0), 5 = K1 tile counting: 0 flattened (default) or n sequential
- * candidates per lane, 6 = sort implementation bits, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop; variant 4: 4 no
+ * candidates per lane, 7 = K11 timing experiments (results WRONG: 1 no atomics, 2 no step loop; variant 4: 4 no
  * matrix instructions / write-out, 8 no pair arithmetic),
  * 8 = Adam walks the arenas from the end (1, default) or the start (0), 9 = depth sort: bit 0 key - bits(near) in 9-bit passes, bit 1
  * 2048-item workgroups (1 default; 0 = round 1: 4 x 8 bits, 4096 items; bit 1 measured slower), 10 = forward-blend tile -> workgroup
