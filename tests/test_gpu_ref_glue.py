@@ -1,0 +1,98 @@
+"""GPU tests (-m gpu) against the fixtures the REFERENCE'S OWN torch_bindings/*.py produced in the build container (tests/golden/ref_glue_*,
+made by tests/golden/make_ref_glue_golden.py on the CPU simulation; see tests/test_ref_glue.py for the bit-exact CPU side). /root/reference
+does not exist here: the fixture and the recorded `_C` call trace are data.
+
+  * the package's operators on the MI355X, run through the scenario of tests/ref_glue.py, agree with the fixture within 1e-4 (north_star's bar);
+  * the recorded call trace -- the reference's argument routing as executed -- replayed against `FasterGSCudaBackend._C` on the MI355X does too
+    (this replaces the re-typed copy of the reference's autograd class this file's predecessor kept).
+
+Adam with eps = 1e-15 (Model.py:247) moves a parameter by lr * sign(g) in its first step and by lr * m / sqrt(v) afterwards: the update is a
+function of gradient RATIOS, so an element whose gradient is small against the tensor's largest (where 1e-4-of-max agreement says little about
+the ratio) may step differently on another summation order. Parameters are therefore compared at 1e-4 on the elements whose GPU gradient agrees
+with the fixture's to 1e-3 of the element itself in every iteration so far (the share of the others is bounded and logged, and they can be off by
+at most the steps taken); moments, being polynomials of the gradients, are compared everywhere at 1e-4, step counts exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import ref_glue
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-4
+
+
+def _compare(name, got, want):
+    lrs = dict(ref_glue.GROUPS)
+    masked_share = {}
+    for key in sorted(want):
+        if '_step_' in key and key not in got:
+            continue
+        a, b = np.asarray(got[key]), np.asarray(want[key])
+        assert a.shape == b.shape, (key, a.shape, b.shape)
+        if b.dtype == np.bool_:
+            assert np.array_equal(a, b), key
+            continue
+        if '_step_' in key:
+            assert int(a) == int(b), key
+            continue
+        if '_param_' in key:
+            it, group = int(key[2]), key.split('_param_')[1]
+            risky = np.zeros(b.shape, bool)
+            for j in range(it + 1):
+                g_fix, g_gpu = want[f'it{j}_grad_{group}'].reshape(b.shape), np.asarray(got[f'it{j}_grad_{group}']).reshape(b.shape)
+                risky |= np.abs(g_gpu - g_fix) > 1e-3 * np.abs(g_fix)
+            scale = np.abs(b).max()
+            assert np.abs(a - b)[~risky].max() <= TOL * scale, (key, float(np.abs(a - b)[~risky].max() / scale))
+            assert np.abs(a - b).max() <= 2.0 * (it + 1) * lrs[group] + TOL * scale, key
+            masked_share[key] = float(risky.mean())
+            continue
+        if key.startswith('f3d_filter'):          # untouched entries stay at FLT_MAX
+            assert np.array_equal(a == np.finfo(np.float32).max, b == np.finfo(np.float32).max), key
+            a, b = np.where(b == np.finfo(np.float32).max, 0.0, a), np.where(b == np.finfo(np.float32).max, 0.0, b)
+        assert helpers.rel_inf(a, b) < TOL, (key, helpers.rel_inf(a, b))
+    assert max(masked_share.values()) < 0.35, masked_share
+    helpers.log_note('ref_glue_masked_share', round(max(masked_share.values()), 5), scene=name)
+
+
+@pytest.mark.parametrize('name', ref_glue.SCENES)
+def test_package_operators_match_the_reference_glue_fixture(hip_backend, name):
+    want, _trace = ref_glue.load_fixture(name)
+    got = ref_glue.run_scenario(ref_glue.package_ops(), name, DEV)
+    assert sorted(got) == sorted(want)
+    _compare(name, got, want)
+
+
+@pytest.mark.parametrize('name', ref_glue.SCENES)
+def test_reference_call_trace_replayed_through_c_module(hip_backend, name):
+    """bindings.cpp:12-21 on the MI355X, driven exactly as the reference's glue drives it (the trace), nothing else."""
+    from FasterGSCudaBackend import _C
+    want, trace = ref_glue.load_fixture(name)
+    got = ref_glue.replay_outputs(_C, name, trace, DEV)
+    _compare(name, got, want)
+    # the three integers of the reference's forward (instance count, bucket count, selector): what the GPU returns is what the fixture run passed on
+    env = ref_glue.replay_environment(name, DEV)
+    out = _C.forward(*[env[k] for k in helpers.NAMES], *[a['v'] if 'v' in a else env[a['t']] for a in trace[0]['args'][6:19]])
+    assert len(out) == 8 and all(t.dtype == torch.uint8 for t in out[1:5]) and all(isinstance(x, int) for x in out[5:]) and out[7] in (0, 1)
+
+
+def test_c_module_aux_entry_points_on_device_inputs(hip_backend, oracle):
+    """relocation_adjustment / add_noise against the oracle on GPU-generated inputs (the fixture covers the reference's call shapes)."""
+    from FasterGSCudaBackend import _C
+    rng = np.random.default_rng(1)
+    n = 500
+    op = torch.from_numpy(rng.uniform(0.05, 0.95, (n, 1)).astype(np.float32)).to(DEV)
+    sc = torch.from_numpy(rng.uniform(0.01, 0.2, (n, 3)).astype(np.float32)).to(DEV)
+    ns = torch.from_numpy(rng.integers(1, 9, n)).to(DEV)
+    new_op, new_sc = _C.relocation_adjustment(op, sc, ns)                       # densification.py:11
+    r_op, r_sc = oracle.relocation_adjustment(op.cpu().numpy(), sc.cpu().numpy(), ns.cpu().numpy())
+    assert helpers.rel_inf(new_op.cpu().numpy(), r_op) < 1e-5 and helpers.rel_inf(new_sc.cpu().numpy(), r_sc) < 1e-5
+    means = torch.zeros(n, 3, device=DEV)
+    noise = torch.randn(n, 3, device=DEV)
+    rs, rq, ro = torch.randn(n, 3, device=DEV) * 0.3 - 3.0, torch.randn(n, 4, device=DEV), torch.randn(n, 1, device=DEV)
+    assert _C.add_noise(rs, rq, ro, noise, means, 1e-3) is None                 # densification.py:21
+    ref = np.zeros((n, 3), np.float32)
+    oracle.add_noise(rs.cpu().numpy(), rq.cpu().numpy(), ro.cpu().numpy(), noise.cpu().numpy(), ref, 1e-3)
+    assert helpers.rel_inf(means.cpu().numpy(), ref) < 1e-4
