@@ -1,6 +1,6 @@
 // Maintenance of the Gaussian set on the device: adaptive density control, pruning, re-ordering and the Morton
 // order, INCLUDING the Adam-state surgery, as three kinds of pass over the 59 + 2 x 59 floats of every Gaussian:
-//   classify (one lane per Gaussian) -> 4-way exclusive scan -> scatter of parameters and both moments        adaptive_density_control
+//   classify (one lane per Gaussian) -> 4-way exclusive scan (own kernels) -> scatter of parameters and both moments        adaptive_density_control
 //   gather of parameters and both moments through an index list                                              prune / sort
 //   30-bit Morton key (one lane per Gaussian) + the stable radix sort of radix_sort.hip                       apply_morton_ordering
 // Semantics: reference Model.py:312-366 (clone small / split large above the gradient threshold, then prune), :275-306 (prune, sort),
@@ -15,8 +15,7 @@
 // Built with -ffp-contract=off (Makefile): keys and thresholds reproduce the numpy restatement of Model.py that the tests compare with, bit for bit.
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
+#include "fgs_tile_scan.h"
 
 namespace fgs {
 
@@ -44,18 +43,97 @@ __global__ void __launch_bounds__(256) adc_classify_kernel(const AdcPlanArgs a) 
     a.plan[i] = word;
 }
 
-// Exclusive scan of the four plan bits over all Gaussians: ONE look-back scan over uint4 counters (rocPRIM, transform iterator over the
-// plan words), offsets[i] = (survivor, clone, child, split) ranks in front of Gaussian i; the totals come from the last element.
-struct PlanBits {
-    __host__ __device__ uint4 operator()(const uint32_t w) const { return make_uint4(w & 1u, (w >> 1) & 1u, (w >> 2) & 1u, (w >> 3) & 1u); }
-};
-struct PlusU4 {
-    __host__ __device__ uint4 operator()(const uint4& a, const uint4& b) const { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-};
-__global__ void adc_totals_kernel(const AdcPlanArgs a) {
-    const uint4 o = a.offsets[a.n - 1];
-    const uint32_t w = a.plan[a.n - 1];
-    a.totals[0] = o.x + (w & 1u); a.totals[1] = o.y + ((w >> 1) & 1u); a.totals[2] = o.z + ((w >> 2) & 1u); a.totals[3] = o.w + ((w >> 3) & 1u);
+// Exclusive scan of the four plan bits over all Gaussians, offsets[i] = (survivor, clone, child, split) ranks in front of Gaussian i, as three
+// small kernels of this repository's own (until round 5 one rocPRIM look-back scan over uint4 counters -- the last library call of the package):
+//   adc_block_sums_kernel   a 256-thread workgroup owns kAdcBlock = 4096 consecutive Gaussians, a thread 16 consecutive plan words (four 16-byte
+//                           loads); the four counts travel PACKED, two 16-bit fields per 32-bit word (a workgroup's count is <= 4096), through one
+//                           DPP wave scan per word -> block_sums[b]
+//   adc_scan_blocks_kernel  ONE 1024-thread workgroup: exclusive scan of the block sums (fgs_tile_scan.h, 16 Ki blocks = 67 M Gaussians per pass),
+//                           in place, and the four totals
+//   adc_offsets_kernel      the same local scan again, now written out: block base + ranks inside the block
+// 24 bytes per Gaussian in all; runs every 100 iterations (Model.py:312).
+constexpr uint32_t kAdcPerThread = 16, kAdcBlock = 256u * kAdcPerThread;
+
+__device__ __forceinline__ uint32_t plan_lo(const uint32_t w) { return (w & 1u) | (((w >> 1) & 1u) << 16); }          // survivors | clones << 16
+__device__ __forceinline__ uint32_t plan_hi(const uint32_t w) { return ((w >> 2) & 1u) | (((w >> 3) & 1u) << 16); }   // children | split << 16
+
+// the 16 plan words of this thread (0 beyond the end), their packed exclusive prefixes inside the thread, and the thread's packed totals
+__device__ __forceinline__ void adc_thread_items(const uint32_t* __restrict__ plan, const uint32_t n, const uint32_t first, uint32_t (&w)[kAdcPerThread],
+                                                 uint32_t (&ex_lo)[kAdcPerThread], uint32_t (&ex_hi)[kAdcPerThread], uint32_t& lo, uint32_t& hi) {
+    if (first + kAdcPerThread <= n) {
+#pragma unroll
+        for (uint32_t q = 0; q < kAdcPerThread / 4u; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(plan + first + 4u * q);          // first is a multiple of 16: 64-byte aligned
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kAdcPerThread; ++k) w[k] = first + k < n ? plan[first + k] : 0u;
+    }
+    lo = 0u; hi = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kAdcPerThread; ++k) { ex_lo[k] = lo; ex_hi[k] = hi; lo += plan_lo(w[k]); hi += plan_hi(w[k]); }
+}
+
+// packed exclusive prefix of (lo, hi) over the 256 threads of the workgroup; returns the workgroup's packed totals through tot_lo / tot_hi
+__device__ __forceinline__ void adc_workgroup_scan(const uint32_t lo, const uint32_t hi, uint32_t& before_lo, uint32_t& before_hi, uint32_t& tot_lo,
+                                                   uint32_t& tot_hi, uint32_t (&s_tot)[2][4]) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t inc_lo = wave_inclusive_sum(lo), inc_hi = wave_inclusive_sum(hi);
+    if (lane == 63u) { s_tot[0][wv] = inc_lo; s_tot[1][wv] = inc_hi; }
+    __syncthreads();
+    before_lo = inc_lo - lo; before_hi = inc_hi - hi; tot_lo = 0u; tot_hi = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t a = s_tot[0][k], b = s_tot[1][k];
+        before_lo += k < wv ? a : 0u; before_hi += k < wv ? b : 0u;
+        tot_lo += a; tot_hi += b;
+    }
+}
+
+__global__ void __launch_bounds__(256) adc_block_sums_kernel(const uint32_t* __restrict__ plan, uint4* __restrict__ block_sums, const uint32_t n) {
+    __shared__ uint32_t s_tot[2][4];
+    uint32_t w[kAdcPerThread], ex_lo[kAdcPerThread], ex_hi[kAdcPerThread], lo, hi, before_lo, before_hi, tot_lo, tot_hi;
+    adc_thread_items(plan, n, blockIdx.x * kAdcBlock + threadIdx.x * kAdcPerThread, w, ex_lo, ex_hi, lo, hi);
+    adc_workgroup_scan(lo, hi, before_lo, before_hi, tot_lo, tot_hi, s_tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(tot_lo & 0xffffu, tot_lo >> 16, tot_hi & 0xffffu, tot_hi >> 16);
+}
+
+__global__ void __launch_bounds__(kTileScanThreads) adc_scan_blocks_kernel(uint4* __restrict__ block_sums, uint32_t* __restrict__ totals, const uint32_t n_blocks) {
+    __shared__ TileScanShared s;
+    uint32_t base[4] = {0u, 0u, 0u, 0u};
+    int parity = 0;
+    for (uint32_t first = 0; first < n_blocks; first += kTileScanThreads * kTileScanPerThread) {
+        const uint32_t mine = first + threadIdx.x * kTileScanPerThread;
+        uint32_t v[4][kTileScanPerThread], ex[4][kTileScanPerThread];
+#pragma unroll
+        for (int k = 0; k < kTileScanPerThread; ++k) {
+            const uint4 b = mine + k < n_blocks ? block_sums[mine + k] : make_uint4(0u, 0u, 0u, 0u);
+            v[0][k] = b.x; v[1][k] = b.y; v[2][k] = b.z; v[3][k] = b.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { base[c] += tile_scan_pass(v[c], ex[c], s, base[c], parity); parity ^= 1; }
+#pragma unroll
+        for (int k = 0; k < kTileScanPerThread; ++k)
+            if (mine + k < n_blocks) block_sums[mine + k] = make_uint4(ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
+    }
+    if (threadIdx.x == 0) { totals[0] = base[0]; totals[1] = base[1]; totals[2] = base[2]; totals[3] = base[3]; }
+}
+
+__global__ void __launch_bounds__(256) adc_offsets_kernel(const uint32_t* __restrict__ plan, const uint4* __restrict__ block_base, uint4* __restrict__ offsets,
+                                                          const uint32_t n) {
+    __shared__ uint32_t s_tot[2][4];
+    uint32_t w[kAdcPerThread], ex_lo[kAdcPerThread], ex_hi[kAdcPerThread], lo, hi, before_lo, before_hi, tot_lo, tot_hi;
+    const uint32_t first = blockIdx.x * kAdcBlock + threadIdx.x * kAdcPerThread;
+    adc_thread_items(plan, n, first, w, ex_lo, ex_hi, lo, hi);
+    adc_workgroup_scan(lo, hi, before_lo, before_hi, tot_lo, tot_hi, s_tot);
+    const uint4 base = block_base[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < kAdcPerThread; ++k) {
+        if (first + k >= n) break;
+        const uint32_t l = before_lo + ex_lo[k], h = before_hi + ex_hi[k];
+        offsets[first + k] = make_uint4(base.x + (l & 0xffffu), base.y + (l >> 16), base.z + (h & 0xffffu), base.w + (h >> 16));
+    }
 }
 
 // Scatter of ONE parameter group (row width W floats) and its two moments. One thread per source float: coalesced reads, writes in runs.
@@ -149,21 +227,16 @@ __global__ void __launch_bounds__(256) widen_indices_kernel(const uint32_t* __re
     if (i < n) out[i] = static_cast<int64_t>(in[i]);
 }
 
-size_t adc_scan_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    auto in = rocprim::make_transform_iterator(static_cast<const uint32_t*>(nullptr), PlanBits{});
-    (void)rocprim::exclusive_scan(nullptr, bytes, in, static_cast<uint4*>(nullptr), make_uint4(0u, 0u, 0u, 0u), n, PlusU4{});
-    return bytes;
-}
+size_t adc_scan_temp_bytes(uint32_t n) { return (size_t)((n + kAdcBlock - 1u) / kAdcBlock) * sizeof(uint4); }      // the block sums
 
 hipError_t launch_adc_plan(const AdcPlanArgs& a, hipStream_t s) {
     if (a.n == 0) return hipMemsetAsync(a.totals, 0, 4 * sizeof(uint32_t), s);
+    const uint32_t n_blocks = (a.n + kAdcBlock - 1u) / kAdcBlock;
+    uint4* const block_sums = static_cast<uint4*>(a.scan_temp);
     hipLaunchKernelGGL(adc_classify_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
-    auto in = rocprim::make_transform_iterator(static_cast<const uint32_t*>(a.plan), PlanBits{});
-    size_t bytes = a.scan_temp_bytes;
-    const hipError_t e = rocprim::exclusive_scan(a.scan_temp, bytes, in, a.offsets, make_uint4(0u, 0u, 0u, 0u), a.n, PlusU4{}, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(adc_totals_kernel, dim3(1), dim3(1), 0, s, a);
+    hipLaunchKernelGGL(adc_block_sums_kernel, dim3(n_blocks), dim3(256), 0, s, a.plan, block_sums, a.n);
+    hipLaunchKernelGGL(adc_scan_blocks_kernel, dim3(1), dim3(kTileScanThreads), 0, s, block_sums, a.totals, n_blocks);
+    hipLaunchKernelGGL(adc_offsets_kernel, dim3(n_blocks), dim3(256), 0, s, a.plan, block_sums, a.offsets, a.n);
     return hipGetLastError();
 }
 

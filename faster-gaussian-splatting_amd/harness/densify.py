@@ -4,11 +4,11 @@ NeRFICG's `Optim.adam_utils` helpers perform in the reference (`extend_param_gro
 `replace_param_group_data`; not vendored, semantics as in the original 3DGS code base: new entries start with zero moments,
 pruned/sorted entries keep theirs, replaced data resets its moments).
 
-On a ROCm device (or whenever a backend is passed as `ops_backend`) adaptive density control, prune, sort and the Morton order run as
-the device passes of csrc/densify.hip (classify -> scan -> one scatter of the 59 parameters and 2 x 59 moments per Gaussian; one
-gather launch for prune / sort; key + radix sort for Morton): every tensor is read once and written once. The torch-op formulation of
-the reference (mask / index / cat chains, ~80 ms per call at 0.5 M Gaussians in round 1) is kept for CPU tensors, where it doubles as
-the readable restatement of Model.py:312-366 that the CPU tests check.
+Adaptive density control runs as the device passes of csrc/densify.hip (classify -> scan -> one scatter of the 59 parameters and 2 x 59
+moments per Gaussian): every tensor is read once and written once; there is no second, torch-op formulation of it in the product (the
+readable restatement of Model.py:312-366 the tests compare with is oracle/oracle.py, test infrastructure). Prune / sort go through one gather
+launch for all 18 tensors, the Morton order through key + radix sort; for CPU tensors (host-side tooling, the CPU tests) prune / sort fall back
+to plain indexing. A backend other than the HIP library -- the CPU simulation in the tests -- is injected with `ops_backend`.
 
 Runs every 100 iterations (Trainer.py:120-139); consumes the `densification_info[2,N]` statistics that the backward pass accumulates
 (kernels_backward.cuh:194-201).
@@ -26,14 +26,6 @@ GARDEN_SCHEDULE = {  # fastergs_garden.yaml:66-70 / Trainer.py:16-67
     'densification_start': 600, 'densification_end': 14_900, 'densification_interval': 100, 'grad_threshold': 2.0e-4,
     'percent_dense': 0.01, 'opacity_reset_interval': 3_000, 'morton_interval': 5_000, 'morton_end': 15_000, 'sh_interval': 1_000,
 }
-
-
-def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
-    q = q / q.norm(dim=1, keepdim=True)
-    r, x, y, z = q.unbind(dim=1)
-    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
 
 
 def _device_backend(g: Gaussians, ops_backend=None):
@@ -188,52 +180,22 @@ def adaptive_density_control(g: Gaussians, grad_threshold: float, min_opacity: f
         g.densification_info = None                                                        # Model.py:353-355
         # cloned / children_per_copy count what SURVIVED the pruning that follows the densification; pruned = old Gaussians that are gone
         return {'cloned': clones, 'split': split, 'pruned': n_old - kept, 'total': g.means.shape[0], 'kept': kept, 'children_per_copy': children}
-    info = g.densification_info
-    extent = g.extent
-    means, scales, rotations = g.means.detach(), g.scales.detach(), g.rotations.detach()
-    opacities, sh0, sh_rest = g.opacities.detach(), g.sh_coefficients_0.detach(), g.sh_coefficients_rest.detach()
-    densification_mask = info[1] >= grad_threshold * info[0].clamp_min(1.0)
-    is_small = scales.max(dim=1).values <= math.log(percent_dense * extent)
-
-    duplicate_mask = densification_mask & is_small
-    split_mask = densification_mask & ~is_small
-    split_scales = scales[split_mask].exp().expand(2, -1, -1).flatten(end_dim=1)
-    split_rotations = rotations[split_mask].expand(2, -1, -1).flatten(end_dim=1)
-    noise = torch.randn(split_scales.shape, generator=generator, device=split_scales.device if generator is None or generator.device.type != 'cpu' else 'cpu').to(split_scales.device)
-    offsets = (quaternion_to_rotation_matrix(split_rotations) @ (split_scales * noise)[..., None])[..., 0]
-    extra = {
-        'means': torch.cat([means[duplicate_mask], means[split_mask].expand(2, -1, -1).flatten(end_dim=1) + offsets]),
-        'sh_coefficients_0': torch.cat([sh0[duplicate_mask], sh0[split_mask].expand(2, -1, -1, -1).flatten(end_dim=1)]),
-        'sh_coefficients_rest': torch.cat([sh_rest[duplicate_mask], sh_rest[split_mask].expand(2, -1, -1, -1).flatten(end_dim=1)]),
-        'opacities': torch.cat([opacities[duplicate_mask], opacities[split_mask].expand(2, -1, -1).flatten(end_dim=1)]),
-        'scales': torch.cat([scales[duplicate_mask], split_scales.mul(0.625).log()]),       # 1 / 1.6 = 0.625
-        'rotations': torch.cat([rotations[duplicate_mask], split_rotations]),
-    }
-    n_new = extra['means'].shape[0]
-    extend(g, extra)
-    g.densification_info = None                                                            # Model.py:353-355
-
-    prune_mask = torch.cat([split_mask, torch.zeros(n_new, dtype=torch.bool, device=means.device)])
-    prune_mask |= g.opacities.detach().flatten() < math.log(min_opacity / (1 - min_opacity))
-    prune_mask |= g.rotations.detach().square().sum(dim=1) < 1e-8
-    if prune_large_gaussians:
-        prune_mask |= g.scales.detach().max(dim=1).values > math.log(0.1 * extent)
-    prune(g, prune_mask)
-    return {'cloned': int(duplicate_mask.sum()), 'split': int(split_mask.sum()), 'pruned': int(prune_mask.sum()), 'total': g.means.shape[0]}
+    raise RuntimeError('adaptive_density_control: the Gaussians live on the CPU and no backend was given -- density control exists as the device '
+                       'passes of csrc/densify.hip only (pass ops_backend=..., or move the model to the ROCm device)')
 
 
-def run_callbacks(g: Gaussians, iteration: int, schedule: dict = GARDEN_SCHEDULE, generator: torch.Generator | None = None) -> dict | None:
+def run_callbacks(g: Gaussians, iteration: int, schedule: dict = GARDEN_SCHEDULE, generator: torch.Generator | None = None, ops_backend=None) -> dict | None:
     """The per-iteration schedule of Trainer.py:114-165 in priority order (SH degree 110, densify 100, Morton 99, opacity
     reset 90); call BEFORE training_iteration(iteration) like the reference's callback dispatcher does."""
     s, out = schedule, None
     if iteration >= s['sh_interval'] and iteration % s['sh_interval'] == 0:
         g.increase_used_sh_degree()
     if s['densification_start'] <= iteration <= s['densification_end'] and (iteration - s['densification_start']) % s['densification_interval'] == 0:
-        out = adaptive_density_control(g, s['grad_threshold'], 0.005, iteration > s['opacity_reset_interval'], s['percent_dense'], generator)
+        out = adaptive_density_control(g, s['grad_threshold'], 0.005, iteration > s['opacity_reset_interval'], s['percent_dense'], generator, ops_backend)
         if iteration < s['densification_end']:
             reset_densification_info(g)
     if iteration <= s['morton_end'] and iteration % s['morton_interval'] == 0:
-        apply_morton_ordering(g)
+        apply_morton_ordering(g, ops_backend)
     if s['opacity_reset_interval'] <= iteration <= s['densification_end'] and iteration % s['opacity_reset_interval'] == 0:
         reset_opacities(g)
     return out
@@ -258,55 +220,75 @@ def reset_state(g: Gaussians, indices: torch.Tensor) -> None:
             st['exp_avg_sq'][indices] = 0.0
 
 
+def _dead_mask(g: Gaussians, min_opacity: float) -> torch.Tensor:
+    """Gaussians the MCMC policy recycles: opacity at or below the threshold, or a quaternion that no longer encodes a rotation."""
+    logit_floor = math.log(min_opacity / (1.0 - min_opacity))
+    return (g.opacities.detach().flatten() <= logit_floor) | (g.rotations.detach().square().sum(dim=1) < 1e-8)
+
+
+def _draw_by_opacity(g: Gaussians, candidates: torch.Tensor | None, how_many: int, generator) -> torch.Tensor:
+    """`how_many` indices drawn with replacement, with probability proportional to the activated opacity (over `candidates` or over everything).
+    The draw happens on the host so that a seeded CPU generator reproduces a run on any device."""
+    weight = torch.sigmoid(g.opacities.detach()).flatten()
+    if candidates is not None:
+        weight = weight[candidates]
+    picks = torch.multinomial(weight.cpu(), how_many, replacement=True, generator=generator).to(g.means.device)
+    return picks if candidates is None else candidates[picks]
+
+
 @torch.no_grad()
-def _relocated(g: Gaussians, sampled: torch.Tensor, min_opacity: float, relocation_adjustment):
-    """Model.py:382-391 / 424-433: opacity and scale shared between a sampled Gaussian and its copies (3DGS-MCMC Eq. 9)."""
-    opacities = torch.sigmoid(g.opacities.detach()).flatten()
-    _, inverse, counts_per_unique = sampled.unique(sorted=False, return_inverse=True, return_counts=True)
-    counts = counts_per_unique[inverse] + 1                                   # +1 for the original Gaussian
-    new_op, new_sc = relocation_adjustment(opacities[sampled][:, None].contiguous(), g.scales.detach()[sampled].exp().contiguous(), counts)
-    new_op = new_op.clamp(min_opacity, 1.0 - torch.finfo(torch.float32).eps).logit()
-    return new_op.reshape(-1, 1), new_sc.log()
+def _split_mass(g: Gaussians, sources: torch.Tensor, min_opacity: float, relocation_adjustment):
+    """3DGS-MCMC Eq. 9 through the backend's kernel: a source drawn c times ends up as c + 1 Gaussians at the same place, and each of them gets
+    the opacity / scale that keeps the rendered result (Model.py:382-391 / 424-433 semantics). Returns (opacity logits [k, 1], log scales [k, 3])
+    for the `sources` list, the same value for every occurrence of a source."""
+    multiplicity = torch.bincount(sources, minlength=g.means.shape[0])[sources] + 1
+    activated = torch.sigmoid(g.opacities.detach()).flatten()[sources].reshape(-1, 1).contiguous()
+    extents = g.scales.detach()[sources].exp().contiguous()
+    shared_opacity, shared_extent = relocation_adjustment(activated, extents, multiplicity)
+    ceiling = 1.0 - torch.finfo(torch.float32).eps
+    return shared_opacity.clamp(min_opacity, ceiling).logit().reshape(-1, 1), shared_extent.log()
+
+
+def _forget_moments_and_statistics(g: Gaussians, rows: torch.Tensor) -> None:
+    reset_state(g, rows)
+    g.densification_info = None
 
 
 @torch.no_grad()
 def mcmc_densification(g: Gaussians, min_opacity: float, cap_max: int, generator: torch.Generator | None = None, ops=None) -> dict:
-    """Model.py:367-457: dead Gaussians are relocated onto live ones sampled by opacity, then the set grows by 5 % up to cap_max."""
+    """The MCMC policy's densification step (Model.py:367-457 semantics): (1) every dead Gaussian is moved onto a live one drawn by opacity, source
+    and copies sharing opacity and scale; (2) the set then grows by 5 % (up to `cap_max`) with copies of Gaussians drawn the same way. Sources lose
+    their Adam moments, copies start without any."""
     relocation_adjustment, _ = ops or _default_ops()
-    stats = {'relocated': 0, 'added': 0}
-    dead = g.opacities.detach().flatten() <= math.log(min_opacity / (1.0 - min_opacity))
-    dead |= g.rotations.detach().square().sum(dim=1) < 1e-8
-    n_dead = int(dead.sum())
-    if n_dead > 0:
-        dead_idx, alive_idx = torch.where(dead)[0], torch.where(~dead)[0]
-        prob = torch.sigmoid(g.opacities.detach()).flatten()[alive_idx]
-        sampled = alive_idx[torch.multinomial(prob.cpu(), n_dead, replacement=True, generator=generator).to(alive_idx.device)]
-        new_op, new_sc = _relocated(g, sampled, min_opacity, relocation_adjustment)
-        g.opacities.data[sampled] = new_op
-        g.scales.data[sampled] = new_sc
-        for k in ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'rotations'):
-            getattr(g, k).data[dead_idx] = getattr(g, k).data[sampled]
-        g.opacities.data[dead_idx] = new_op
-        g.scales.data[dead_idx] = new_sc
-        reset_state(g, sampled)
-        g.densification_info = None
-        stats['relocated'] = n_dead
-    n = g.means.shape[0]
-    n_add = max(0, min(cap_max, int(1.05 * n)) - n)
-    if n_add > 0:
-        prob = torch.sigmoid(g.opacities.detach()).flatten()
-        sampled = torch.multinomial(prob.cpu(), n_add, replacement=True, generator=generator).to(g.means.device)
-        new_op, new_sc = _relocated(g, sampled, min_opacity, relocation_adjustment)
-        g.opacities.data[sampled] = new_op
-        g.scales.data[sampled] = new_sc
-        extend(g, {'means': g.means.detach()[sampled], 'sh_coefficients_0': g.sh_coefficients_0.detach()[sampled],
-                   'sh_coefficients_rest': g.sh_coefficients_rest.detach()[sampled], 'opacities': new_op, 'scales': new_sc,
-                   'rotations': g.rotations.detach()[sampled]})
-        reset_state(g, sampled)
-        g.densification_info = None
-        stats['added'] = n_add
-    stats['total'] = g.means.shape[0]
-    return stats
+    report = {'relocated': 0, 'added': 0}
+    untouched = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'rotations')          # what a copy inherits as it is
+    dead = _dead_mask(g, min_opacity)
+    graves = dead.nonzero().flatten()
+    if graves.numel() > 0:
+        sources = _draw_by_opacity(g, (~dead).nonzero().flatten(), graves.numel(), generator)
+        logit, log_scale = _split_mass(g, sources, min_opacity, relocation_adjustment)
+        for rows in (sources, graves):
+            g.opacities.data[rows] = logit
+            g.scales.data[rows] = log_scale
+        for name in untouched:
+            tensor = getattr(g, name).data
+            tensor[graves] = tensor[sources]
+        _forget_moments_and_statistics(g, sources)
+        report['relocated'] = int(graves.numel())
+    current = g.means.shape[0]
+    growth = min(cap_max, int(1.05 * current)) - current
+    if growth > 0:
+        sources = _draw_by_opacity(g, None, growth, generator)
+        logit, log_scale = _split_mass(g, sources, min_opacity, relocation_adjustment)
+        g.opacities.data[sources] = logit
+        g.scales.data[sources] = log_scale
+        newcomers = {name: getattr(g, name).detach()[sources] for name in untouched}
+        newcomers.update(opacities=logit, scales=log_scale)
+        extend(g, newcomers)
+        _forget_moments_and_statistics(g, sources)
+        report['added'] = growth
+    report['total'] = g.means.shape[0]
+    return report
 
 
 @torch.no_grad()
@@ -328,7 +310,7 @@ def post_optimizer_step(g: Gaussians, inject_noise: bool, lr_means: float, ops=N
 
 
 # ---- a whole (possibly time-compressed) training run from a random initialisation: Trainer.py:86-201 end to end ---------------------------------
-def run_mcmc_callbacks(g: Gaussians, iteration: int, schedule: dict, cap_max: int, generator: torch.Generator | None = None, ops=None) -> dict | None:
+def run_mcmc_callbacks(g: Gaussians, iteration: int, schedule: dict, cap_max: int, generator: torch.Generator | None = None, ops=None, ops_backend=None) -> dict | None:
     """The callbacks of Trainer.py:114-165 under USE_MCMC: SH degree, `mcmc_densification` in the densification window, Morton order; no
     opacity reset (Trainer.py:154-165 skip it) and no densification statistics."""
     s, out = schedule, None
@@ -337,7 +319,7 @@ def run_mcmc_callbacks(g: Gaussians, iteration: int, schedule: dict, cap_max: in
     if s['densification_start'] <= iteration <= s['densification_end'] and (iteration - s['densification_start']) % s['densification_interval'] == 0:
         out = mcmc_densification(g, 0.005, cap_max, generator, ops)
     if iteration <= s['morton_end'] and iteration % s['morton_interval'] == 0:
-        apply_morton_ordering(g)
+        apply_morton_ordering(g, ops_backend)
     return out
 
 

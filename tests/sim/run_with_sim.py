@@ -18,6 +18,8 @@ from FasterGSCudaBackend import _backend, aux_ops, rasterization
 _backend._DEFAULT = helpers.sim_backend()
 rasterization._require_gpu = lambda t: None
 aux_ops._gpu = lambda t: None
+from harness import densify as _densify
+_densify._device_backend = lambda g, ops_backend=None: ops_backend or _backend._DEFAULT      # density control has no torch-op formulation: CPU tensors go to the simulation
 for name in ('synchronize', 'reset_peak_memory_stats', 'empty_cache'):
     setattr(torch.cuda, name, lambda *a, **k: None)
 for name in ('max_memory_allocated', 'max_memory_reserved'):

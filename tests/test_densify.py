@@ -24,7 +24,7 @@ def _gaussians(n=200):
     return g
 
 
-def test_adaptive_density_control_clone_split_prune():
+def test_adaptive_density_control_clone_split_prune(sim_backend):
     g = _gaussians()
     n = g.means.shape[0]
     info = torch.zeros(2, n)
@@ -37,7 +37,7 @@ def test_adaptive_density_control_clone_split_prune():
         g.opacities[100:105] = -10.0      # nearly transparent: pruned
         g.rotations[110] = 0.0            # degenerate quaternion: pruned
     before = {k: getattr(g, k).detach().clone() for k in PARAM_ORDER}
-    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0))
+    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0), ops_backend=sim_backend)
     assert stats['cloned'] == 20 and stats['split'] == 10
     assert g.means.shape[0] == n + 20 + 2 * 10 - 10 - 5 - 1 == stats['total']
     # clones are exact copies; split children are shrunk by 1/1.6 and displaced
@@ -77,7 +77,7 @@ def test_callback_schedule_matches_trainer():
     g.active_sh_degree = 0
     orig = (D.adaptive_density_control, D.apply_morton_ordering, D.reset_opacities)
     D.adaptive_density_control = lambda *a, **k: fired['densify'].append(cur) or {'total': 0}
-    D.apply_morton_ordering = lambda g_: fired['morton'].append(cur)
+    D.apply_morton_ordering = lambda g_, *a: fired['morton'].append(cur)
     D.reset_opacities = lambda g_: fired['reset'].append(cur)
     try:
         for cur in range(0, 16_001, 100):
@@ -274,6 +274,11 @@ def test_device_adaptive_density_control_matches_model_py(sim_backend, oracle, p
     check_adc_against_restatement(sim_backend, oracle, 'cpu', prune_large=prune_large, with_state=with_state)
 
 
+def test_device_adaptive_density_control_across_scan_blocks(sim_backend, oracle):
+    """The 4-way exclusive scan of csrc/densify.hip works in 4096-Gaussian workgroup blocks: two whole blocks and a ragged third."""
+    check_adc_against_restatement(sim_backend, oracle, 'cpu', n=2 * 4096 + 37)
+
+
 def test_device_gather_and_morton_order(sim_backend, oracle):
     P, M, V, _ = _adc_case(n=500)
     order = sim_backend.morton_order(P['means'])
@@ -285,8 +290,9 @@ def test_device_gather_and_morton_order(sim_backend, oracle):
         assert torch.equal(o, t[idx])
 
 
-def test_harness_densify_uses_the_device_passes(sim_backend):
-    """harness.densify with a backend: same Gaussians as the torch-op formulation of Model.py:312-366, moments carried along."""
+def test_harness_densify_uses_the_device_passes(sim_backend, oracle):
+    """harness.densify on top of the device passes: the Gaussians and moments the numpy restatement of Model.py:312-366 (oracle/oracle.py) gives,
+    step counts kept; the gather launch behind prune / Morton order equals plain indexing. Without a backend there is nothing to fall back to."""
     params, _ = make_s0(seed=2, n=300)
     info = torch.zeros(2, 300); info[0] = 10.0; info[1, :60] = 10.0 * 1e-3
     make = lambda: T.Gaussians({k: v.clone() for k, v in params.items()}, 'cpu')
@@ -297,17 +303,28 @@ def test_harness_densify_uses_the_device_passes(sim_backend):
             p = group['params'][0]
             g.optimizer.state[p] = {'step': 3, 'exp_avg': torch.full_like(p, 0.5), 'exp_avg_sq': torch.full_like(p, 0.25)}
         g.densification_info = info.clone()
-    sa = D.adaptive_density_control(ga, 2e-4, 0.005, True, generator=torch.Generator().manual_seed(5))
+    with pytest.raises(RuntimeError, match='no backend'):
+        D.adaptive_density_control(ga, 2e-4, 0.005, True, generator=torch.Generator().manual_seed(5))
+    before = {k: getattr(gb, k).detach().numpy().copy() for k in ORDER}
+    moments = {k: np.full(before[k].shape, 0.5, np.float32) for k in ORDER}, {k: np.full(before[k].shape, 0.25, np.float32) for k in ORDER}
     sb = D.adaptive_density_control(gb, 2e-4, 0.005, True, generator=torch.Generator().manual_seed(5), ops_backend=sim_backend)
-    assert sa['total'] == sb['total'] and sa['split'] == sb['split'] and gb.densification_info is None
+    noise = torch.randn((2 * sb['split'], 3), generator=torch.Generator().manual_seed(5)).numpy()
+    ref_p, ref_m, ref_v, ref_counts = oracle.adaptive_density_control(before, moments[0], moments[1], info.numpy(), noise, 2e-4, 0.005, True, 0.01, 5.0)
+    assert (sb['kept'], sb['cloned'], sb['children_per_copy'], sb['split']) == tuple(ref_counts) and sb['total'] == ref_p['means'].shape[0] and gb.densification_info is None
     for k in ORDER:
-        assert torch.allclose(getattr(ga, k), getattr(gb, k), rtol=0, atol=2e-6), k
-        sta, stb = ga.optimizer.state[getattr(ga, k)], gb.optimizer.state[getattr(gb, k)]
-        assert torch.equal(sta['exp_avg'], stb['exp_avg']) and torch.equal(sta['exp_avg_sq'], stb['exp_avg_sq']) and stb['step'] == 3
-    # re-ordering and pruning start from bit-identical sets (the split children above differ in the last bit between libms)
+        assert np.allclose(getattr(gb, k).detach().numpy(), ref_p[k], rtol=0, atol=2e-6), k
+        stb = gb.optimizer.state[getattr(gb, k)]
+        assert np.array_equal(stb['exp_avg'].numpy(), ref_m[k]) and np.array_equal(stb['exp_avg_sq'].numpy(), ref_v[k]) and stb['step'] == 3
+    # re-ordering and pruning: the gather launch against plain indexing, from bit-identical sets
+    ga = make()
+    ga.training_setup(training_cameras_extent=5.0)
+    ga.densification_info = None
     with torch.no_grad():
         for k in ORDER:
-            getattr(ga, k).copy_(getattr(gb, k))
+            getattr(ga, k).data = getattr(gb, k).detach().clone()
+    for group in ga.optimizer.param_groups:
+        p = group['params'][0]
+        ga.optimizer.state[p] = {key: (val.clone() if torch.is_tensor(val) else val) for key, val in gb.optimizer.state[getattr(gb, group['name'])].items()}
     D.apply_morton_ordering(ga)
     D.apply_morton_ordering(gb, ops_backend=sim_backend)
     assert torch.equal(ga.means, gb.means) and torch.equal(ga.optimizer.state[ga.means]['exp_avg'], gb.optimizer.state[gb.means]['exp_avg'])
@@ -321,7 +338,7 @@ def test_partial_optimizer_state_keeps_moments_row_aligned(sim_backend, device_p
     """Round-2 advisor finding: with optimizer state on only SOME groups (a group that never received a gradient, a checkpoint saved
     without one group's moments) the device passes used to rebind every group without moments, leaving the groups that had state with
     moments of the OLD row count -- the next Adam step would read past them. Now the missing groups get the state Adam creates lazily
-    (zero moments) and every group goes through the same gather / scatter; the torch-op path leaves stateless groups stateless."""
+    (zero moments) and every group goes through the same gather / scatter; the plain-indexing prune for CPU tensors leaves stateless groups stateless."""
     g = _gaussians(150)
     n = g.means.shape[0]
     opt = g.optimizer
@@ -336,7 +353,7 @@ def test_partial_optimizer_state_keeps_moments_row_aligned(sim_backend, device_p
         g.scales[:20] = math.log(0.01)
         g.opacities[50:60] = -10.0
     be = sim_backend if device_passes else None
-    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0), ops_backend=be)
+    stats = D.adaptive_density_control(g, 2e-4, 0.005, False, generator=torch.Generator().manual_seed(0), ops_backend=sim_backend)
     assert g.means.shape[0] == stats['total'] == n + 20 - 10
     D.prune(g, torch.arange(g.means.shape[0]) % 3 == 0, ops_backend=be)
     for grp in g.optimizer.param_groups:

@@ -53,7 +53,7 @@ def _compare(name, got, want):
             assert np.array_equal(a == np.finfo(np.float32).max, b == np.finfo(np.float32).max), key
             a, b = np.where(b == np.finfo(np.float32).max, 0.0, a), np.where(b == np.finfo(np.float32).max, 0.0, b)
         assert helpers.rel_inf(a, b) < TOL, (key, helpers.rel_inf(a, b))
-    assert max(masked_share.values()) < 0.35, masked_share
+    assert max(masked_share.values()) < 0.05, masked_share          # realised on the MI355X: 0.5 - 0.7 %
     helpers.log_note('ref_glue_masked_share', round(max(masked_share.values()), 5), scene=name)
 
 

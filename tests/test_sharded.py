@@ -322,7 +322,7 @@ def test_owner_side_densification_between_steps():
         assert float(g.densification_info[0].max()) >= 1.0                     # the owner saw the statistics of both views
         n0 = g.means.shape[0]
         kept_moment = g.optimizer.state[g.means]['exp_avg'].clone()
-        stats = D.adaptive_density_control(g, 1e-7, 0.005, False, generator=torch.Generator().manual_seed(3))
+        stats = D.adaptive_density_control(g, 1e-7, 0.005, False, generator=torch.Generator().manual_seed(3), ops_backend=helpers.sim_backend())
         assert stats['cloned'] + stats['split'] > 0
         D.reset_densification_info(g)
         t.rebuild_from(g)

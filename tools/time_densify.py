@@ -21,21 +21,16 @@ def fresh():
     return g
 
 
-class NoBackend:      # forces the torch-op path on device tensors
-    pass
-
-
-for label, kernel in (('device passes', True), ('torch ops', False)):
-    times = {}
-    for rep in range(3):
-        g = fresh(); torch.cuda.synchronize()
-        if not kernel:
-            D._device_backend = lambda g_, ops_backend=None: None
-        t0 = time.perf_counter(); stats = D.adaptive_density_control(g, 2e-4, 0.005, True); torch.cuda.synchronize(); t1 = time.perf_counter()
-        D.reset_densification_info(g)
-        D.apply_morton_ordering(g); torch.cuda.synchronize(); t2 = time.perf_counter()
-        mask = torch.rand(g.means.shape[0], device=dev) < 0.2; torch.cuda.synchronize(); t3 = time.perf_counter()
-        D.prune(g, mask); torch.cuda.synchronize(); t4 = time.perf_counter()
-        times.setdefault('adc', []).append(t1 - t0); times.setdefault('morton', []).append(t2 - t1); times.setdefault('prune', []).append(t4 - t3)
-        del g
-    print(f'{label:14s} N={n}: adaptive_density_control {min(times["adc"]) * 1e3:8.2f} ms   morton re-order {min(times["morton"]) * 1e3:8.2f} ms   prune 20% {min(times["prune"]) * 1e3:8.2f} ms   ({stats})')
+# Device passes only: the torch-op formulation this tool used to time beside them (10 ms / 250-370 ms / - at 3 M Gaussians on the same GPU,
+# profiles/archive/r02_time_densify.txt) left the product in round 6.
+times = {}
+for rep in range(3):
+    g = fresh(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); stats = D.adaptive_density_control(g, 2e-4, 0.005, True); torch.cuda.synchronize(); t1 = time.perf_counter()
+    D.reset_densification_info(g)
+    D.apply_morton_ordering(g); torch.cuda.synchronize(); t2 = time.perf_counter()
+    mask = torch.rand(g.means.shape[0], device=dev) < 0.2; torch.cuda.synchronize(); t3 = time.perf_counter()
+    D.prune(g, mask); torch.cuda.synchronize(); t4 = time.perf_counter()
+    times.setdefault('adc', []).append(t1 - t0); times.setdefault('morton', []).append(t2 - t1); times.setdefault('prune', []).append(t4 - t3)
+    del g
+print(f'device passes N={n}: adaptive_density_control {min(times["adc"]) * 1e3:8.2f} ms   morton re-order {min(times["morton"]) * 1e3:8.2f} ms   prune 20% {min(times["prune"]) * 1e3:8.2f} ms   ({stats})')
