@@ -282,6 +282,9 @@ def main():
     # this size (measured: 2.66 ms vs 2.70 ms per iteration for the synchronisation-free form, whose launches are sized by bounds).
     FGS.set_async_forward(args.async_forward)
     if 'FGS_BACKWARD_VARIANT' in os.environ:      # A/B of the blend-backward formulation: needs the dev library (FGS_HIP_LIBRARY=.../libfgs_hip_dev.so)
+        if not hasattr(be.lib, 'fgs_debug_set_backward_variant'):
+            sys.exit('FGS_BACKWARD_VARIANT needs the dev library (the product has one formulation of every kernel): '
+                     'FGS_HIP_LIBRARY=$PWD/faster-gaussian-splatting_amd/libfgs_hip_dev.so python bench.py ...')
         be.lib.fgs_debug_set_backward_variant(int(os.environ['FGS_BACKWARD_VARIANT']))
 
     g = T.Gaussians(params, device)
@@ -461,6 +464,47 @@ def main():
             return (56.0 + 36.0) * vis * (world - 1) / world
         return 2.0 * (world - 1) / world * 236.0 * n
 
+    # N > 1, first contact with the fabric made falsifiable: ONE dry exchange of each kind at the step's real sizes, nothing rendered -- the all-reduce
+    # of the 236-B/Gaussian gradient arena (north star's exchange) and the two all-to-alls of the sharded step (56-B records out, 36-B accumulators
+    # back, (G-1)/G of the visible Gaussians) -- timed next to the wire time DESIGN.md section 6 predicts from bytes / ((G-1) links x 76.8 GB/s): the
+    # first SCALE record confirms or kills that per-link model in one run. Every rank must also sit on a device of its own.
+    dry = None
+    if dist.is_initialized() and world > 1:
+        ident = 'cpu' if sim else f'{os.uname().nodename}:{torch.cuda.get_device_properties(device).uuid if hasattr(torch.cuda.get_device_properties(device), "uuid") else device.index}'
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if not (sim or shared) and len(set(idents)) != world:
+            raise SystemExit(f'bench.py --gpus {world}: ranks share devices ({idents}); one process per GPU is required')
+        link_gbs = 76.8
+
+        def timed(fn, reps=3):
+            fn(); fence()                                   # warm-up (communicator set-up, first-touch)
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            t_ = torch.tensor([(time.perf_counter() - t0_) / reps], dtype=torch.float64, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item()) * 1e3
+        vis = float(np.mean([s_['V'] for s_ in stats.values()]))
+        arena = torch.zeros(59 * n, dtype=torch.float32, device=device)
+        per_peer = int(vis / world)
+        rec_out, rec_in = torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device), torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device)
+        acc_out, acc_in = torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device), torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device)
+        ms_allreduce = timed(lambda: dist.all_reduce(arena))
+        ms_records = timed(lambda: dist.all_to_all_single(rec_in, rec_out))
+        ms_accs = timed(lambda: dist.all_to_all_single(acc_in, acc_out))
+        predict = lambda nbytes: nbytes / ((world - 1) * link_gbs * 1e9) * 1e3
+        dry = {'what': 'one dry exchange of each kind at the real sizes of this step (no rendering), MAX over ranks of the mean of 3 calls after 1 warm-up call',
+               'devices': idents, 'link_model_GBps_per_direction': link_gbs,
+               'allreduce_gradient_arena': {'bytes': 236.0 * n, 'wire_bytes_per_rank': wire_bytes('allreduce'), 'measured_ms': ms_allreduce, 'predicted_wire_ms': predict(wire_bytes('allreduce'))},
+               'sharded_all_to_all': {'records_bytes_per_rank': 56.0 * per_peer * (world - 1), 'accumulator_bytes_per_rank': 36.0 * per_peer * (world - 1),
+                                      'measured_ms_records': ms_records, 'measured_ms_accumulators': ms_accs,
+                                      'predicted_wire_ms': predict((56.0 + 36.0) * per_peer * (world - 1))},
+               'note': 'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6; gloo / shared-device runs measure host memory, not xGMI' if (sim or shared) else
+                       'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6'}
+        del arena, rec_out, rec_in, acc_out, acc_in
+
     # N > 1: the other exchange as well (north star: all-reduce of the per-Gaussian gradients; default: Gaussian-sharded records)
     other = None
     if vp is not None and world > 1 and not args.no_extras:
@@ -598,6 +642,8 @@ def main():
 
     if other is not None:
         out['other_exchange'] = other
+    if dry is not None:
+        out['dry_exchange'] = dry
     if rank == 0 and not args.no_extras and world == 1 and not sim:
         # BASELINE.json configs[1]: forward render only (the reference's render_image_benchmark path)
         v = my_views[0]

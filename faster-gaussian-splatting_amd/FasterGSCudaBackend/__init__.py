@@ -9,7 +9,7 @@ from ._lib import ExtensionError, library
 library()   # fail loudly at import time if libfgs_hip.so is missing (reference: __init__.py:19-20)
 
 from ._backend import RasterizerSettings  # noqa: E402
-from .rasterization import (async_forward_stats, diff_rasterize, live_block_stats, rasterize, set_async_forward,  # noqa: E402
+from .rasterization import (async_forward_scope, async_forward_stats, diff_rasterize, live_block_stats, rasterize, set_async_forward,  # noqa: E402
                             set_live_block_handover, take_async_overflow, update_pruning_scores)
 from .adam import FusedAdam  # noqa: E402
 from .fused import FusedRasterizerOptimizer  # noqa: E402
@@ -19,4 +19,4 @@ from .aux_ops import add_noise, relocation_adjustment, update_3d_filter  # noqa:
 
 __all__ = ['diff_rasterize', 'rasterize', 'update_pruning_scores', 'RasterizerSettings', 'FusedAdam', 'update_3d_filter',
            'relocation_adjustment', 'add_noise', 'FusedRasterizerOptimizer', 'ExtensionError', 'set_async_forward', 'async_forward_stats',
-           'set_live_block_handover', 'live_block_stats', 'take_async_overflow']
+           'set_live_block_handover', 'live_block_stats', 'take_async_overflow', 'async_forward_scope']

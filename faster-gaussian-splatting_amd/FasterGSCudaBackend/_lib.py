@@ -101,6 +101,7 @@ _DEV_SIGNATURES = {
     'fgs_debug_set_option': (C.c_int32, [_I32, _I32]),
 }
 
+ABI_VERSION = 3                       # FGS_ABI_VERSION of include/fgs_hip.h
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 DEV_LIBRARY = PACKAGE_ROOT / 'libfgs_hip_dev.so'
 
@@ -134,6 +135,6 @@ def library() -> C.CDLL:
             _LIB = bind(path)
         except OSError as exc:          # e.g. libamdhip64.so missing
             raise ExtensionError(f'failed to load {path}: {exc}') from exc
-        if _LIB.fgs_abi_version() != 2:
-            raise ExtensionError(f'{path} has ABI version {_LIB.fgs_abi_version()}, expected 2')
+        if _LIB.fgs_abi_version() != ABI_VERSION:
+            raise ExtensionError(f'{path} has ABI version {_LIB.fgs_abi_version()}, expected {ABI_VERSION}')
     return _LIB

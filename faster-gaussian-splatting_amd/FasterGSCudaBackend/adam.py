@@ -58,11 +58,12 @@ class FusedAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self) -> None:
-        if take_async_overflow([p for group in self.param_groups for p in group['params']]):
+        owned = [p for group in self.param_groups for p in group['params']]
+        if take_async_overflow(owned):
             # the rasterizer's backward pass returned zeros because its (asynchronously sized) forward pass was truncated: stepping on them would
             # decay the moments, advance the step counts and move every parameter on momentum for a loss that was never evaluated. The mark names
             # the parameters of that pass: only the optimizer that owns them skips (and consumes the mark), any other FusedAdam steps normally
-            clear_live_blocks()
+            clear_live_blocks(owned)
             return
         launches: dict[tuple, list[_Update]] = {}
         for key, update in self._pending():
@@ -73,8 +74,8 @@ class FusedAdam(torch.optim.Adam):
                 chunk = updates[first:first + _GROUPS_PER_LAUNCH]
                 # gradients that are still exactly what the rasterizer's backward pass wrote come with its per-block "any visible" flags: the
                 # zeros of dead blocks are not read back (rasterization.match_live_blocks; bit-identical result, ~4 % less optimizer traffic)
-                live = match_live_blocks([u.grad for u in chunk]) if len(updates) <= _GROUPS_PER_LAUNCH else None
+                live = match_live_blocks([u.grad for u in chunk], owned) if len(updates) <= _GROUPS_PER_LAUNCH else None
                 backend.adam_step_multi([u.grad for u in chunk], [u.param for u in chunk], [u.exp_avg for u in chunk],
                                         [u.exp_avg_sq for u in chunk], [u.step for u in chunk], [u.lr for u in chunk], beta1, beta2, eps,
                                         live_blocks=live)
-        clear_live_blocks()
+        clear_live_blocks(owned)

@@ -38,8 +38,39 @@ def set_gradient_buffers(provider) -> None:
 # `FusedAdam.step` consumes that mark and skips the step -- no moment decay, no step count, no parameter motion on momentum (any other optimizer
 # can ask `take_async_overflow()`). A pass that asked for gradients but whose backward never runs (an evaluation loop without no_grad) is checked
 # lazily by the next forward pass, which warns if that image was truncated.
-_ASYNC = {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0, 'per_view': {}, 'pending': {}, 'step_invalid': False, 'ticket': 0}
+# Scopes: the per-view table records instances PER GAUSSIAN, a property of the model as much as of the view. A process that trains two models over
+# the same view tensors gives each its own table with `async_forward_scope(name)` (a context manager around that model's iterations); everything
+# outside such a block uses the default scope. Switches (`set_async_forward`) and counters are per scope as well.
+def _new_async_table() -> dict:
+    return {'enabled': False, 'headroom': 1.25, 'ratio': 0.0, 'overflows': 0, 'per_view': {}, 'pending': {}, 'step_invalid': False, 'ticket': 0}
+
+
+_ASYNC_SCOPES = {None: _new_async_table()}
+_ASYNC = _ASYNC_SCOPES[None]          # the ACTIVE scope's table (rebound by async_forward_scope)
 _ASYNC_MAX_VIEWS = 1024
+
+
+class async_forward_scope:
+    """`with async_forward_scope('model_b'): ...` -- the asynchronous-forward bookkeeping (switch, per-view ratios, pending checks, overflow mark) of
+    the block is kept apart from every other scope's. Scopes persist across blocks of the same name; `async_forward_scope.drop(name)` forgets one."""
+
+    def __init__(self, name):
+        self.name, self._outer = name, None
+
+    def __enter__(self):
+        global _ASYNC
+        self._outer = _ASYNC
+        _ASYNC = _ASYNC_SCOPES.setdefault(self.name, _new_async_table())
+        return self
+
+    def __exit__(self, *exc):
+        global _ASYNC
+        _ASYNC = self._outer
+
+    @staticmethod
+    def drop(name) -> None:
+        if name is not None:
+            _ASYNC_SCOPES.pop(name, None)
 
 # ---- live-block hand-over from this backward pass to FusedAdam.step ------------------------------------------------------------------
 # One third of the Gaussians is invisible in a view; their gradients are zeros that the backward pass writes (the gradient tensors are dense and
@@ -52,7 +83,10 @@ _ASYNC_MAX_VIEWS = 1024
 # in-place edit -- accumulation of a second backward, clipping, scaling -- shows). Anything else takes the ordinary path; results are
 # bit-identical either way. Writes the version counter does not see (`.grad.data.add_(...)`, raw pointers) are the kernel's business: it reads
 # one sentinel float per dead block and tensor and, unless that is +-0, the block's gradients after all (csrc/preprocess_backward.hip).
-_LIVE = {'enabled': True, 'arena': None, 'version': -1, 'flags': None, 'views': (), 'matched': 0, 'missed': 0}
+# The registry holds ONE registration per model, keyed by the address of the `means` tensor of the pass (two models in one process do not evict
+# each other's registration; a model's next backward pass replaces its own). An optimizer names the parameters it owns when it asks.
+_LIVE = {'enabled': True, 'slots': {}, 'matched': 0, 'missed': 0}
+_LIVE_MAX_SLOTS = 8
 _ALIGN_FLOATS = 64          # every gradient starts on a 256-byte boundary (16-byte loads in the optimizer kernel)
 
 
@@ -65,8 +99,13 @@ def live_block_stats() -> dict:
     return {'matched': _LIVE['matched'], 'missed': _LIVE['missed']}
 
 
-def clear_live_blocks() -> None:
-    _LIVE.update(arena=None, version=-1, flags=None, views=())
+def clear_live_blocks(owned=None) -> None:
+    """Forgets the registrations of the passes over the given parameter tensors (an optimizer's own), or all of them."""
+    if owned is None:
+        _LIVE['slots'].clear()
+        return
+    for t in owned:
+        _LIVE['slots'].pop(t.data_ptr(), None)
 
 
 def _gradient_arena(shapes, device):
@@ -87,13 +126,18 @@ def _gradient_arena(shapes, device):
     return arena, tuple(views)
 
 
-def match_live_blocks(gradients) -> 'torch.Tensor | None':
-    """The flags of the registered backward pass if `gradients` (the tensors an optimizer is about to consume, one per parameter group) are
-    exactly the tensors it wrote -- same addresses, shapes, untouched since -- else None. The registration is consumed either way."""
-    arena, flags, views, version = _LIVE['arena'], _LIVE['flags'], _LIVE['views'], _LIVE['version']
-    clear_live_blocks()
-    if arena is None or flags is None or len(gradients) == 0:
+def match_live_blocks(gradients, owned=None) -> 'torch.Tensor | None':
+    """The flags of a registered backward pass if `gradients` (the tensors an optimizer is about to consume, one per parameter group) are
+    exactly the tensors it wrote -- same addresses, shapes, untouched since -- else None. `owned`: the optimizer's parameter tensors; only the
+    registration of a pass over one of them is looked at (and consumed either way). Without it every registration is a candidate."""
+    slots = _LIVE['slots']
+    keys = list(slots) if owned is None else [t.data_ptr() for t in owned if t.data_ptr() in slots]
+    if not keys or len(gradients) == 0:
         return None
+    first = gradients[0].data_ptr()
+    key = next((k for k in keys if any(address == first for address, _ in slots[k]['views'])), keys[0])
+    slot = slots.pop(key)
+    arena, flags, views, version = slot['arena'], slot['flags'], slot['views'], slot['version']
     by_address = {address: shape for address, shape in views if address != 0}
     seen = set()
     for g in gradients:
@@ -125,13 +169,23 @@ def take_async_overflow(owned=None) -> bool:
     `owned` (an iterable of tensors) only an optimizer that owns one of them takes it -- a second FusedAdam over other parameters neither
     consumes the mark nor skips its own step; without arguments any pending mark is taken. The next forward pass over the same parameters
     drops a mark nobody took (no optimizer step followed: another optimizer, an exception), so it cannot skip a later, valid step."""
-    marked = _ASYNC['step_invalid']
-    if not marked:
-        return False
-    if owned is not None and not any(t.data_ptr() in marked for t in owned):
-        return False
-    _ASYNC['step_invalid'] = False
-    return True
+    if owned is None:
+        marked, _ASYNC['step_invalid'] = _ASYNC['step_invalid'], False
+        return bool(marked)
+    mine = {a for t in owned for a in _addresses(t)}
+    for table in _ASYNC_SCOPES.values():          # the optimizer may step outside the scope block its passes ran in
+        if table['step_invalid'] and not mine.isdisjoint(table['step_invalid']):
+            table['step_invalid'] = False
+            return True
+    return False
+
+
+def _addresses(t: torch.Tensor) -> tuple:
+    """What identifies `t` in an overflow mark: its own address and the address of its storage -- a `.contiguous()` copy is neither, but a view, a
+    slice or a reshaped alias of a marked parameter (or a parameter that is a view into a marked arena) still is."""
+    if t.numel() == 0:
+        return ()
+    return (t.data_ptr(), t.untyped_storage().data_ptr())
 
 
 def _tensor_version(t: torch.Tensor) -> int:
@@ -148,32 +202,32 @@ def _view_key(settings: RasterizerSettings):
             float(settings.center_x), float(settings.center_y))
 
 
-def _view_ratio(key, w2c: torch.Tensor) -> float:
+def _view_ratio(A: dict, key, w2c: torch.Tensor) -> float:
     """The recorded instances-per-Gaussian ratio of this view, or 0.0 if `w2c` is not the very tensor (object and content version) it was recorded for."""
-    entry = _ASYNC['per_view'].get(key)
+    entry = A['per_view'].get(key)
     if entry is None:
         return 0.0
     ratio, ref, version = entry
     if ref() is not w2c or version is None or _tensor_version(w2c) != version:
-        del _ASYNC['per_view'][key]
+        del A['per_view'][key]
         return 0.0
-    _ASYNC['per_view'][key] = _ASYNC['per_view'].pop(key)          # most recently used last
+    A['per_view'][key] = A['per_view'].pop(key)          # most recently used last
     return ratio
 
 
-def _record_ratio(key, w2c: torch.Tensor, ratio: float) -> None:
+def _record_ratio(A: dict, key, w2c: torch.Tensor, ratio: float) -> None:
     import weakref
-    table = _ASYNC['per_view']
+    table = A['per_view']
     table.pop(key, None)
     table[key] = (ratio, weakref.ref(w2c), _tensor_version(w2c))
     while len(table) > _ASYNC_MAX_VIEWS:
         del table[next(iter(table))]
-    _ASYNC['ratio'] = max(_ASYNC['ratio'], ratio)
+    A['ratio'] = max(A['ratio'], ratio)
 
 
-def _check_abandoned_passes() -> None:
+def _check_abandoned_passes(A: dict) -> None:
     """Asynchronous passes whose backward never ran: look at their counts now (their copies completed long ago) and say so if an image was truncated."""
-    pending = _ASYNC['pending']
+    pending = A['pending']
     for ticket in list(pending):
         host, event, capacity = pending[ticket]
         if event is not None and not event.query():
@@ -181,7 +235,7 @@ def _check_abandoned_passes() -> None:
         del pending[ticket]
         if int(host[2]) != 0:
             import warnings
-            _ASYNC['overflows'] += 1
+            A['overflows'] += 1
             warnings.warn(f'FasterGS async forward: an earlier pass whose backward never ran needed {int(host[1])} instances but had capacity {capacity}: '
                           f'the image it returned was incomplete (render evaluation views under torch.no_grad(): those passes are sized synchronously)',
                           RuntimeWarning)
@@ -202,30 +256,34 @@ class _Rasterize(torch.autograd.Function):
     def forward(ctx: Any, means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, densification_info,
                 rasterizer_settings: RasterizerSettings) -> torch.Tensor:
         _require_gpu(means)
-        be, n = default_backend(), means.shape[0]
+        be, n, A = default_backend(), means.shape[0], _ASYNC          # the active scope's table; backward uses the same one
         capacity, key = None, None
-        if _ASYNC['step_invalid'] and means.data_ptr() in _ASYNC['step_invalid']:
-            _ASYNC['step_invalid'] = False          # the step of that overflowed pass never came: a stale mark must not skip a later one
-        if _ASYNC['enabled'] and n > 0:
-            if _ASYNC['pending']:
-                _check_abandoned_passes()
+        if A['step_invalid']:
+            # the step of that overflowed pass never came (no optimizer took the mark: another optimizer class, an exception, inputs that were
+            # copies of the optimizer's tensors): a stale mark must not skip a later, valid step -- whatever tensors this pass is over
+            A['step_invalid'] = False
+        if A['enabled'] and n > 0:
+            if A['pending']:
+                _check_abandoned_passes(A)
             key = _view_key(rasterizer_settings)
-            ratio = _view_ratio(key, rasterizer_settings.w2c)
+            ratio = _view_ratio(A, key, rasterizer_settings.w2c)
             # only a pass whose backward will run ever looks at the asynchronous counts; everything else is checked now (synchronously)
             if ratio > 0.0 and any(ctx.needs_input_grad[:6]):
-                capacity = int(ratio * n * _ASYNC['headroom']) + 4096
+                capacity = int(ratio * n * A['headroom']) + 4096
         res = be.forward(means, scales, rotations, opacities, sh_coefficients_0, sh_coefficients_rest, rasterizer_settings, capacity)
         if capacity is None:
             if key is not None:
-                _record_ratio(key, rasterizer_settings.w2c, res.state[1] / n)
+                _record_ratio(A, key, rasterizer_settings.w2c, res.state[1] / n)
             ctx.async_check = None
         else:
             host, event = be.forward_counts(res, n)
-            _ASYNC['ticket'] += 1
-            _ASYNC['pending'][_ASYNC['ticket']] = (host, event, capacity)      # consumed by backward; looked at by a later forward otherwise
-            ctx.async_check = (host, event, key, _ASYNC['ticket'])
+            A['ticket'] += 1
+            A['pending'][A['ticket']] = (host, event, capacity)      # consumed by backward; looked at by a later forward otherwise
+            ctx.async_check = (host, event, key, A['ticket'])
         ctx.rasterizer_settings = rasterizer_settings
         ctx.buffer_state = res.state
+        ctx.sh0_addresses = _addresses(sh_coefficients_0)
+        ctx.async_table = A
         ctx.save_for_backward(res.image, means, scales, rotations, opacities, sh_coefficients_rest, *res.buffers)
         ctx.densification_info = densification_info
         ctx.mark_non_differentiable(densification_info)
@@ -235,22 +293,22 @@ class _Rasterize(torch.autograd.Function):
     @once_differentiable
     def backward(ctx: Any, grad_image: torch.Tensor):
         image, means, scales, rotations, opacities, sh_rest, *buffers = ctx.saved_tensors
-        state = ctx.buffer_state
+        state, A = ctx.buffer_state, ctx.async_table
         if ctx.async_check is not None:
             host, event, key, ticket = ctx.async_check
-            _ASYNC['pending'].pop(ticket, None)
+            A['pending'].pop(ticket, None)
             if event is not None:
                 event.synchronize()
             n = means.shape[0]
-            _record_ratio(key, ctx.rasterizer_settings.w2c, int(host[1]) / max(n, 1))
+            _record_ratio(A, key, ctx.rasterizer_settings.w2c, int(host[1]) / max(n, 1))
             if int(host[2]) != 0:          # the capacity was too small: the image (and the loss gradient) missed the instances beyond it
                 import warnings
-                _ASYNC['overflows'] += 1
+                A['overflows'] += 1
                 warnings.warn(f'FasterGS async forward: {int(host[1])} instances exceeded the capacity {state[1]} of this pass: its image was '
                               f'incomplete, so this backward pass returns zero gradients and FusedAdam.step skips the step (the view is rendered with the '
                               f'right capacity next time)', RuntimeWarning)
-                clear_live_blocks()
-                _ASYNC['step_invalid'] = frozenset(t.data_ptr() for t in (means, scales, rotations, opacities, sh_rest) if t.numel())
+                clear_live_blocks([means])
+                A['step_invalid'] = frozenset(a for t in (means, scales, rotations, opacities, sh_rest) for a in _addresses(t)) | frozenset(ctx.sh0_addresses)
                 if _GRAD_OUT is not None:          # a consumer that reads the provider's arena directly must not see the previous step's gradients
                     zeros = tuple(_GRAD_OUT())
                     for z in zeros:
@@ -267,10 +325,15 @@ class _Rasterize(torch.autograd.Function):
             flags = torch.empty((n + 63) // 64, dtype=torch.uint8, device=means.device)
             grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
                                                buffers, ctx.rasterizer_settings, state, out=views, live_blocks=flags)
-            _LIVE.update(arena=arena, version=arena._version, flags=flags, views=tuple((v.data_ptr() if v.numel() else 0, tuple(v.shape)) for v in views))
+            slots = _LIVE['slots']
+            slots.pop(means.data_ptr(), None)
+            slots[means.data_ptr()] = {'arena': arena, 'version': arena._version, 'flags': flags,
+                                       'views': tuple((v.data_ptr() if v.numel() else 0, tuple(v.shape)) for v in views)}
+            while len(slots) > _LIVE_MAX_SLOTS:          # models that backpropagate but never step: their arenas are not kept alive for ever
+                del slots[next(iter(slots))]
             del views
         else:
-            clear_live_blocks()
+            clear_live_blocks([means])
             grads = default_backend().backward(ctx.densification_info, grad_image, image, means, scales, rotations, opacities, sh_rest,
                                                buffers, ctx.rasterizer_settings, state,
                                                out=_GRAD_OUT() if _GRAD_OUT is not None else None)

@@ -431,9 +431,12 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
 
 int run_blend_backward(const BackwardPlan& P, const float* grad_image, const float* image, int32_t n_primitives,
                        const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream) {
-    // replaces api:127-134: only the 9-float accumulators (and the hot Gaussians' replicas behind them) are cleared
-    if (n_primitives > 0) FGS_HIP(hipMemsetAsync(P.sc.acc, 0, static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc)), stream));
     BlendBackwardArgs a{};
+    // replaces api:127-134: only the 9-float accumulators (and the hot Gaussians' replicas behind them) are cleared -- by the staging kernel, on the
+    // side of its own work (no memset launch). Both sub-arrays start on 256-byte boundaries and kHotFloats * 4 is a multiple of 16.
+    static_assert(BackwardScratch::kHotFloats % 4 == 0, "the cleared region is a whole number of 16-byte pieces");
+    const size_t clear_bytes = n_primitives > 0 ? static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc)) : 0;
+    a.clear_f4 = static_cast<uint32_t>(clear_bytes / 16);          // n <= 477 M (plan_backward): < 2^32 pieces
     a.ranges = P.tb.ranges; a.bucket_offsets = P.tb.bucket_offsets; a.inst_prims = P.ib.prims[state->selector]; a.rec = P.pb.rec;
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;

@@ -46,6 +46,15 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
         const unsigned base = a.live_offsets[tile];
         for (unsigned k = local; k < nl; k += kTilePixels) a.work_list[base + k] = make_uint2(tile, k);
     }
+    // K11's accumulator records and the hot replicas behind them start at zero (replaces api:127-134). Until round 5 a hipMemsetAsync in front of
+    // this kernel (16 us at 3 M Gaussians: a launch of its own on the critical path of every backward pass); the stores are independent of
+    // everything above, so this latency-bound kernel issues them on the side: every workgroup clears an equal share, 16 bytes per store.
+    if (a.clear_f4 != 0u) {
+        const unsigned per_group = (a.clear_f4 + gridDim.x - 1u) / gridDim.x;
+        const unsigned first = tile * per_group, last = min(first + per_group, a.clear_f4);
+        float4* const z = reinterpret_cast<float4*>(a.acc);
+        for (unsigned k = first + local; k < last; k += kTilePixels) z[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 #ifdef FGS_DEV_SWITCHES   // A/B exhibits (variants 0 / 2 systolic, 1 strip): built into libfgs_hip_dev.so only, see docs/history.md

@@ -127,6 +127,7 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket and their number
     uint32_t* live_offsets;                   // [T] first list slot of each tile (planning pass -> stage_pixels_kernel)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
+    uint32_t clear_f4;                    // 16-byte pieces from `acc` on (records + hot replicas) that the staging pass sets to zero
     int proper_aa;
     int ablate;                           // dev build only: timing experiments (fgs_debug_set_option key 7)
     int variant;                          // K11 formulation, read once per backward pass (blend_backward_variant(); 3 in the product build)

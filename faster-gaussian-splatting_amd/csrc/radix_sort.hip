@@ -141,6 +141,13 @@ __global__ void __launch_bounds__(TH) radix_scatter_kernel(const KeyT* __restric
     constexpr uint32_t kBigPerBlock = 256;              // payload pass only: big footprints found by this workgroup (see the end of the kernel)
     __shared__ uint32_t s_big[kBigPerBlock];
     __shared__ uint32_t s_n_big, s_big_base;
+    // gfx950 only: the 8192-item / 512-thread shape stages ~85 KB per workgroup -- fine in CDNA4's 160 KB of LDS per CU (one workgroup per CU, which
+    // the measured times accept), impossible on a 64 KB target. The Makefile's ARCH is overridable; this is where such a build has to stop.
+    static_assert(sizeof(s_cnt) + sizeof(s_first) + sizeof(s_dst) + sizeof(s_part) + sizeof(s_key) + sizeof(s_val) + sizeof(s_big) + 8 <= 160 * 1024,
+                  "radix_scatter_kernel: workgroup LDS exceeds the 160 KB of a gfx950 CU");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "radix_sort.hip sizes its workgroups for the 160 KB LDS of gfx950 (MI355X); other targets need the 4096-item / 256-thread shape"
+#endif
     if (threadIdx.x == 0) s_n_big = 0u;                 // several workgroup barriers lie between this and the first append
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t d0 = threadIdx.x * DPT;                          // this thread's first digit

@@ -6,7 +6,7 @@ pruned/sorted entries keep theirs, replaced data resets its moments).
 
 Adaptive density control runs as the device passes of csrc/densify.hip (classify -> scan -> one scatter of the 59 parameters and 2 x 59
 moments per Gaussian): every tensor is read once and written once; there is no second, torch-op formulation of it in the product (the
-readable restatement of Model.py:312-366 the tests compare with is oracle/oracle.py, test infrastructure). Prune / sort go through one gather
+readable numpy restatement of Model.py:312-366 that the tests compare with lives with the test infrastructure). Prune / sort go through one gather
 launch for all 18 tensors, the Morton order through key + radix sort; for CPU tensors (host-side tooling, the CPU tests) prune / sort fall back
 to plain indexing. A backend other than the HIP library -- the CPU simulation in the tests -- is injected with `ops_backend`.
 

@@ -70,6 +70,34 @@ class ViewParallelTrainer:
         state_len = total if mode == 'allreduce' else self.chunk
         self.exp_avg = torch.zeros(state_len, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(state_len, dtype=torch.float32, device=device)
+        self.gather_from_copy = False
+        if mode == 'zero1' and self.world > 1 and not self.emulate_reduce_scatter:
+            self._probe_collectives(device)
+
+    def _probe_collectives(self, device) -> None:
+        """zero1 uses `reduce_scatter_tensor` with the output aliasing the input and an in-place `all_gather_into_tensor`. RCCL and the gloo of the
+        installed torch do both; an older gloo may lack the first or mishandle the aliasing of the second (round-5 advisor finding). Tried ONCE here
+        on 4 floats per rank with known answers; every rank takes the same decision (MIN over ranks): all-reduce form of the reduce-scatter, a
+        copied all-gather input."""
+        w, r, expect = self.world, self.rank, float(self.world * (self.world + 1) // 2)
+        ok = torch.ones(2, dtype=torch.float32, device=device)
+        try:
+            buf = torch.full((4 * w,), float(r + 1), dtype=torch.float32, device=device)
+            mine = buf[4 * r:4 * r + 4]
+            dist.reduce_scatter_tensor(mine, buf, group=self.group)
+            ok[0] = float(bool((mine == expect).all()))
+        except (RuntimeError, NotImplementedError, AttributeError):
+            ok[0] = 0.0
+        try:
+            buf = torch.zeros(4 * w, dtype=torch.float32, device=device)
+            buf[4 * r:4 * r + 4] = float(r + 1)
+            dist.all_gather_into_tensor(buf, buf[4 * r:4 * r + 4], group=self.group)
+            ok[1] = float(bool((buf.view(w, 4) == torch.arange(1, w + 1, dtype=torch.float32, device=device)[:, None]).all()))
+        except (RuntimeError, NotImplementedError, AttributeError):
+            ok[1] = 0.0
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        self.emulate_reduce_scatter = not bool(ok[0])
+        self.gather_from_copy = not bool(ok[1])
 
     # ---- the pieces of one step -----------------------------------------------------------------------------------
     def _render_backward(self, settings: RasterizerSettings, grad_fn: Callable[[torch.Tensor], torch.Tensor], update_densification: bool):
@@ -136,7 +164,8 @@ class ViewParallelTrainer:
             lo = self.rank * self.chunk
             self._adam(lo, lo + self.chunk, lo)
             # in place: the input is this rank's slice of the output arena (the in-place form of all-gather; no 1/G-arena copy per step)
-            dist.all_gather_into_tensor(self.param_arena, self.param_arena[lo:lo + self.chunk], group=self.group)
+            mine = self.param_arena[lo:lo + self.chunk]
+            dist.all_gather_into_tensor(self.param_arena, mine.clone() if self.gather_from_copy else mine, group=self.group)
         return image
 
     def gather_densification_info(self) -> torch.Tensor:

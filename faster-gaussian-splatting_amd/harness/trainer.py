@@ -89,6 +89,19 @@ def photometric_loss(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return l1_dssim_loss(image, target, 0.8, 0.2)
 
 
+_UNIT = {}
+
+
+def _unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """dL/dL = 1 as a tensor that already exists: `loss.backward()` allocates and fills one per call (a 5 us kernel on the critical path of a
+    2 ms iteration; profiles/r05_kernel_sequence.txt). Nothing writes to it: autograd only reads the seed."""
+    key = (loss.device, loss.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        one = _UNIT[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return one
+
+
 def training_iteration(g: Gaussians, view: View, target: torch.Tensor, iteration: int, *, densification_end: int = 14_900,
                        loss_scale: float = 1.0, before_step=None, loss_fn=photometric_loss) -> torch.Tensor:
     """One optimisation step in the reference's order (Trainer.py:170-199): lr update -> render -> loss -> backward ->
@@ -98,7 +111,7 @@ def training_iteration(g: Gaussians, view: View, target: torch.Tensor, iteration
     loss = loss_fn(image, target)
     if loss_scale != 1.0:                 # (two elementwise launches per iteration otherwise)
         loss = loss * loss_scale
-    loss.backward()
+    loss.backward(gradient=_unit_gradient(loss))          # = loss.backward() without the fill kernel that seeds it every iteration
     if before_step is not None:
         before_step()
     g.optimizer.step()

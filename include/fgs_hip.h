@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define FGS_ABI_VERSION 2
+/* 3 (round 6): the private layout of the primitive blob grew in round 5 (footprint rows, tile counts, wave / block sums, big-footprint list) and the
+ * product library stopped exporting fgs_debug_set_option / fgs_debug_set_backward_variant (libfgs_hip_dev.so has them): a caller that sized or
+ * decoded blobs by the version-2 layout, or bound the two debug symbols, must notice. Signatures of the version-2 entry points are unchanged. */
+#define FGS_ABI_VERSION 3
 
 typedef enum fgs_status {
     FGS_OK = 0,

@@ -44,7 +44,7 @@ def test_header_symbols_are_exported_and_bound(hip_lib):
     for name in declared | dev_declared:
         assert getattr(dev_lib, name) is not None
     assert b'dev-switches' in dev_lib.fgs_build_info() and b'dev' not in hip_lib.fgs_build_info()
-    assert hip_lib.fgs_abi_version() == 2
+    assert hip_lib.fgs_abi_version() == 3          # FGS_ABI_VERSION (include/fgs_hip.h)
     assert b'gfx950' in hip_lib.fgs_build_info()
     # ... and no switch variables either: every A/B switch of the sources (FGS_SWITCH, csrc/fgs_kernels.h) is a compile-time constant in the product
     data = lambda lib: {ln.split()[-1] for ln in subprocess.run(['nm', '-C', str(lib)], check=True, capture_output=True, text=True).stdout.splitlines()

@@ -42,6 +42,10 @@ def test_bench_multirank_branch_runs_and_reports_every_rank(n, mode):
     other = d['other_exchange']                                             # the second exchange ran as well
     assert other['dp_mode'] == ('allreduce' if mode == 'sharded' else 'sharded') and other['iters_per_sec'] > 0
     assert other['wire_bytes_per_rank_per_step'] > 0
+    dry = d['dry_exchange']                                                 # one dry exchange of each kind at the step's sizes, next to the predicted wire time
+    assert len(dry['devices']) == n and dry['allreduce_gradient_arena']['bytes'] == 236.0 * 300
+    assert dry['allreduce_gradient_arena']['measured_ms'] > 0 and dry['allreduce_gradient_arena']['predicted_wire_ms'] > 0
+    assert dry['sharded_all_to_all']['measured_ms_records'] > 0 and dry['sharded_all_to_all']['predicted_wire_ms'] > 0 and 'host memory' in dry['note']
     assert d['value'] > 0 and abs(d['value'] - n * 1e3 / d['ms_per_step']) < 1e-6 * d['value']      # whole-job rate = N views per step
     assert len(d['repeatability']['ms_per_step']) == 2
     assert d['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in d     # N > 1: no CPU leg

@@ -129,7 +129,7 @@ def _train(dev, be, steps, handover: bool, tamper=None):
                                    torch.empty(0, device=dev), RS)
         ((image - target) ** 2).mean().backward()
         if handover:
-            stolen &= {P[k].grad.data_ptr() for k in ORDER} == {address for address, _ in R._LIVE['views']}
+            stolen &= {P[k].grad.data_ptr() for k in ORDER} == {address for address, _ in R._LIVE['slots'][P['means'].data_ptr()]['views']}
         if tamper is not None:
             tamper(P, FGS, RS, target)
         opt.step()
@@ -190,6 +190,82 @@ def _check_handover(dev, be, monkeypatch):
     assert FGS.live_block_stats()['matched'] == before['matched'] + 1          # the registry cannot see it ...
     b, _ = _train(dev, be, 1, False, decay_behind_the_counter)
     same(a, b, 'decay_behind_the_counter')                                       # ... the kernel does
+
+
+def _check_two_models(dev, be, monkeypatch):
+    """Two models in one process, their iterations interleaved (backward A, backward B, step A, step B): each optimizer finds the registration of ITS
+    model's pass (the registry is keyed by the model's `means`), and both train exactly as they do alone (round-5 verdict: the single-slot registry
+    made the first model miss)."""
+    import FasterGSCudaBackend as FGS
+    from FasterGSCudaBackend import adam as A, rasterization as R
+    if dev == 'cpu':
+        monkeypatch.setattr(R, '_require_gpu', lambda t: None)
+        monkeypatch.setattr(R, 'default_backend', lambda: be)
+        monkeypatch.setattr(A, 'default_backend', lambda: be)
+    dp, view = _scene(dev, n=450, small_image=(dev == 'cpu'))
+    _, RS = helpers.settings_pair(view, device=dev)
+    target = torch.rand(3, view.height, view.width, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def model(shift):
+        P = {k: (dp[k] + (shift if k == 'means' else 0.0)).clone().requires_grad_(True) for k in ORDER}
+        opt = FGS.FusedAdam([{'params': [P[k]], 'lr': lr, 'name': k} for k, lr in zip(ORDER, LRS)], lr=0.0, eps=1e-15)
+        for i, k in enumerate(ORDER):
+            m0, v0 = helpers.seeded_moments(dp[k].shape, 31 + i)
+            opt.state[P[k]] = {'step': 0, 'exp_avg': m0.to(dev), 'exp_avg_sq': v0.to(dev)}
+        return P, opt
+
+    def backward(P):
+        image = FGS.diff_rasterize(P['means'], P['scales'], P['rotations'], P['opacities'], P['sh_coefficients_0'], P['sh_coefficients_rest'],
+                                   torch.empty(0, device=dev), RS)
+        ((image - target) ** 2).mean().backward()
+
+    results = {}
+    for interleaved in (False, True):
+        FGS.set_live_block_handover(True)
+        (Pa, oa), (Pb, ob) = model(0.0), model(0.01)
+        before = FGS.live_block_stats()
+        for _ in range(2):
+            if interleaved:
+                backward(Pa); backward(Pb); oa.step(); ob.step()
+            else:
+                backward(Pa); oa.step(); backward(Pb); ob.step()
+            oa.zero_grad(); ob.zero_grad()
+        after = FGS.live_block_stats()
+        assert after['matched'] == before['matched'] + 4 and after['missed'] == before['missed'], (interleaved, before, after)
+        assert not R._LIVE['slots']                                           # every registration was consumed by its owner
+        results[interleaved] = ({k: Pa[k].detach().clone() for k in ORDER}, {k: Pb[k].detach().clone() for k in ORDER})
+    if dev == 'cpu':
+        for m in (0, 1):
+            for k in ORDER:
+                assert torch.equal(results[True][m][k], results[False][m][k]), (m, k)
+
+
+def test_sim_two_models_keep_their_own_registration(monkeypatch):
+    _check_two_models('cpu', helpers.sim_backend(), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_gpu_two_models_keep_their_own_registration(hip_backend, monkeypatch):
+    _check_two_models('cuda', hip_backend, monkeypatch)
+
+
+def test_async_forward_scopes_keep_their_own_tables():
+    """`async_forward_scope`: switch, per-view ratios and the overflow mark of a scope are invisible to the others (two models over the same views)."""
+    import FasterGSCudaBackend as FGS
+    from FasterGSCudaBackend import rasterization as R
+    assert FGS.async_forward_stats()['enabled'] is False
+    with FGS.async_forward_scope('model_b'):
+        FGS.set_async_forward(True, headroom=1.5)
+        R._ASYNC['per_view']['some view'] = (2.0, lambda: None, 0)
+        R._ASYNC['step_invalid'] = frozenset({1234})
+        assert FGS.async_forward_stats()['enabled'] and FGS.async_forward_stats()['views'] == 1
+    assert FGS.async_forward_stats()['enabled'] is False and FGS.async_forward_stats()['views'] == 0 and not FGS.take_async_overflow()
+    with FGS.async_forward_scope('model_b'):
+        assert FGS.async_forward_stats()['headroom'] == 1.5 and FGS.async_forward_stats()['views'] == 1       # scopes persist by name
+        assert FGS.take_async_overflow() and not FGS.take_async_overflow()
+    FGS.async_forward_scope.drop('model_b')
+    with FGS.async_forward_scope('model_b'):
+        assert FGS.async_forward_stats()['enabled'] is False
 
 
 def test_sim_handover_through_autograd(monkeypatch):
