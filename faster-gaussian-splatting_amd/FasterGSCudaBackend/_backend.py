@@ -519,8 +519,8 @@ class Backend:
 
     # -- introspection (tests / bench only) ------------------------------------------------------------------------------
     def blob_layout(self, which: int, n: int, width: int, height: int, n_instances: int, n_buckets: int) -> dict:
-        entries = (_lib.BlobEntry * 16)()
-        k = self.lib.fgs_blob_layout(which, n, width, height, n_instances, n_buckets, entries, 16)
+        entries = (_lib.BlobEntry * 32)()
+        k = self.lib.fgs_blob_layout(which, n, width, height, n_instances, n_buckets, entries, 32)
         if k < 0:
             raise RuntimeError(self.lib.fgs_last_error().decode())
         return {entries[i].name.decode(): (entries[i].offset, entries[i].bytes) for i in range(k)}

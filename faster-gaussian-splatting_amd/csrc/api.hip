@@ -109,7 +109,13 @@ struct PrimitiveBuffers {             // cf. bu:45-94
     uint32_t* wave_sums; uint32_t* block_sums;  // their sums per 64-Gaussian wave segment / per 4096-Gaussian block (binning.hip)
     uint32_t* big_list;                         // depth-order positions of the footprints of more than kBigInstanceFootprint candidate tiles (counters[2] of them)
     char* temp; size_t temp_bytes;
-    static PrimitiveBuffers carve(Carver& c, uint32_t n) {
+    // K11's accumulator records [N][9] and the hot Gaussians' replicas behind them (K11 addresses both as 32-bit float offsets from `acc`). Round 6:
+    // they live HERE, at the end of the forward pass's primitive blob, not in the backward scratch -- K1 clears the record of every Gaussian it
+    // finds visible on the side of its own (latency-bound) work, so the backward pass starts without a 117 MB clear on its critical path. Passes
+    // that are never differentiated (inference, pruning scores, the sharded owner's K1) carve the blob without them.
+    float* acc; float* acc_hot;
+    static constexpr size_t kHotFloats = (size_t)kHotReplicas * 9 * kMaxHot;
+    static PrimitiveBuffers carve(Carver& c, uint32_t n, bool with_acc = true) {
         PrimitiveBuffers b;
         b.rec = c.take<PrimRec>("rec", n);
         b.n_touched = c.take<uint32_t>("n_touched", n);
@@ -125,6 +131,8 @@ struct PrimitiveBuffers {             // cf. bu:45-94
         b.big_list = c.take<uint32_t>("big_list", n);
         b.temp_bytes = depth_sort_temp_bytes(n);
         b.temp = c.take<char>("sort_temp", b.temp_bytes);
+        b.acc = with_acc ? c.take<float>("acc", (size_t)n * 9) : nullptr;
+        b.acc_hot = with_acc ? c.take<float>("acc_hot", kHotFloats) : nullptr;
         return b;
     }
 };
@@ -176,13 +184,10 @@ struct BucketBuffers {                // cf. bu:154-163
         return b;
     }
 };
-struct BackwardScratch {
-    float* acc; float* acc_hot; float* view_dir; float4* pixrec;
-    static constexpr size_t kHotFloats = (size_t)kHotReplicas * 9 * kMaxHot;
+struct BackwardScratch {             // (K11's accumulator records moved into the primitive blob in round 6: PrimitiveBuffers::acc)
+    float* view_dir; float4* pixrec;
     static BackwardScratch carve(Carver& c, uint32_t n, uint32_t t) {
         BackwardScratch b;
-        b.acc = c.take<float>("acc", (size_t)n * 9);
-        b.acc_hot = c.take<float>("acc_hot", kHotFloats);
         b.view_dir = c.take<float>("view_dir", (size_t)n * 3);
         b.pixrec = c.take<float4>("pixrec", (size_t)t * kTilePixels * 2);
         return b;
@@ -286,13 +291,14 @@ int run_forward(ForwardMode mode, const float* means, const float* scales, const
 
     // primitive buffers + K1 (fwd:58-98)
     Carver prim_size(nullptr);
-    PrimitiveBuffers::carve(prim_size, n);
+    PrimitiveBuffers::carve(prim_size, n, training);
     void* prim_blob = resize(user, FGS_BUF_PRIMITIVE, prim_size.total());
     if (!prim_blob && prim_size.total() > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", prim_size.total());
     Carver prim_c(prim_blob);
-    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n);
-    FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));
+    PrimitiveBuffers pb = PrimitiveBuffers::carve(prim_c, n, training);
+    FGS_HIP(hipMemsetAsync(pb.counters, 0, kCounterWords * sizeof(uint32_t), stream));      // incl. counters[7]: "the accumulator records are dirty"
     PreprocessArgs pa{};
+    pa.acc = pb.acc;                                   // training: K1 clears the accumulator record of every visible Gaussian
     pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh0; pa.sh_rest = sh_rest;
     pa.rec = pb.rec; pa.n_touched = pb.n_touched; pa.depth_keys = pb.keys[0]; pa.prim_idx = pb.prims[0]; pa.counters = pb.counters; pa.huge_list = pb.offsets;   // `offsets` is free until the K4 scan writes it
     pa.hot_list = pb.hot_list; pa.foot = pb.foot[0];
@@ -415,7 +421,7 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
                   int32_t n_primitives, const fgs_settings* settings, const fgs_forward_state* state) {
     if (int rc = check_settings(settings)) return rc;
     if (!state || n_primitives < 0) return fail(FGS_ERR_INVALID_ARGUMENT, "bad state / n_primitives");
-    if (static_cast<uint64_t>(n_primitives) * kAccRecordWords + BackwardScratch::kHotFloats > 0xfffffff0ull)      // K11 addresses the accumulator records by 32-bit float offsets
+    if (static_cast<uint64_t>(n_primitives) * kAccRecordWords + PrimitiveBuffers::kHotFloats > 0xfffffff0ull)      // K11 addresses the accumulator records by 32-bit float offsets
         return fail(FGS_ERR_INVALID_ARGUMENT, "n_primitives %d: more than 477 M Gaussians per backward pass are not supported", n_primitives);
     if (!prim_blob || !tile_blob || !scratch || (state->n_instances > 0 && !inst_blob) || (state->n_buckets > 0 && !bucket_blob))
         return fail(FGS_ERR_INVALID_ARGUMENT, "NULL scratch buffer");
@@ -430,19 +436,24 @@ int plan_backward(BackwardPlan& P, void* prim_blob, void* tile_blob, void* inst_
 }
 
 int run_blend_backward(const BackwardPlan& P, const float* grad_image, const float* image, int32_t n_primitives,
-                       const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream) {
+                       const fgs_settings* settings, const fgs_forward_state* state, hipStream_t stream, bool cleared_by_preprocess = true) {
     BlendBackwardArgs a{};
-    // replaces api:127-134: only the 9-float accumulators (and the hot Gaussians' replicas behind them) are cleared -- by the staging kernel, on the
-    // side of its own work (no memset launch). Both sub-arrays start on 256-byte boundaries and kHotFloats * 4 is a multiple of 16.
-    static_assert(BackwardScratch::kHotFloats % 4 == 0, "the cleared region is a whole number of 16-byte pieces");
-    const size_t clear_bytes = n_primitives > 0 ? static_cast<size_t>(reinterpret_cast<char*>(P.sc.acc_hot + BackwardScratch::kHotFloats) - reinterpret_cast<char*>(P.sc.acc)) : 0;
-    a.clear_f4 = static_cast<uint32_t>(clear_bytes / 16);          // n <= 477 M (plan_backward): < 2^32 pieces
+    // replaces api:127-134. K11 adds into 9-float records that must start at zero. The records of the visible Gaussians were cleared by K1 during the
+    // forward pass (PrimitiveBuffers::acc); what is left for the staging kernel is the hot replicas (9 MB) -- or everything, when no K1 of this
+    // library filled the blob (the sharded renderer: records arrive from the owners) or when these buffers already went through a backward pass
+    // (a retained graph differentiated twice): counters[7], set by the last kernel of a backward pass, read on the device.
+    static_assert(PrimitiveBuffers::kHotFloats % 4 == 0, "the cleared regions are whole numbers of 16-byte pieces");
+    const size_t all_bytes = n_primitives > 0 ? static_cast<size_t>(reinterpret_cast<char*>(P.pb.acc_hot + PrimitiveBuffers::kHotFloats) - reinterpret_cast<char*>(P.pb.acc)) : 0;
+    a.clear_all_f4 = static_cast<uint32_t>(all_bytes / 16);          // n <= 477 M (plan_backward): < 2^32 pieces
+    a.clear_hot_f4 = n_primitives > 0 ? static_cast<uint32_t>(PrimitiveBuffers::kHotFloats / 4) : 0u;
+    a.clear_everything = cleared_by_preprocess ? 0 : 1;
+    a.dirty_flag = P.pb.counters + 7;
     a.ranges = P.tb.ranges; a.bucket_offsets = P.tb.bucket_offsets; a.inst_prims = P.ib.prims[state->selector]; a.rec = P.pb.rec;
     a.bg = settings->bg_color; a.grad_image = grad_image; a.image = image;
     a.final_T = P.tb.final_T; a.n_processed = P.tb.n_processed; a.max_n_processed = P.tb.max_n_processed;
-    a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.sc.acc;
+    a.bucket_tile = P.bb.tile_index; a.ckpt = P.bb.ckpt; a.pixrec = P.sc.pixrec; a.acc = P.pb.acc;
     a.work_list = P.bb.work_list; a.live_count = P.tb.live_count; a.live_offsets = P.tb.live_offsets;
-    a.acc_hot = P.sc.acc_hot; a.hot_list = P.pb.hot_list; a.hot_count = P.pb.counters + 4;
+    a.acc_hot = P.pb.acc_hot; a.hot_list = P.pb.hot_list; a.hot_count = P.pb.counters + 4;
     a.n = static_cast<uint32_t>(n_primitives); a.width = settings->width; a.height = settings->height;
     a.grid_w = P.geo.grid_w; a.n_tiles = P.geo.n_tiles; a.n_buckets_cap = static_cast<uint32_t>(state->n_buckets);
     a.proper_aa = settings->proper_antialiasing ? 1 : 0;
@@ -535,7 +546,7 @@ int32_t fgs_backward_live(const float* grad_image, const float* image,
     PreprocessBackwardArgs a{};
     a.means = means; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.sh_rest = sh_coefficients_rest;
     a.n_views = 1;
-    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, P.sc.view_dir);
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.pb.acc, P.sc.view_dir);
     a.grad_means = grad_means; a.grad_scales = grad_scales; a.grad_rotations = grad_rotations; a.grad_opacities = grad_opacities;
     a.grad_sh0 = grad_sh_coefficients_0; a.densification_info = densification_info;
     a.n = static_cast<uint32_t>(n_primitives);
@@ -591,7 +602,7 @@ int32_t fgs_backward_adam_fused(const float* grad_image, const float* image,
     a.means = params[0]; a.scales = params[4]; a.rotations = params[5]; a.opacities = params[3]; a.sh_rest = params[2];
     a.densification_info = densification_info;
     a.n_views = 1;
-    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.sc.acc, P.sc.view_dir);
+    a.view[0] = backward_view(*settings, P.geo, P.pb.n_touched, nullptr, P.pb.acc, P.sc.view_dir);
     a.n = static_cast<uint32_t>(n_primitives);
     const int map[5] = {0, 1, 3, 4, 5};     // kernel group order: means, sh0, opacities, scales, rotations
     for (int k = 0; k < 5; ++k) {
@@ -634,7 +645,7 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
     const uint32_t n = static_cast<uint32_t>(n_primitives);
     const Geometry geo = geometry_of(settings->width, settings->height);
     Carver one(nullptr);
-    PrimitiveBuffers::carve(one, n);
+    PrimitiveBuffers::carve(one, n, false);
     const size_t per_view = one.total();
     char* prim_blob = static_cast<char*>(resize(resize_user, FGS_BUF_PRIMITIVE, per_view * n_views));
     if (!prim_blob && per_view > 0) return fail(FGS_ERR_ALLOC, "resize(primitive, %zu) returned NULL", per_view * n_views);
@@ -646,7 +657,7 @@ int32_t fgs_shard_preprocess(const float* means, const float* scales, const floa
         for (int k = 0; k < pb.n_views; ++k) {
             const int v = v0 + k;
             Carver c(prim_blob + per_view * v);
-            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
+            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n, false);
             FGS_HIP(hipMemsetAsync(b.counters, 0, kCounterWords * sizeof(uint32_t), stream));
             PreprocessArgs& pa = pb.v[k];
             pa.means = means; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.sh0 = sh_coefficients_0; pa.sh_rest = sh_coefficients_rest;
@@ -734,8 +745,8 @@ int32_t fgs_backward_to_shard_records(const float* grad_image, const float* imag
     if (n_records == 0) return FGS_OK;
     if (!acc_records_out) return fail(FGS_ERR_INVALID_ARGUMENT, "NULL acc_records_out");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream)) return rc;
-    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.sc.acc, static_cast<uint32_t>(n_records), acc_records_out, order, stream)); }
+    if (int rc = run_blend_backward(P, grad_image, image, n_records, settings, state, stream, false)) return rc;      // no K1 of this library wrote this blob
+    { StageScope t(ST_RECORDS, stream); FGS_HIP(launch_pack_acc(P.pb.acc, static_cast<uint32_t>(n_records), acc_records_out, order, stream)); }
     return FGS_OK;
 }
 
@@ -772,7 +783,7 @@ static int run_shard_backward(const float* acc_records, const int32_t* n_visible
     const uint32_t n = static_cast<uint32_t>(n_primitives);
     const Geometry geo = geometry_of(settings->width, settings->height);
     Carver one(nullptr);
-    PrimitiveBuffers::carve(one, n);
+    PrimitiveBuffers::carve(one, n, false);
     const size_t per_view = one.total();
     const size_t dir_stride = ((size_t)n * 3 * sizeof(float) + 255) / 256 * 256;
     char* const dir_base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~static_cast<uintptr_t>(255));
@@ -788,7 +799,7 @@ static int run_shard_backward(const float* acc_records, const int32_t* n_visible
         for (int k = 0; k < a.n_views; ++k) {
             const int v = v0 + k;
             Carver c(const_cast<char*>(static_cast<const char*>(primitive_buffers)) + per_view * v);
-            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n);
+            const PrimitiveBuffers b = PrimitiveBuffers::carve(c, n, false);
             // accumulator records are read in place through the slot table K1 left behind: no scatter pass, no dense copy
             a.view[k] = backward_view(settings[v], geo, b.n_touched, b.keys[1], acc_records + first_record * kAccRecordWords,
                                       reinterpret_cast<float*>(dir_base + dir_stride * v));

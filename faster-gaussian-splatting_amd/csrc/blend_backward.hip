@@ -46,13 +46,16 @@ __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBa
         const unsigned base = a.live_offsets[tile];
         for (unsigned k = local; k < nl; k += kTilePixels) a.work_list[base + k] = make_uint2(tile, k);
     }
-    // K11's accumulator records and the hot replicas behind them start at zero (replaces api:127-134). Until round 5 a hipMemsetAsync in front of
-    // this kernel (16 us at 3 M Gaussians: a launch of its own on the critical path of every backward pass); the stores are independent of
-    // everything above, so this latency-bound kernel issues them on the side: every workgroup clears an equal share, 16 bytes per store.
-    if (a.clear_f4 != 0u) {
-        const unsigned per_group = (a.clear_f4 + gridDim.x - 1u) / gridDim.x;
-        const unsigned first = tile * per_group, last = min(first + per_group, a.clear_f4);
-        float4* const z = reinterpret_cast<float4*>(a.acc);
+    // K11 adds into records that start at zero (replaces api:127-134). The records of the visible Gaussians were cleared by K1 in the forward pass;
+    // left for this kernel are the hot replicas -- or records and replicas alike when no K1 filled the blob or a backward pass already ran over it
+    // (BlendBackwardArgs). Every workgroup clears an equal share, 16 bytes per store. (Round 5: a hipMemsetAsync of 117 MB in front of this kernel,
+    // 16 us on the critical path of every backward pass; doing all of it here costs the same 16 us -- HBM write rate, profiles/r06_ab_acc_clear.txt.)
+    {
+        const bool everything = a.clear_everything != 0 || *a.dirty_flag != 0u;
+        const unsigned n_f4 = everything ? a.clear_all_f4 : a.clear_hot_f4;
+        float4* const z = reinterpret_cast<float4*>(everything ? a.acc : a.acc_hot);
+        const unsigned per_group = (n_f4 + gridDim.x - 1u) / gridDim.x;
+        const unsigned first = tile * per_group, last = min(first + per_group, n_f4);
         for (unsigned k = first + local; k < last; k += kTilePixels) z[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
@@ -972,6 +975,9 @@ namespace fgs {
 __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendBackwardArgs a) {
     const unsigned n_hot = min(*a.hot_count, kMaxHot);
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    // this is the last kernel of a backward pass: the accumulator records now hold sums -- a second backward pass over the same buffers (a retained
+    // graph) must clear them itself (stage_pixels_kernel reads the flag)
+    if (e == 0u) *a.dirty_flag = 1u;
     const unsigned slot = e / kAccRecordWords, k = e % kAccRecordWords;          // consecutive threads: the nine sums of a slot, then the next slot
     if (slot >= n_hot) return;
     float sum = 0.0f;
@@ -979,6 +985,9 @@ __global__ void __launch_bounds__(256) fold_hot_accumulators_kernel(const BlendB
     for (unsigned r = 0; r < kHotReplicas; ++r) sum += a.acc_hot[((size_t)r * kMaxHot + slot) * kAccRecordWords + k];
     if (sum != 0.0f) a.acc[(size_t)a.hot_list[slot] * kAccRecordWords + k] += sum;      // one slot per primitive: no other writer at this point
 }
+#ifdef FGS_DEV_SWITCHES
+__global__ void mark_accumulators_dirty_kernel(uint32_t* flag) { *flag = 1u; }      // the A/B variants that do not end in the fold kernel
+#endif
 
 #ifdef FGS_DEV_SWITCHES
 std::atomic<int> g_k11m_max_blocks{FGS_K11M_MAX_BLOCKS};   // variant 4: upper bound of its grid (fgs_debug_set_option(13, n)); items beyond it are walked grid-stride
@@ -1014,12 +1023,14 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
     }
     if (a.variant == 1) {
         hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(a.n_buckets_cap), dim3(kTilePixels), 0, s, a);
+        hipLaunchKernelGGL(mark_accumulators_dirty_kernel, dim3(1), dim3(1), 0, s, a.dirty_flag);
         return hipGetLastError();
     }
     if (a.variant != 3) {
         const dim3 grid((a.n_buckets_cap + kBackwardWavesPerBlock - 1) / kBackwardWavesPerBlock), block(kBackwardWavesPerBlock * kWave);
         if (a.variant == 2) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, block, 0, s, a);
+        hipLaunchKernelGGL(mark_accumulators_dirty_kernel, dim3(1), dim3(1), 0, s, a.dirty_flag);
         return hipGetLastError();
     }
 #endif

@@ -21,6 +21,7 @@ struct PreprocessArgs {                 // K1
     uint32_t* huge_list;                           // indices of footprints > kHugeFootprint candidate tiles (counted by a second kernel)
     uint32_t* hot_list;                            // [kMaxHot] primitive index of hot-accumulator slot s (counters[4] = slots handed out)
     uint2* ranges; uint32_t n_tiles;               // cleared by the kernel (K0)
+    float* acc;                                    // training: K11's accumulator records [N][9]; K1 clears those of the Gaussians it finds visible (else nullptr)
     uint32_t n;
     int seq_tiles;                                 // candidate tiles each lane tests itself before the wave cooperates (1..32)
     int count_appended;                            // sharded path: counters[2] counts the huge-footprint entries appended to the list
@@ -127,7 +128,10 @@ struct BlendBackwardArgs {              // K11 (+ per-pixel staging pass)
     uint2* work_list; uint32_t* live_count;   // variant 3: (tile, bucket in tile) of every live bucket and their number
     uint32_t* live_offsets;                   // [T] first list slot of each tile (planning pass -> stage_pixels_kernel)
     uint32_t n, width, height, grid_w, n_tiles, n_buckets_cap;
-    uint32_t clear_f4;                    // 16-byte pieces from `acc` on (records + hot replicas) that the staging pass sets to zero
+    // what the staging pass sets to zero: the hot replicas (clear_hot_f4 16-byte pieces from acc_hot), or -- `clear_everything`, or *dirty_flag != 0 --
+    // records and replicas (clear_all_f4 pieces from acc). K1 cleared the records of the visible Gaussians during the forward pass (api.hip).
+    uint32_t clear_all_f4, clear_hot_f4; int clear_everything;
+    uint32_t* dirty_flag;                 // counters[7]: set by the last kernel of a backward pass over these buffers
     int proper_aa;
     int ablate;                           // dev build only: timing experiments (fgs_debug_set_option key 7)
     int variant;                          // K11 formulation, read once per backward pass (blend_backward_variant(); 3 in the product build)

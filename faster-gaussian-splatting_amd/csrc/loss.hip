@@ -28,6 +28,30 @@ static_assert(kLossTileW * (kLossTileH / kRowsPerThread) == 256, "one (column, r
 
 struct GaussWindow { float w[kTaps]; };
 
+// Which tile does workgroup `block` of a 1-D launch filter? The hardware deals workgroups to the 8 XCDs round-robin (XCD = block % 8) and every tile
+// re-reads a 5-pixel halo of its neighbours' pixels: with the natural order the four neighbours of a tile run on four other XCDs, each with an L2 of
+// its own, and every one of them fetches the shared 128-byte lines from memory again (round-5 counters: the two kernels fetched 2.4x their
+// algorithmic bytes). Here XCD x owns the contiguous band of tiles [x * per_xcd, (x + 1) * per_xcd) in (channel, row, column) order -- a dozen full
+// tile rows -- so a tile's neighbours are its own XCD's neighbours in time and space. FGS_LOSS_XCD_BANDS=0: the natural order (A/B).
+#ifndef FGS_LOSS_XCD_BANDS
+#define FGS_LOSS_XCD_BANDS 1
+#endif
+__device__ __forceinline__ bool loss_tile_of(const unsigned block, const unsigned tiles_x, const unsigned tiles_y, unsigned& tx, unsigned& ty, unsigned& c,
+                                             unsigned& logical) {
+    const unsigned total = tiles_x * tiles_y * 3u;
+#if FGS_LOSS_XCD_BANDS
+    const unsigned per_xcd = (total + kXcds - 1u) / kXcds;
+    logical = (block % kXcds) * per_xcd + block / kXcds;
+#else
+    logical = block;
+#endif
+    if (logical >= total) return false;
+    c = logical / (tiles_x * tiles_y);
+    const unsigned in_plane = logical - c * tiles_x * tiles_y;
+    ty = in_plane / tiles_x; tx = in_plane - ty * tiles_x;
+    return true;
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* s_red) {   // sum over the 256-thread workgroup, valid in thread 255
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     v = wave_sum_to_lane63(v);
@@ -69,7 +93,9 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
     __shared__ float hz4[4][kRegionH][kLossTileW];
     float (*const hz_last)[kLossTileW] = reinterpret_cast<float (*)[kLossTileW]>(&sxy[0][0][0]);      // map 4, written after the barrier below
     float* const s_red = &sxy[0][0][0] + kMapFloats;                                   // 8 floats behind it
-    const int x0 = blockIdx.x * kLossTileW, y0 = blockIdx.y * kLossTileH, c = blockIdx.z;
+    unsigned tile_x, tile_y, chan, logical;
+    if (!loss_tile_of(blockIdx.x, (a.width + kLossTileW - 1) / kLossTileW, (a.height + kLossTileH - 1) / kLossTileH, tile_x, tile_y, chan, logical)) return;   // workgroup-uniform
+    const int x0 = tile_x * kLossTileW, y0 = tile_y * kLossTileH, c = chan;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ X = a.image + c * plane; const float* __restrict__ Y = a.target + c * plane;
     stage_region<2>(sxy, x0, y0, a.width, a.height, [&](int k, size_t e) { return k == 0 ? X[e] : Y[e]; });
@@ -153,8 +179,7 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
     // per-workgroup partial sums, reduced by ssim_reduce_kernel: thousands of workgroups adding to two words would serialise on the
     // same-address atomic rate (measured 0.28 ms at 1080p), and a fixed order makes the loss reproducible
     if (threadIdx.x == 255) {
-        const unsigned b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.partials[2 * b] = bl; a.partials[2 * b + 1] = bs;
+        a.partials[2 * logical] = bl; a.partials[2 * logical + 1] = bs;          // in tile order whatever the mapping: the reduction order is fixed
     }
 }
 
@@ -192,7 +217,9 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
     static_assert(3 * kBwdRegionH * kBwdRegionW >= 3 * kMapFloats, "the three filtered maps fit in the staged region");
     __shared__ float sd[3][kBwdRegionH][kBwdRegionW];
     float (*const hz)[kBwdRegionH][kBwdTileW] = reinterpret_cast<float (*)[kBwdRegionH][kBwdTileW]>(&sd[0][0][0]);
-    const int x0 = blockIdx.x * kBwdTileW, y0 = blockIdx.y * kBwdTileH, c = blockIdx.z;
+    unsigned tile_x, tile_y, chan, logical;
+    if (!loss_tile_of(blockIdx.x, (a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, tile_x, tile_y, chan, logical)) return;     // workgroup-uniform
+    const int x0 = tile_x * kBwdTileW, y0 = tile_y * kBwdTileH, c = chan;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ m0 = a.d_mu + c * plane; const float* __restrict__ m1 = a.d_m11 + c * plane; const float* __restrict__ m2 = a.d_m12 + c * plane;
     for (int idx = threadIdx.x; idx < kBwdRegionH * kBwdRegionW; idx += 256) {       // flat index: every lane loads (division by a constant)
@@ -283,22 +310,26 @@ static GaussWindow make_window() {
     return gw;
 }
 
+// 1-D launch of one workgroup per tile, rounded up so that every XCD gets the same number of workgroups (loss_tile_of; the spare ones return at once)
+static dim3 loss_grid(const unsigned tiles) { return dim3((tiles + kXcds - 1u) / kXcds * kXcds); }
+
 hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s) {
     const GaussWindow gw = make_window();
-    const dim3 grid((a.width + kLossTileW - 1) / kLossTileW, (a.height + kLossTileH - 1) / kLossTileH, 3), block(256);
-    hipLaunchKernelGGL(ssim_forward_kernel, grid, block, 0, s, a, gw);
-    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), block, 0, s, a, grid.x * grid.y * grid.z);
+    const dim3 block(256);
+    const unsigned tiles = static_cast<unsigned>((a.width + kLossTileW - 1) / kLossTileW) * static_cast<unsigned>((a.height + kLossTileH - 1) / kLossTileH) * 3u;
+    hipLaunchKernelGGL(ssim_forward_kernel, loss_grid(tiles), block, 0, s, a, gw);
+    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), block, 0, s, a, tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.grad == nullptr) return e;
-    const dim3 grid_b((a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, 3);
-    hipLaunchKernelGGL(ssim_backward_kernel, grid_b, block, 0, s, a, gw);
+    const unsigned tiles_b = static_cast<unsigned>((a.width + kBwdTileW - 1) / kBwdTileW) * static_cast<unsigned>((a.height + kBwdTileH - 1) / kBwdTileH) * 3u;
+    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), block, 0, s, a, gw);
     return hipGetLastError();
 }
 
 hipError_t launch_l1_dssim_backward(const LossArgs& a, hipStream_t s) {
     const GaussWindow gw = make_window();
-    const dim3 grid((a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, 3), block(256);
-    hipLaunchKernelGGL(ssim_backward_kernel, grid, block, 0, s, a, gw);
+    const unsigned tiles_b = static_cast<unsigned>((a.width + kBwdTileW - 1) / kBwdTileW) * static_cast<unsigned>((a.height + kBwdTileH - 1) / kBwdTileH) * 3u;
+    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), dim3(256), 0, s, a, gw);
     return hipGetLastError();
 }
 

@@ -224,6 +224,13 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 dst[1] = make_float4(cc, opacity, col[0], col[1]);
                 // footprints of <= 32 candidate tiles hand their exact-overlap bitmap to the instance generator; hot ones their slot
                 dst[2] = make_float4(col[2], __uint_as_float(bx), __uint_as_float(by), __uint_as_float(slot_word));
+                // training: K11's accumulator record of this Gaussian starts at zero (replaces api:127-134; the only records K11 adds into and K12
+                // reads are those of visible Gaussians). Nine stores that nothing waits for, in a kernel whose HBM traffic is a third of the rate.
+                if (!INFERENCE && a.acc != nullptr) {
+                    float* const z = a.acc + (size_t)idx * kAccRecordWords;
+#pragma unroll
+                    for (unsigned k = 0; k < kAccRecordWords; ++k) z[k] = 0.0f;
+                }
             }
             const uint64_t huge_mask = wave_ballot(huge);
             if (huge_mask != 0) {

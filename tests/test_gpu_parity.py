@@ -165,6 +165,39 @@ def test_equal_depth_keys_keep_every_order_independent_quantity(hip_backend, ora
     assert float(np.abs(res.image.cpu().numpy() - f['image']).max()) < 0.5          # a different order of tied layers, not a different scene
 
 
+def test_equal_depth_keys_image_and_gradients_in_the_device_order(hip_backend, oracle):
+    """The other half of the tied-depth contract (round-5 verdict: no test held image / gradient parity on a scene with ties). Among equal depth keys
+    the blending order is whatever the visible list's order was (K1's atomic compaction on hardware, kf:204-208 in the reference; the index order in the
+    oracle). So: read the order the DEVICE chose out of its buffers, hand the oracle the same Gaussians re-indexed in that order -- its stable sort
+    then reproduces the device's order exactly -- and hold image, final transmittance, per-pixel contributor counts and all six gradients to the usual
+    bars. Nothing about this scene is order-independent any more; the comparison is."""
+    p, view = helpers.tied_depth_scene()
+    S, RS = helpers.settings_pair(view, device=DEV)
+    dp = _to(p)
+    n = p['means'].shape[0]
+    res = hip_backend.forward(*[dp[k] for k in helpers.NAMES], RS)
+    gi = np.random.default_rng(4).standard_normal((3, view.height, view.width)).astype(np.float32)
+    grads = hip_backend.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'], dp['rotations'],
+                                 dp['opacities'], dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    torch.cuda.synchronize()
+    dec = helpers.decode_forward(hip_backend, res, n, view.width, view.height)
+    f0 = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    sel = 0 if np.array_equal(np.sort(dec['prim_idx0']), np.sort(f0['prim_idx'])) and np.all(np.diff(dec['depth_keys0'].astype(np.int64)) >= 0) else 1
+    device_order = dec[f'prim_idx{sel}'].astype(np.int64)                       # the visible Gaussians, front to back, ties as the device broke them
+    assert len(np.unique(f0['depth_keys'])) < f0['V'] // 50 and not np.array_equal(device_order, f0['prim_idx'])      # heavily tied, and broken differently
+    perm = np.concatenate([device_order, np.setdiff1d(np.arange(n), device_order)])
+    pp = {k: v[torch.from_numpy(perm)].contiguous() for k, v in p.items()}
+    f = oracle.forward(*helpers.np_params(pp), S, bucket_size=64)
+    assert np.array_equal(perm[f['prim_idx']], device_order)                   # the oracle now walks the device's order
+    assert helpers.rel_inf(res.image.cpu().numpy(), f['image']) < 1e-4
+    assert np.abs(helpers.tiles_to_image(dec['final_T_tiles'], view.width, view.height).reshape(-1) - f['final_T']).max() < 1e-5
+    assert np.array_equal(helpers.tiles_to_image(dec['n_processed_tiles'], view.width, view.height).reshape(-1), f['n_processed'])
+    g = oracle.backward(f, S, gi)
+    inverse = np.empty(n, np.int64); inverse[perm] = np.arange(n)
+    g = {k: g[k][inverse] for k in helpers.GRAD_KEYS}                           # back to the caller's indexing
+    _grads_close(grads, g)
+
+
 def test_uninitialised_scratch_is_harmless(hip_dev_backend, oracle):
     """Same as the simulation test: 0xFF-poisoned scratch must not reach any output (NaN checkpoints of finished pixels); every K11 formulation
     of the dev library (variant 3 = the product's kernel, same source)."""
@@ -187,6 +220,18 @@ def test_uninitialised_scratch_is_harmless(hip_dev_backend, oracle):
             _grads_close(grads, g, truth=truth)
         finally:
             be.lib.fgs_debug_set_backward_variant(3)
+    # the fused backward + Adam over poisoned buffers as well: lr = 1 and zero moments turn the first step into p - sign(g), so the parameters that
+    # moved the wrong way (or did not stay put) name every gradient sign the fused kernel got wrong
+    order = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
+    key_of = dict(zip(order, ('means', 'sh0', 'sh_rest', 'opacities', 'scales', 'rotations')))
+    res2 = be.forward(*[dp[k] for k in helpers.NAMES], RS)
+    P = [dp[k].clone() for k in order]
+    M, V = [torch.zeros_like(t) for t in P], [torch.zeros_like(t) for t in P]
+    be.backward_adam_fused(None, torch.from_numpy(gi).to(DEV), res2.image, P, M, V, res2.buffers, RS, res2.state, 1, [1.0] * 6)
+    for k, t, m in zip(order, P, M):
+        assert bool(torch.isfinite(t).all()) and bool(torch.isfinite(m).all()), k
+        ref = g[key_of[k]].reshape(tuple(t.shape))
+        assert helpers.rel_inf(m.cpu().numpy(), 0.1 * ref) < 1e-4, k                 # exp_avg after one step = (1 - beta1) * gradient
 
 
 def test_large_footprints_and_long_lists(hip_backend, oracle):
@@ -370,8 +415,12 @@ def test_fused_backward_adam_matches_unfused(hip_backend):
     order = ('means', 'sh_coefficients_0', 'sh_coefficients_rest', 'opacities', 'scales', 'rotations')
     lrs = [1.6e-4, 2.5e-3, 1.25e-4, 2.5e-2, 5e-3, 1e-3]
     ref_p = {k: params[k].to(DEV).clone() for k in order}
-    ref_m = {k: (torch.randn(params[k].shape) * 1e-3).to(DEV) for k in order}
-    ref_v = {k: (torch.rand(params[k].shape) * 1e-6).to(DEV) for k in order}
+    # seeded, with a floor under exp_avg_sq (helpers.seeded_moments): unseeded moments made this test depend on the global RNG state the tests before it
+    # left behind -- an exp_avg_sq entry near zero turns the step into lr * m / (0.03 |g|), whose relative error is that of a tiny gradient (round 6:
+    # one failure in five suite runs, 6e-4 on one element, none in isolation)
+    seeded = {k: helpers.seeded_moments(params[k].shape, 71 + i) for i, k in enumerate(order)}
+    ref_m = {k: seeded[k][0].to(DEV) for k in order}
+    ref_v = {k: seeded[k][1].to(DEV) for k in order}
     fus_p, fus_m, fus_v = ({k: d[k].clone() for k in order} for d in (ref_p, ref_m, ref_v))
     gi = torch.randn(3, view.height, view.width, generator=torch.Generator().manual_seed(2)).to(DEV)
     dens_ref, dens_fus = torch.zeros(2, 2000, device=DEV), torch.zeros(2, 2000, device=DEV)

@@ -177,6 +177,30 @@ def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
             be.lib.fgs_debug_set_backward_variant(3)
 
 
+def test_second_backward_over_the_same_buffers(sim_product_backend, oracle):
+    """A retained graph differentiated twice: K11's accumulator records live in the forward pass's primitive blob and are cleared by K1 (round 6);
+    the first backward pass leaves sums in them and a flag (counters[7]) that makes the second one clear them itself. Same gradients, bit for bit,
+    also for another upstream gradient in between."""
+    be = sim_product_backend
+    p, v = make_s0(seed=5, n=700)
+    p['scales'] = p['scales'] + 0.8                                   # some hot (large-footprint) Gaussians as well: their replicas are cleared per pass
+    S, RS = helpers.settings_pair(v)
+    res = be.forward(*[p[k] for k in helpers.NAMES], RS)
+    gi = torch.randn(res.image.shape, generator=torch.Generator().manual_seed(2))
+    args = (res.image, p['means'], p['scales'], p['rotations'], p['opacities'], p['sh_coefficients_rest'], res.buffers, RS, res.state)
+    first = [g.clone() for g in be.backward(torch.empty(0), gi, *args)]
+    other = be.backward(torch.empty(0), 3.0 * gi, *args)
+    again = be.backward(torch.empty(0), gi, *args)
+    assert any(float(g.abs().max()) > 0 for g in first)
+    for a, b, c in zip(first, again, other):
+        assert torch.equal(a, b)
+        assert not torch.equal(a, c) or float(a.abs().max()) == 0.0
+    f = oracle.forward(*helpers.np_params(p), S, bucket_size=64)
+    g = oracle.backward(f, S, gi.numpy())
+    for t, k in zip(first, helpers.GRAD_KEYS):
+        assert helpers.rel_inf(t.numpy().reshape(g[k].shape), g[k]) < 1e-4, k
+
+
 def test_empty_and_fully_culled(sim_backend, oracle):
     params, view = make_s0(n=32)
     S, RS = helpers.settings_pair(view, bg=(0.1, 0.2, 0.3))
