@@ -24,27 +24,32 @@ namespace fgs {
 
 // staging pass: kb:349-380 hoisted out of the per-bucket loop
 __global__ void __launch_bounds__(kTilePixels) stage_pixels_kernel(const BlendBackwardArgs a) {
-    const unsigned tile = blockIdx.x, local = threadIdx.x;
-    const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
-    const unsigned px = tile_x * kTileW + (local % kTileW), py = tile_y * kTileH + (local / kTileW);
-    float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-    if (px < a.width && py < a.height) {
-        const size_t pix = (size_t)a.width * py + px, n_pixels = (size_t)a.width * a.height;
-        const float fT = a.final_T[(size_t)tile * kTilePixels + local];
-        const float b0 = a.bg[0], b1 = a.bg[1], b2 = a.bg[2];
-        g.x = a.grad_image[pix]; g.y = a.grad_image[n_pixels + pix]; g.z = a.grad_image[2 * n_pixels + pix];
-        g.w = fT * -(g.x * b0 + g.y * b1 + g.z * b2);                                  // kb:375-377
-        c.x = a.image[pix] - fT * b0; c.y = a.image[n_pixels + pix] - fT * b1; c.z = a.image[2 * n_pixels + pix] - fT * b2;
-        c.w = __uint_as_float(a.n_processed[(size_t)tile * kTilePixels + local]);
-    }
-    a.pixrec[((size_t)tile * kTilePixels + local) * 2] = g;
-    a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1] = c;
-    // the tile's entries of the live-bucket list (variant 3): the planning pass has scanned the per-tile counts, the entries are written here,
-    // by 12 k workgroups instead of one
-    if (a.live_offsets != nullptr) {
-        const unsigned nl = (a.max_n_processed[tile] + kBucket - 1) / kBucket;              // kb:295
-        const unsigned base = a.live_offsets[tile];
-        for (unsigned k = local; k < nl; k += kTilePixels) a.work_list[base + k] = make_uint2(tile, k);
+    // (Round 6, measured and withdrawn: XCD x taking a contiguous band of tiles, so that the two tiles sharing a 128-byte line of the six image planes
+    // run under one L2 -- what took 6 % off the loss kernels -- leaves this kernel at 0.040 ms: profiles/r06_ab_stage_pixels_xcd.txt.)
+    const unsigned tile = blockIdx.x;
+    const unsigned local = threadIdx.x;
+    if (tile < a.n_tiles) {
+        const unsigned tile_x = tile % a.grid_w, tile_y = tile / a.grid_w;
+        const unsigned px = tile_x * kTileW + (local % kTileW), py = tile_y * kTileH + (local / kTileW);
+        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+        if (px < a.width && py < a.height) {
+            const size_t pix = (size_t)a.width * py + px, n_pixels = (size_t)a.width * a.height;
+            const float fT = a.final_T[(size_t)tile * kTilePixels + local];
+            const float b0 = a.bg[0], b1 = a.bg[1], b2 = a.bg[2];
+            g.x = a.grad_image[pix]; g.y = a.grad_image[n_pixels + pix]; g.z = a.grad_image[2 * n_pixels + pix];
+            g.w = fT * -(g.x * b0 + g.y * b1 + g.z * b2);                                  // kb:375-377
+            c.x = a.image[pix] - fT * b0; c.y = a.image[n_pixels + pix] - fT * b1; c.z = a.image[2 * n_pixels + pix] - fT * b2;
+            c.w = __uint_as_float(a.n_processed[(size_t)tile * kTilePixels + local]);
+        }
+        a.pixrec[((size_t)tile * kTilePixels + local) * 2] = g;
+        a.pixrec[((size_t)tile * kTilePixels + local) * 2 + 1] = c;
+        // the tile's entries of the live-bucket list (variant 3): the planning pass has scanned the per-tile counts, the entries are written here,
+        // by 12 k workgroups instead of one
+        if (a.live_offsets != nullptr) {
+            const unsigned nl = (a.max_n_processed[tile] + kBucket - 1) / kBucket;              // kb:295
+            const unsigned base = a.live_offsets[tile];
+            for (unsigned k = local; k < nl; k += kTilePixels) a.work_list[base + k] = make_uint2(tile, k);
+        }
     }
     // K11 adds into records that start at zero (replaces api:127-134). The records of the visible Gaussians were cleared by K1 in the forward pass;
     // left for this kernel are the hot replicas -- or records and replicas alike when no K1 filled the blob or a backward pass already ran over it

@@ -341,6 +341,9 @@ __device__ __forceinline__ void preprocess_huge_body(const PreprocessArgs& a) {
 __global__ void __launch_bounds__(kHugeBlock) preprocess_huge_kernel(const PreprocessArgs a) { preprocess_huge_body(a); }
 __global__ void __launch_bounds__(kHugeBlock) preprocess_huge_batch_kernel(const PreprocessBatch b) { preprocess_huge_body(b.v[blockIdx.y]); }
 
+// (Round 6, measured and withdrawn: K1's counter block cleared and published by one-wave kernels of our own instead of hipMemsetAsync /
+// hipMemcpyAsync -- the trace shows a ~6 us gap behind each of the runtime's two operations -- left the forward-only frame unchanged, 0.674-0.682 vs
+// 0.673-0.675 ms in alternating processes on one box: the gaps are the host's wake-up behind the event, not the operations. profiles/r06_ab_counter_kernels.txt)
 hipError_t launch_preprocess(bool inference, const PreprocessArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const dim3 grid((a.n + kPreprocessBlock - 1) / kPreprocessBlock), block(kPreprocessBlock);

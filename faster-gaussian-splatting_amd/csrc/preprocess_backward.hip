@@ -295,7 +295,10 @@ __device__ __forceinline__ float4 sh_rest_gradient_piece(const float* const slic
 // two-kernel form of round 1 the SH-rest parameters are read from HBM once instead of twice, the view direction never
 // leaves registers, and the 15 basis values are evaluated once per Gaussian instead of once per (Gaussian, basis) pair.
 // Bytes per Gaussian: 59 x 24 (state in / out) + 36 + 4 (accumulators, tile count) [+ 16 densification] = 1456.
-constexpr int kFusedUnroll = 3;          // 16-byte pieces of each of the three streams in flight per lane
+#ifndef FGS_FUSED_UNROLL
+#define FGS_FUSED_UNROLL 3
+#endif
+constexpr int kFusedUnroll = FGS_FUSED_UNROLL;          // 16-byte pieces of each of the three streams in flight per lane
 #ifndef FGS_FUSED_WAVES
 #define FGS_FUSED_WAVES 3
 #endif
@@ -458,6 +461,10 @@ fused_backward_adam_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) 
 // gradients written instead of applied. Against round 1's two kernels it drops the view-direction round trip through HBM and the second
 // read of tile counts / colour gradients, and keeps the fully coalesced 16-byte stores of the [N, R, 3] gradient (every element of every
 // gradient is written exactly once, zeros for invisible Gaussians: no zero-fill, rasterization_api.cu:127-134).
+#ifndef FGS_K12_NT_STORES
+#define FGS_K12_NT_STORES 1      // round 6: the 540 MB SH-rest gradient leaves as non-temporal stores (K12 0.248 -> 0.242 ms and the Adam kernel behind it
+                                 // 0.771 -> 0.758 in alternating processes, profiles/r06_ab_k12_nt_stores.txt); 2: the 14 small floats as well (A/B)
+#endif
 template <int RT>
 __global__ void __launch_bounds__(256) backward_gradients_kernel(const PreprocessBackwardArgs a, const ShRestArgs sh) {
     __shared__ __attribute__((aligned(16))) float s_grad[256 / kWave][kWave * 15 * 3];
@@ -479,7 +486,13 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
 #pragma unroll
         for (int grp = 0; grp < 5; ++grp)
 #pragma unroll
-            for (int k = 0; k < kGroupWidth[grp]; ++k) outs[grp][(size_t)i * kGroupWidth[grp] + k] = grad[kGroupOffset[grp] + k];
+            for (int k = 0; k < kGroupWidth[grp]; ++k) {
+#if FGS_K12_NT_STORES >= 2
+                __builtin_nontemporal_store(grad[kGroupOffset[grp] + k], outs[grp] + (size_t)i * kGroupWidth[grp] + k);
+#else
+                outs[grp][(size_t)i * kGroupWidth[grp] + k] = grad[kGroupOffset[grp] + k];
+#endif
+            }
     }
     float* const slice = s_grad[wv];
     const bool any_visible = wave_ballot(visible) != 0;
@@ -501,7 +514,11 @@ __global__ void __launch_bounds__(256) backward_gradients_kernel(const Preproces
     for (uint32_t e = 4u * lane; e < count; e += 4u * kWave) {
         if (e + 4u <= count && a.vector_ok) {                          // 16-byte stores need a 16-byte aligned gradient tensor (checked at launch)
             const float4 g = any_visible ? *reinterpret_cast<const float4*>(slice + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#if FGS_K12_NT_STORES
+            store_float4_nt(out + e, g);
+#else
             *reinterpret_cast<float4*>(out + e) = g;
+#endif
         } else {
             for (uint32_t j = e; j < count && j < e + 4u; ++j) out[j] = any_visible ? slice[j] : 0.0f;
         }
