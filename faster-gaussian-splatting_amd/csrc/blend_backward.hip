@@ -20,6 +20,9 @@
 #include <fgs_wave.h>
 #include "fgs_tile_scan.h"
 
+#ifndef FGS_CKPT_NT
+#define FGS_CKPT_NT 1      // round 6: ... and are read as non-temporal loads (training iteration 2.218 -> 2.187 ms, layered scene 3.728 -> 3.706, three alternating pairs: profiles/r06_ab_ckpt_nt.txt); 0: A/B
+#endif
 namespace fgs {
 
 // staging pass: kb:349-380 hoisted out of the per-bucket loop
@@ -454,7 +457,12 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
 #pragma unroll
             for (int c = 0; c < kTilePixels / kWave; ++c) {                        // all nine loads in flight together
                 const unsigned p = static_cast<unsigned>(c) * kWave + lane;
-                g[c] = pix[2 * p]; cst[c] = pix[2 * p + 1]; k[c] = ck[p];
+                g[c] = pix[2 * p]; cst[c] = pix[2 * p + 1];
+#if FGS_CKPT_NT
+                k[c] = load_float4_nt(reinterpret_cast<const float*>(ck + p));
+#else
+                k[c] = ck[p];
+#endif
             }
 #pragma unroll
             for (int c = 0; c < kTilePixels / kWave; ++c) {

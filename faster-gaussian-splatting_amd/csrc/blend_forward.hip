@@ -16,6 +16,9 @@
 #include "fgs_kernels.h"
 #include <fgs_wave.h>
 
+#ifndef FGS_CKPT_NT
+#define FGS_CKPT_NT 1      // round 6: K10's checkpoints -- written once, read once by K11 a millisecond later -- leave as non-temporal stores (training iteration 2.218 -> 2.187 ms, layered scene 3.728 -> 3.706, three alternating pairs: profiles/r06_ab_ckpt_nt.txt); 0: A/B
+#endif
 namespace fgs {
 
 // Which tile does workgroup `block` blend? The hardware deals workgroups to the 8 XCDs round-robin (XCD = block % 8), and a Gaussian's
@@ -204,7 +207,11 @@ __global__ void __launch_bounds__(kBlendBlock) blend_kernel(const BlendArgs a) {
         for (unsigned chunk = 0; chunk < batch; chunk += kBucket) {
             const bool done = FGS_PIXEL_DONE;
             if (TRAINING && !done)                                                     // kf:436-442, every 64 instead of 32
+#if FGS_CKPT_NT
+                store_float4_nt(reinterpret_cast<float*>(a.ckpt + (size_t)(bucket_base + (batch_start + chunk) / kBucket) * kTilePixels + local), make_float4(cr, cg, cb, T));
+#else
                 a.ckpt[(size_t)(bucket_base + (batch_start + chunk) / kBucket) * kTilePixels + local] = make_float4(cr, cg, cb, T);
+#endif
             bool in_l = false, in_r = false;
             const unsigned j = chunk + lane;
             if (j < batch) {                                                           // kf:445-450

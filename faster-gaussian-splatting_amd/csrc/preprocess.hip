@@ -229,7 +229,7 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
                 if (!INFERENCE && a.acc != nullptr) {
                     float* const z = a.acc + (size_t)idx * kAccRecordWords;
 #pragma unroll
-                    for (unsigned k = 0; k < kAccRecordWords; ++k) z[k] = 0.0f;
+                    for (unsigned k = 0; k < kAccRecordWords; ++k) z[k] = 0.0f;      // (as non-temporal stores: no gain, profiles/r06_ab_k1_acc_nt.txt)
                 }
             }
             const uint64_t huge_mask = wave_ballot(huge);
