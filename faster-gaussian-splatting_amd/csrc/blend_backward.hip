@@ -450,6 +450,9 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         const float y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
         // ---- stage the live pixels, compacted (kb:349-380) ----
         unsigned n_px = 0;
+#ifdef FGS_PAIR_STATS
+        uint64_t st_live[kTilePixels / kWave] = {};
+#endif
         {
             const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
             const float4* __restrict__ ck = a.ckpt + (size_t)bucket * kTilePixels;
@@ -471,6 +474,9 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
                 // a pixel that finished before this bucket never wrote its checkpoint (kf:436) and receives nothing here
                 const bool live = last > first_gaussian;
                 const uint64_t m = wave_ballot(live);
+#ifdef FGS_PAIR_STATS
+                st_live[c] = m;
+#endif
                 if (live) {
                     const unsigned slot = n_px + lanes_below(m);
                     const unsigned rel = min(last - first_gaussian, static_cast<unsigned>(kBucket));
@@ -508,6 +514,23 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
             footprint = (tx1 - tx0) * (ty1 - ty0);
             hot_slot_word = __float_as_uint(r2.w);
         }
+#ifdef FGS_PAIR_STATS
+        unsigned st_trim = 0;                                                    // [5]: live pixels outside the union of the bucket's screen bounds
+        {
+            unsigned bx = 0xffffu, by = 0xffffu;                                  // x_min | x_max << 16: an empty box for lanes without a Gaussian
+            if (valid_prim) { const float4 r2q = reinterpret_cast<const float4*>(a.rec + prim)[2]; bx = __float_as_uint(r2q.y); by = __float_as_uint(r2q.z); }
+            const unsigned ux0 = 0xffffu - wave_max(0xffffu - (bx & 0xffffu)), ux1 = wave_max(bx >> 16);
+            const unsigned uy0 = 0xffffu - wave_max(0xffffu - (by & 0xffffu)), uy1 = wave_max(by >> 16);
+            const unsigned tx_px = (tile % a.grid_w) * kTileW, ty_px = (tile / a.grid_w) * kTileH;
+#pragma unroll
+            for (int c = 0; c < kTilePixels / kWave; ++c) {
+                const unsigned p = static_cast<unsigned>(c) * kWave + lane;
+                const unsigned px_ = tx_px + (p & (kTileW - 1)), py_ = ty_px + p / kTileW;
+                const bool inside = px_ >= ux0 && px_ < ux1 && py_ >= uy0 && py_ < uy1;
+                st_trim += static_cast<unsigned>(__popcll(st_live[c] & wave_ballot(!inside)));
+            }
+        }
+#endif
         wave_lds_fence();
         // alpha is recomputed with the FORWARD kernel's expression, operation for operation (kf:455-466 / kb:415-418; blend_forward.hip): the
         // backward pass replays the forward pass's alpha bit for bit, so both passes agree on every alpha >= 1/255 decision and the
@@ -626,7 +649,7 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
         if (lane == 0) {
             atomicAdd(&g_k11_pair_stats[0], 1ull); atomicAdd(&g_k11_pair_stats[1], static_cast<unsigned long long>(st_steps));
             atomicAdd(&g_k11_pair_stats[2], static_cast<unsigned long long>(st_body)); atomicAdd(&g_k11_pair_stats[3], static_cast<unsigned long long>(st_elig));
-            atomicAdd(&g_k11_pair_stats[4], static_cast<unsigned long long>(st_pass));
+            atomicAdd(&g_k11_pair_stats[4], static_cast<unsigned long long>(st_pass)); atomicAdd(&g_k11_pair_stats[5], static_cast<unsigned long long>(st_trim));
         }
 #endif
 #ifdef FGS_K11_TIMELINE

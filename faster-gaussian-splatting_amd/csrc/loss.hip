@@ -36,15 +36,15 @@ struct GaussWindow { float w[kTaps]; };
 #ifndef FGS_LOSS_XCD_BANDS
 #define FGS_LOSS_XCD_BANDS 1
 #endif
+#ifndef FGS_LOSS_XCD_BANDS_BWD
+#define FGS_LOSS_XCD_BANDS_BWD FGS_LOSS_XCD_BANDS
+#endif
+template <bool BANDS>
 __device__ __forceinline__ bool loss_tile_of(const unsigned block, const unsigned tiles_x, const unsigned tiles_y, unsigned& tx, unsigned& ty, unsigned& c,
                                              unsigned& logical) {
     const unsigned total = tiles_x * tiles_y * 3u;
-#if FGS_LOSS_XCD_BANDS
     const unsigned per_xcd = (total + kXcds - 1u) / kXcds;
-    logical = (block % kXcds) * per_xcd + block / kXcds;
-#else
-    logical = block;
-#endif
+    logical = BANDS ? (block % kXcds) * per_xcd + block / kXcds : block;
     if (logical >= total) return false;
     c = logical / (tiles_x * tiles_y);
     const unsigned in_plane = logical - c * tiles_x * tiles_y;
@@ -94,7 +94,7 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
     float (*const hz_last)[kLossTileW] = reinterpret_cast<float (*)[kLossTileW]>(&sxy[0][0][0]);      // map 4, written after the barrier below
     float* const s_red = &sxy[0][0][0] + kMapFloats;                                   // 8 floats behind it
     unsigned tile_x, tile_y, chan, logical;
-    if (!loss_tile_of(blockIdx.x, (a.width + kLossTileW - 1) / kLossTileW, (a.height + kLossTileH - 1) / kLossTileH, tile_x, tile_y, chan, logical)) return;   // workgroup-uniform
+    if (!loss_tile_of<FGS_LOSS_XCD_BANDS != 0>(blockIdx.x, (a.width + kLossTileW - 1) / kLossTileW, (a.height + kLossTileH - 1) / kLossTileH, tile_x, tile_y, chan, logical)) return;   // workgroup-uniform
     const int x0 = tile_x * kLossTileW, y0 = tile_y * kLossTileH, c = chan;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ X = a.image + c * plane; const float* __restrict__ Y = a.target + c * plane;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, co
     __shared__ float sd[3][kBwdRegionH][kBwdRegionW];
     float (*const hz)[kBwdRegionH][kBwdTileW] = reinterpret_cast<float (*)[kBwdRegionH][kBwdTileW]>(&sd[0][0][0]);
     unsigned tile_x, tile_y, chan, logical;
-    if (!loss_tile_of(blockIdx.x, (a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, tile_x, tile_y, chan, logical)) return;     // workgroup-uniform
+    if (!loss_tile_of<FGS_LOSS_XCD_BANDS_BWD != 0>(blockIdx.x, (a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, tile_x, tile_y, chan, logical)) return;     // workgroup-uniform
     const int x0 = tile_x * kBwdTileW, y0 = tile_y * kBwdTileH, c = chan;
     const size_t plane = (size_t)a.width * a.height;
     const float* __restrict__ m0 = a.d_mu + c * plane; const float* __restrict__ m1 = a.d_m11 + c * plane; const float* __restrict__ m2 = a.d_m12 + c * plane;

@@ -10,6 +10,8 @@
  * BY DEFINITION (torch_check.py: brute_force_forward -- every Gaussian at every pixel under the per-pair alpha / transmittance
  * rules alone) for the discrete half: bounds, tile test, sub-tile test, sorts, lists, culls
  * (all in tests/test_oracle.py). None of these is an output of the reference itself. See DESIGN.md "Oracle".
+ * (Round 6: the reference's Python glue -- torch_bindings/*.py -- IS executed in the build container and pinned by committed fixtures,
+ * tests/golden/ref_glue_*; that pins the operator surface above the kernels, not the arithmetic restated in this file, which stays unpinned.)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product path (faster-gaussian-splatting_amd/) never links, imports or calls it.

@@ -28,7 +28,7 @@ def measure(tag, params, views, view_ids):
         k10, k11 = k10.astype(np.float64), k11.astype(np.float64)
         n_vis, n_inst = res.state[0], res.state[1]
         tiles, staged, pairs, mine, passed, offered = k10[:6]
-        items, steps, body, elig, p11 = k11[:5]
+        items, steps, body, elig, p11, trim = k11[:6]
         print(f'{tag} view {vi}: N {g.means.shape[0]}  visible {n_vis}  instances {n_inst}')
         print(f'  K10: instances staged {staged:.0f} ({staged / max(n_inst, 1):.3f} of all)  (Gaussian, strip) slots offered {offered:.0f}  pairs walked {pairs:.0f} '
               f'= {pairs / max(offered, 1):.3f} of offered = {pairs / max(staged, 1):.2f} strips per staged instance')
@@ -37,6 +37,7 @@ def measure(tag, params, views, view_ids):
         print(f'  K11: work items {items:.0f}  steps {steps:.0f} ({steps / max(items, 1):.1f} per item, 63 of them fill)  steps whose contribution block ran {body / max(steps, 1):.3f}')
         print(f'       lane-steps: issued {steps * 64:.0f}, real pixel in front of its last contributor {elig / max(steps * 64, 1):.3f}, passed the alpha test {p11 / max(steps * 64, 1):.4f} '
               f'({p11:.0f}; K10 blended {passed:.0f})')
+        print(f'       live pixels outside the union of their bucket\'s 64 screen bounds (the ceiling of trimming the pixel side by the bucket\'s bounds): {trim:.0f} = {trim / max(steps, 1):.4f} of the steps')
         print(f'       a lane = pixel walk of the same lists visits {pairs:.0f} (Gaussian, strip) pairs x 64 lanes = {pairs / max(steps, 1):.3f} of the lane-steps K11 issues', flush=True)
         del res
     del g
