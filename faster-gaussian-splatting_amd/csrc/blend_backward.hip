@@ -434,6 +434,8 @@ __global__ void __launch_bounds__(kWave * kCompactWaves) blend_backward_compact_
     const unsigned n_live = *a.live_count;
     const float lane_f = static_cast<float>(lane);
     const bool lane0 = lane == 0;
+    // (round 6, measured and withdrawn: XCD x walking a contiguous eighth of the live list, so that the buckets of neighbouring tiles share an L2 --
+    // K11 0.313 -> 0.319 ms at S2, layered scene 3.73 -> 3.80 ms: the kernel is bound by vector issue, and the bands unbalance the XCDs. profiles/r06_ab_k11_xcd_bands.txt)
     for (unsigned item = blockIdx.x * kCompactWaves + wave_in_group; item < n_live; item += gridDim.x * kCompactWaves) {            // wave-uniform
 #ifdef FGS_K11_TIMELINE
         const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();       // 100 MHz, the same clock on every CU (the cycle counter is not)
