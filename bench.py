@@ -388,9 +388,6 @@ def main():
     fence()
     if not sim:
         torch.cuda.reset_peak_memory_stats(device)
-    for i in range(args.warmup):
-        step(i)
-    fence()
     # Stage table: a separate, untimed pass of PROFILE_STEPS iterations with HIP events around every stage. The events themselves cost
     # GPU idle time (~5 us each, ~0.2 ms per iteration with all ~15 stages bracketed: measured with rocprofv3 --kernel-trace), so the
     # timed region below brackets only the dominant stage found here -- the `roofline` figure is still measured live, over the timed steps.
@@ -404,6 +401,12 @@ def main():
     be.profile_enable(False)
     n_prof = PROFILE_STEPS
     dom_stage = max((k for k, v_ in prof.items() if v_[1] > 0 and k in STAGE_KEYS), key=lambda k: prof[k][0] / prof[k][1])
+    # The W untimed warm-up steps come LAST, directly in front of the timed region (round 6): everything above ends in host-side work (reading the
+    # stage profile back) during which the GPU idles for milliseconds, and on some boxes of the pool the first 10-20 iterations after such a pause
+    # run 5-15 % slow (tools/diag_spikes.py: the first 10-iteration window after a pause 2.41-2.49 ms against 2.13-2.14 in steady state, the
+    # round-5 tree alike: clocks, not code) -- the warm-up is there to absorb exactly that.
+    for i in range(args.warmup):
+        step(i)
     be.profile_enable(True, only=dom_stage)
     be.profile_read()
     fence()
