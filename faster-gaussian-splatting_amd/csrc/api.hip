@@ -1114,7 +1114,7 @@ int32_t fgs_profile_read(fgs_stage_time* out, int32_t max_entries) {
 
 #ifdef FGS_DEV_SWITCHES      // the A/B switchboard exists in libfgs_hip_dev.so only (tools/, the variant tests); the product library has no process-wide knobs
 int32_t fgs_debug_set_backward_variant(int32_t variant) {
-    if (variant < 0 || variant > 4) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC), 3 (live list + compacted pixels) or 4 (lane = pixel, matrix-core reduction)");
+    if (variant < 0 || variant > 5) return fail(FGS_ERR_INVALID_ARGUMENT, "variant must be 0 (systolic), 1 (strip), 2 (systolic, global dL/dC), 3 (live list + compacted pixels), 4 (lane = pixel, matrix-core reduction) or 5 (3 with the items of a wave chained through the lanes)");
     fgs::g_backward_variant = variant;
     return FGS_OK;
 }
@@ -1134,6 +1134,7 @@ int32_t fgs_debug_set_option(int32_t key, int32_t value) {
                  fgs::g_tile_row_group = value; return FGS_OK;
         case 11: g_library_bucket_scan = value ? 1 : 0; return FGS_OK;
         case 12: fgs::g_plan_experiment = value & 3; return FGS_OK;
+        case 14: if (value < 1) return fail(FGS_ERR_INVALID_ARGUMENT, "the chained K11 needs at least one wave"); fgs::g_k11_chain_waves = value; return FGS_OK;
         case 5: if (value < 0 || value > 32) return fail(FGS_ERR_INVALID_ARGUMENT, "seq_tiles must be 0 (flattened counting) or 1..32");
                 g_seq_tiles = value; return FGS_OK;
         default: return fail(FGS_ERR_INVALID_ARGUMENT, "unknown option %d", key);

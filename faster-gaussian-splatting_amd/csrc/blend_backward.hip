@@ -683,6 +683,267 @@ namespace fgs {
 #endif
 
 
+#ifdef FGS_DEV_SWITCHES   // A/B exhibit (variant 5, round 6): libfgs_hip_dev.so only -- parity-green, and SLOWER than the kernel above: see the end of this comment
+// ---- K11, chained (round 6): the items of a wave follow each other through the lanes without draining ------------------------------------------
+// The kernel above runs one item -- (tile, 64-Gaussian bucket) -- at a time: n_px live pixels stream through the 64 lanes in n_px + 63 steps, and
+// 63 of the ~240 steps are fill / drain (27 %; removing the drain alone measured -18 % at S2 and -22 % on the layered scene,
+// profiles/r06_k11_chain_ceiling.txt). Here a wave owns a CHAIN of items of the live list (every G-th, G = waves launched) and their pixels form ONE stream of positions:
+// item i occupies positions [S_i, S_i + n_i), followed by sentinel positions (rel = 0: never contribute) up to S_{i+1} = S_i + L_i with
+// L_i = max(round_up_8(n_i + 8), 64). Lane l handles position s - l at step s, so while the tail of item i still travels through the upper lanes the
+// lower lanes already work on item i + 1. A lane changes Gaussians when the boundary passes it -- in GROUPS of eight lanes: the >= 8 sentinels in
+// front of every boundary mean that at step S_{i+1} + 8 g - 1 all eight lanes of group g look at sentinels, so the group flushes its nine sums of
+// item i (72 floats through LDS, two atomic instructions) and takes the parameters of item i + 1 from a shadow register set between two steps;
+// L_i >= 64 keeps the eight group switches of one boundary apart from those of the next. Cost per item: n_i + 8..15 steps + eight switches of
+// ~60 instructions + the wave's single fill / drain spread over its chain, against n_i + 63.
+// LDS must not grow (12.5 KB per wave instead of 7.7 costs this kernel 10 %, same file), so the rings keep their 256 slots = the 64 positions in
+// flight + at most 192 staged ahead: the stream is staged in UNITS of one 64-pixel third of an item (its raw records prefetched into registers a
+// unit ahead) whenever fewer than 16 positions lie in front of lane 0, into the slots the tail has left.
+// MEASURED (profiles/r06_ab_k11_chained.txt): correct on the simulator and on the MI355X (all parity suites), and 12-18 % SLOWER than the kernel
+// above -- S2 0.354 vs 0.310 ms, layered scene 1.74 vs 1.47 ms. The steps are the same 46 vector instructions; what it loses is (a) the prefetch:
+// every register that a load inside the loop defines and a later iteration uses (the unit's raw records, the shadow set) is copied at the loop's
+// back edge by the register allocator, and the copy makes the compiler wait for ALL outstanding loads (`s_waitcnt vmcnt(0)` in front of every block
+// of eight steps) -- three exposed memory latencies per item instead of the kernel above's one; (b) occupancy: 110 registers = 16 waves per CU
+// against 20. Holding a whole item's raw records (one stall per item) needs 134 registers = 12 waves per CU, which costs this kernel 10 % by itself.
+// Kept as an exhibit of the dev library (variant 5) with its tests; the product's K11 stays the kernel above.
+// Which items: wave w chains the items w, w + G, w + 2 G, ... of the live list, G = waves launched = g_k11_chain_waves (fgs_kernels.h: 4096 = 16 resident
+// waves x 256 CUs at 110 registers and 8.5 KB of LDS per wave, so every wave of the launch runs from the first cycle): no queue, no atomics, +-1 item of
+// imbalance. A first version gave each wave 8 CONSECUTIVE items: 2 770 waves at S2, two thirds of the chip, 0.46 ms instead of 0.32
+// (profiles/r06_ab_k11_chained.txt).
+constexpr unsigned kChDesc = 32;                            // descriptor window: lane q mod 32 holds item q of the wave's chain, refilled 16 at a time
+constexpr unsigned kChRing = 256, kChXyBytes = kChRing * 8u, kChInjBase = kChXyBytes, kChPixBase = 2u * kChXyBytes, kChFlushBase = kChPixBase + kChRing * 16u;
+constexpr unsigned kChOffBase = kChFlushBase + 8u * kAccRecordWords * 4u, kChZeroBase = kChOffBase + 8u * 4u, kChBytes = kChZeroBase + 16u;
+__global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const BlendBackwardArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_base[kChBytes];
+    const unsigned lane = lane_id();
+    const float lane_f = static_cast<float>(lane);
+    const unsigned n_live = *a.live_count;
+    const unsigned first_item = blockIdx.x, stride = gridDim.x;
+    if (first_item >= n_live) return;                                                     // wave-uniform
+    const unsigned n_items = wave_uniform((n_live - first_item + stride - 1u) / stride);  // this wave's chain: items first_item + q * stride, q < n_items
+    float2* const s_xy = reinterpret_cast<float2*>(s_base);
+    float2* const s_inj = reinterpret_cast<float2*>(s_base + kChInjBase);
+    float4* const s_pix = reinterpret_cast<float4*>(s_base + kChPixBase);
+    float* const s_flush = reinterpret_cast<float*>(s_base + kChFlushBase);
+    uint32_t* const s_off = reinterpret_cast<uint32_t*>(s_base + kChOffBase);
+    if (lane == 0) *reinterpret_cast<float2*>(s_base + kChZeroBase) = make_float2(0.0f, 0.0f);
+    // positions -64 .. -1 (what the lanes above lane 0 look at until the stream reaches them): sentinels
+    s_pix[kChRing - kWave + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[kChRing - kWave + lane] = make_float2(0.0f, 0.0f);
+
+    // ---- descriptors: lane j holds item j (tile, bucket in tile, list start, list length, checkpoint row) and, later, its first position ----
+    unsigned d_tile = 0, d_tb = 0, d_rx = 0, d_n = 0, d_bucket = 0, d_start = 0;
+    auto load_descriptors = [&](const unsigned q0) {                                       // items q0 .. q0 + 15 of the chain (q0 a multiple of 16) -> lanes (q0 & 31) ..
+        const unsigned base = q0 & (kChDesc - 1u), q = q0 + (lane - base);
+        if (lane >= base && lane < base + 16u && q < n_items) {
+            const uint2 work = a.work_list[first_item + q * stride];
+            d_tile = work.x; d_tb = work.y;
+            const uint2 range = a.ranges[d_tile];
+            d_rx = range.x; d_n = range.y - range.x;
+            d_bucket = (d_tile == 0 ? 0u : a.bucket_offsets[d_tile - 1]) + d_tb;
+        }
+    };
+    load_descriptors(0u);
+    load_descriptors(16u);
+    auto slot_of = [&](const unsigned q) { return static_cast<int>(wave_uniform(q & (kChDesc - 1u))); };
+
+    // ---- the lane's Gaussian: ACTIVE set (what the steps use) and SHADOW set (the next item's, requested early) ----
+    uint32_t prim = 0, hot_word = 0, rep_tile = 0;
+    bool have = false;
+    float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, op = 0.0f;           // op = 0: alpha = 0, nothing passes the test (no item yet / after the last)
+    float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+    uint32_t sh_prim = 0, pf_prim = 0, sh_tile = 0;
+    bool sh_valid = false, pf_valid = false;
+    float4 sh_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sh_r1 = sh_r0, sh_r2 = sh_r0;
+    auto prefetch_prim = [&](const unsigned j) {                                         // the primitive index of item j's Gaussian for this lane
+        pf_valid = false; pf_prim = 0;
+        if (j < n_items) {
+            const int jj = slot_of(j);
+            const unsigned tp = wave_read(d_tb, jj) * kBucket + lane, list_n = wave_read(d_n, jj), list_first = wave_read(d_rx, jj);   // (convergent: all lanes)
+            pf_valid = tp < list_n;
+            if (pf_valid) pf_prim = a.inst_prims[list_first + tp];
+        }
+    };
+    auto load_shadow = [&](const unsigned j) {                                           // item j's records -> shadow (j == n_items: the empty item behind the last)
+        sh_valid = pf_valid; sh_prim = pf_prim;
+        sh_tile = j < n_items ? wave_read(d_tile, slot_of(j)) : 0u;
+        sh_r0 = sh_r1 = sh_r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (sh_valid) { const float4* r = reinterpret_cast<const float4*>(a.rec + sh_prim); sh_r0 = r[0]; sh_r1 = r[1]; sh_r2 = r[2]; }
+        prefetch_prim(j + 1u);
+    };
+
+    float a_c0 = 0.0f, a_c1 = 0.0f, a_c2 = 0.0f, a_h = 0.0f, a_x = 0.0f, a_y = 0.0f, a_xx = 0.0f, a_xy = 0.0f, a_yy = 0.0f;
+    float sT = 0.0f, sS = 0.0f;
+
+    // group g (lanes 8 g .. 8 g + 7) leaves its current item (its nine sums go out, kb:459-470) and takes the shadow set
+    constexpr uint32_t kNoRecord = 0xffffffffu;
+    auto switch_group = [&](const unsigned g, const bool flush) {
+        const bool mine = (lane >> 3) == g;
+        if (flush) {
+            const bool silent = a_h == 0.0f && a_c0 == 0.0f && a_c1 == 0.0f && a_c2 == 0.0f && a_x == 0.0f && a_y == 0.0f
+                                && a_xx == 0.0f && a_xy == 0.0f && a_yy == 0.0f;
+            const float v5 = a.proper_aa ? -2.0f * a_h / op : -2.0f * a_h * (1.0f - op);
+            const float v0 = 2.0f * (ca * a_x + cb * a_y), v1 = 2.0f * (cb * a_x + cc * a_y);
+            const uint32_t rec_off = hot_word != 0u ? static_cast<uint32_t>(a.acc_hot - a.acc) + ((rep_tile % kHotReplicas) * kMaxHot + (hot_word - 1u)) * kAccRecordWords
+                                                    : prim * kAccRecordWords;
+            if (mine) {
+                float* const out = s_flush + (lane & 7u) * kAccRecordWords;
+                out[0] = v0; out[1] = v1; out[2] = a_xx; out[3] = a_xy; out[4] = a_yy; out[5] = v5;
+                out[6] = a_c0 * f0; out[7] = a_c1 * f1; out[8] = a_c2 * f2;
+                s_off[lane & 7u] = (have && !silent) ? rec_off : kNoRecord;
+            }
+            wave_lds_fence();
+            if (lane < 63u) {                                                              // seven records of nine words
+                const uint32_t rec = s_off[lane / kAccRecordWords];
+                if (rec != kNoRecord) unsafeAtomicAdd(a.acc + (size_t)rec + (lane % kAccRecordWords), s_flush[lane]);
+            }
+            if (lane < kAccRecordWords) {                                                  // the eighth
+                const uint32_t rec = s_off[7];
+                if (rec != kNoRecord) unsafeAtomicAdd(a.acc + (size_t)rec + lane, s_flush[63u + lane]);
+            }
+            wave_lds_fence();
+        }
+        if (mine) {
+            prim = sh_prim; have = sh_valid; rep_tile = sh_tile;
+            mx = sh_r0.x; my = sh_r0.y; ca = sh_r0.z; cb = sh_r0.w; cc = sh_r1.x; op = sh_r1.y;
+            const float raw2 = sh_r2.x;
+            col0 = fmaxf(sh_r1.z, 0.0f); col1 = fmaxf(sh_r1.w, 0.0f); col2 = fmaxf(raw2, 0.0f);
+            f0 = sh_r1.z >= 0.0f ? 1.0f : 0.0f; f1 = sh_r1.w >= 0.0f ? 1.0f : 0.0f; f2 = raw2 >= 0.0f ? 1.0f : 0.0f;   // kb:313-318
+            unsigned tx0, tx1, ty0, ty1;
+            tile_rect(__float_as_uint(sh_r2.y), __float_as_uint(sh_r2.z), tx0, tx1, ty0, ty1);
+            hot_word = (have && (tx1 - tx0) * (ty1 - ty0) > kHotFootprint) ? __float_as_uint(sh_r2.w) : 0u;
+            a_c0 = a_c1 = a_c2 = a_h = a_x = a_y = a_xx = a_xy = a_yy = 0.0f;
+        }
+    };
+
+    // ---- staging cursor: the next UNIT = third `st_chunk` of item `st_item`, its raw records in (rg, rc, rk) ----
+    unsigned st_item = 0, st_chunk = 0, st_pos = 0, st_n = 0;       // uniform; st_pos = first position not staged yet, st_n = live pixels of the item so far
+    bool st_done = false;
+    float4 rg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rc = rg, rk = rg;
+    auto fetch_unit = [&]() {                                                             // requests the cursor's unit (nothing waits for it here)
+        if (st_item >= n_items) return;
+        const unsigned tile = wave_read(d_tile, slot_of(st_item)), bucket = wave_read(d_bucket, slot_of(st_item));
+        const unsigned p = st_chunk * kWave + lane;
+        const float4* __restrict__ pix = a.pixrec + (size_t)tile * kTilePixels * 2;
+        rg = pix[2 * p]; rc = pix[2 * p + 1];
+#if FGS_CKPT_NT
+        rk = load_float4_nt(reinterpret_cast<const float*>(a.ckpt + (size_t)bucket * kTilePixels + p));
+#else
+        rk = a.ckpt[(size_t)bucket * kTilePixels + p];
+#endif
+    };
+    auto put_sentinels = [&](const unsigned count) {                                      // `count` <= 64 positions from st_pos on that never contribute
+        if (lane < count) {
+            const unsigned slot = (st_pos + lane) & (kChRing - 1u);
+            s_pix[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s_xy[slot] = make_float2(0.0f, 0.0f); s_inj[slot] = make_float2(0.0f, 0.0f);
+        }
+        st_pos += count;
+    };
+    auto stage_unit = [&]() {
+        if (st_item >= n_items) { put_sentinels(kWave); st_done = true; return; }         // behind the last item: what the lanes see while it drains
+        const unsigned tile = wave_read(d_tile, slot_of(st_item)), first_gaussian = wave_read(d_tb, slot_of(st_item)) * kBucket;
+        const float x0 = static_cast<float>((tile % a.grid_w) * kTileW) + 0.5f, y0 = static_cast<float>((tile / a.grid_w) * kTileH) + 0.5f;
+        const unsigned p = st_chunk * kWave + lane;
+        const unsigned last = __float_as_uint(rc.w);
+        const bool live = last > first_gaussian;                                           // kb:349-380, as in the kernel above
+        const uint64_t m = wave_ballot(live);
+        if (live) {
+            const unsigned slot = (st_pos + lanes_below(m)) & (kChRing - 1u);
+            const unsigned rel = min(last - first_gaussian, static_cast<unsigned>(kBucket));
+            s_pix[slot] = make_float4(rg.x, rg.y, rg.z, static_cast<float>(rel));
+            s_xy[slot] = make_float2(x0 + static_cast<float>(p & (kTileW - 1)), y0 + static_cast<float>(p / kTileW));
+            const float S = (rc.x - rk.x) * rg.x + (rc.y - rk.y) * rg.y + (rc.z - rk.z) * rg.z;                           // kb:371-374
+            s_inj[slot] = make_float2(rk.w, S - rg.w);
+        }
+        const unsigned added = static_cast<unsigned>(__popcll(m));
+        st_pos += added; st_n += added;
+        if (++st_chunk == kTilePixels / kWave) {                                           // the item is complete: pad it, the next one starts behind the pads
+            const unsigned padded = (st_n + 8u + 7u) & ~7u;
+            const unsigned length = padded < static_cast<unsigned>(kWave) ? static_cast<unsigned>(kWave) : padded;
+            put_sentinels(length - st_n);                                                  // 8 .. 63 of them
+            ++st_item; st_chunk = 0; st_n = 0;
+            if (lane == (st_item & (kChDesc - 1u))) d_start = st_pos;                      // (item n_items: where the stream ends)
+        }
+        fetch_unit();
+    };
+
+    // ---- the pipeline ----
+    unsigned ring_at = ((0u - lane) & (kChRing - 1u)) * 8u;                                // byte offset of position (step - lane) in the 8-byte rings
+    const unsigned inj_mul = lane == 0 ? 1u : 0u, inj_add = lane == 0 ? kChInjBase : kChZeroBase;   // lane 0 injects the position's state, the others add zero
+    struct PixRead { float4 g; float2 xy; };
+    auto read_inj = [&]() { return *reinterpret_cast<const float2*>(s_base + (ring_at * inj_mul + inj_add)); };
+    auto read_pix = [&]() {
+        PixRead r;
+        r.xy = *reinterpret_cast<const float2*>(s_base + ring_at);
+        r.g = *reinterpret_cast<const float4*>(s_base + (2u * ring_at + kChPixBase));
+        ring_at = (ring_at + 8u) & (kChXyBytes - 1u);
+        return r;
+    };
+    auto step = [&](const float2 inj, const PixRead pr) {                                 // exactly the step of the kernel above
+        sT = wave_shift_up1_zero(sT) + inj.x;                                               // kb:383-410
+        sS = wave_shift_up1_zero(sS) + inj.y;
+        const float4 px = pr.g;
+        const float rel = px.w;
+        const float dx = mx - pr.xy.x, dy = my - pr.xy.y;
+        const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+        const float alpha = op * __expf(fminf(power, 0.0f));
+        if (lane_f < rel && alpha >= kMinAlphaThreshold) {                                  // kb:412,419-421
+            const float T = sT;
+            const float w = T * alpha;
+            a_c0 += w * px.x; a_c1 += w * px.y; a_c2 += w * px.z;
+            const float cg = col0 * px.x + col1 * px.y + col2 * px.z;
+            sS -= w * cg;                                                                    // kb:429 projected on dL/dC
+            const float oma = 1.0f - alpha;
+            const float oma_rcp = fast_rcp(fmaxf(oma, kOneMinusAlphaEps));
+            const float dl_dalpha = T * cg - sS * oma_rcp;                                   // kb:434-436
+            const float hh = (-0.5f * alpha) * dl_dalpha;
+            const float t = hh * dx, u = hh * dy;
+            a_h += hh; a_x += t; a_y += u;
+            a_xx += t * dx; a_xy += t * dy; a_yy += u * dy;
+            sT = T * oma;
+        }
+    };
+
+    prefetch_prim(0u);
+    load_shadow(0u);                                                                       // item 0's records (and item 1's primitive indices)
+    fetch_unit();
+    unsigned next_shadow = 1;                                                              // the item the shadow set takes next
+    bool shadow_free = false;
+    unsigned sw_item = 0, sw_g = 0;                                                        // the next group switch: group sw_g enters item sw_item
+    float2 inj_a, inj_b;
+    PixRead pix_a, pix_b;
+    bool primed = false;
+    for (unsigned s0 = 0;; s0 += 8u) {                                                     // wave-uniform
+        while (!st_done && st_pos < s0 + 16u) stage_unit();                                // lane 0 never runs into positions that are not there yet
+        wave_lds_fence();
+        if (!primed) { inj_a = read_inj(); pix_a = read_pix(); primed = true; }            // the reads of step 0
+        // the start of item sw_item is known as soon as everything in front of it is staged -- which the 16 positions of look-ahead guarantee
+        if (sw_item <= st_item) {                                                          // d_start of item j is written when item j - 1 completes (item 0: 0)
+            const unsigned start = wave_read(d_start, slot_of(sw_item));
+            if (s0 == start + 8u * sw_g) {                                                 // (the shadow set holds item sw_item since the boundary before)
+                switch_group(sw_g, sw_item > 0u);
+                if (++sw_g == 8u) {
+                    sw_g = 0; ++sw_item; shadow_free = true;
+                    // every group has entered item sw_item - 1, so item sw_item - 2 is staged to its end (an item's start is known only then) and
+                    // flushed: nothing refers to the descriptors of items <= sw_item - 2 any more, while staging may still be busy with the tail of
+                    // item sw_item - 1 and runs at most three items ahead (256 ring slots, items of >= 64 positions). One item into the other half
+                    // of the window, the half the chain has left takes the sixteen items after the next sixteen
+                    if ((sw_item & 15u) == 1u && sw_item > 1u) load_descriptors(sw_item + 15u);
+                }
+            }
+        }
+        if (sw_item > n_items) break;                                                      // every group has left the last item
+        if (shadow_free && next_shadow <= n_items) { load_shadow(next_shadow); ++next_shadow; shadow_free = false; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                                      // eight steps, the reads of a step issued one step ahead
+            inj_b = read_inj(); pix_b = read_pix();
+            step(inj_a, pix_a);
+            inj_a = read_inj(); pix_a = read_pix();
+            step(inj_b, pix_b);
+        }
+    }
+}
+
+#endif  // FGS_DEV_SWITCHES (variant 5)
+
 #ifdef FGS_DEV_SWITCHES   // A/B exhibit (variant 4): libfgs_hip_dev.so only
 // ---- variant 4: lane = PIXEL, reduction over the pixels on the matrix cores ----------------------------------------------------------------
 // Measured in round 4 (tools/pair_stats.sh, profiles/r04_k11_pair_efficiency.txt): of the (pixel, Gaussian) lane-steps the systolic kernel above
@@ -1056,6 +1317,12 @@ hipError_t launch_blend_backward(const BlendBackwardArgs& a_in, hipStream_t s) {
         const unsigned cap_blocks = static_cast<unsigned>(g_k11m_max_blocks.load());
         const unsigned blocks = a.n_buckets_cap < cap_blocks ? a.n_buckets_cap : cap_blocks;
         hipLaunchKernelGGL(blend_backward_pixel_kernel, dim3(blocks), dim3(kWave), 0, s, a);
+        hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.variant == 5) {        // chained (round 6): option 14 = its number of waves (tests shorten it so that chains get long)
+        const unsigned chain_waves = static_cast<unsigned>(static_cast<int>(g_k11_chain_waves));
+        hipLaunchKernelGGL(blend_backward_chained_kernel, dim3(a.n_buckets_cap < chain_waves ? a.n_buckets_cap : chain_waves), dim3(kWave), 0, s, a);
         hipLaunchKernelGGL(fold_hot_accumulators_kernel, dim3(9u * kMaxHot / 256u), dim3(256), 0, s, a);
         return hipGetLastError();
     }

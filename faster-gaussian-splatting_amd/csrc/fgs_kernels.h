@@ -75,6 +75,9 @@ constexpr unsigned kPlannedBlocks = 254u;
 constexpr unsigned kColumnsTopDown = 252u, kColumnsBottomUp = 251u;   // one vertical strip of the image per XCD, walked row by row
 constexpr unsigned kBandsThroughPlan = 253u;         // A/B only: the round-1 bands, but with the plan's dependent load on every workgroup's path
 FGS_SWITCH(g_tile_row_group, static_cast<int>(kColumnsTopDown));   // blend_forward.hip: tile -> workgroup mapping (254: device-side block plan; 0: round-1 bands; 1..64 row groups)
+#ifdef FGS_DEV_SWITCHES
+FGS_SWITCH(g_k11_chain_waves, 4096);                 // blend_backward.hip, option 14: waves of the chained K11 exhibit (variant 5); 4096 = 16 resident waves x 256 CUs
+#endif
 FGS_SWITCH(g_plan_experiment, 0);                    // binning.hip, option 12: 1 = blocks unsorted and dealt statically (A/B of the deal itself)
 // radix_sort.hip: stable LSD radix sort of (key, uint32) pairs sized for these two sorts
 FGS_SWITCH(g_depth_sort_mode, 1);                    // option 9 -- bit 0: key range / 9-bit digits, bit 1: 2048-item workgroups (radix_sort.hip)

@@ -131,9 +131,9 @@ def test_partial_tiles_sh_degrees_antialiasing(hip_backend, oracle, w, h, K, aa)
     assert helpers.rel_inf(dens.cpu().numpy(), dens_o) < 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5])
 def test_blend_backward_variants_agree_with_oracle(hip_dev_backend, oracle, variant):
-    """All formulations of K11 (0 / 2 systolic lane = Gaussian, 1 strip lane = pixel, 3 the product's, 4 lane = pixel + matrix cores) against the oracle
+    """All formulations of K11 (0 / 2 systolic lane = Gaussian, 1 strip lane = pixel, 3 the product's, 4 lane = pixel + matrix cores, 5 the product's with the items of a wave chained through the lanes) against the oracle
     on a deep scene -- on libfgs_hip_dev.so: the product library carries variant 3 only."""
     hip_backend = hip_dev_backend
     p, v = make_s0(seed=11, n=1500)
@@ -211,7 +211,7 @@ def test_uninitialised_scratch_is_harmless(hip_dev_backend, oracle):
     gi = np.random.default_rng(9).standard_normal(f['image'].shape).astype(np.float32)
     g = oracle.backward(f, S, gi)
     truth = oracle.forward_backward_f64(f, S, gi)
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5):
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             grads = be.backward(torch.empty(0, device=DEV), torch.from_numpy(gi).to(DEV), res.image, dp['means'], dp['scales'],

@@ -148,7 +148,7 @@ def test_long_tile_lists_span_several_batches(sim_backend, oracle):
     assert (f['ranges'][:, 1] - f['ranges'][:, 0]).max() > 400
 
 
-@pytest.mark.parametrize('variant', [1, 4])
+@pytest.mark.parametrize('variant', [1, 4, 5])
 def test_strip_backward_variant(sim_backend, oracle, variant):
     """The default is the systolic formulation; the lane = pixel ones (1: DPP reductions, 4: matrix-core reduction through an LDS transposition, the
     matrix instruction emulated as the fmaf chain it is) stay selectable and must give the same gradients."""
@@ -161,6 +161,23 @@ def test_strip_backward_variant(sim_backend, oracle, variant):
         sim_backend.lib.fgs_debug_set_backward_variant(3)
 
 
+@pytest.mark.parametrize('waves', [1, 3])
+def test_chained_backward_variant_on_long_chains(sim_backend, oracle, waves):
+    """K11 variant 5 (dev library exhibit, round 6): the items of a wave follow each other through the lanes without draining. With 1 / 3 waves
+    (option 14) a wave chains 79 / 27 items: the descriptor window (32 lanes, refilled 16 at a time) wraps four times, items of every length follow
+    each other. Same gradients as the oracle."""
+    sim_backend.lib.fgs_debug_set_backward_variant(5)
+    assert sim_backend.lib.fgs_debug_set_option(14, waves) == 0
+    try:
+        p, v = make_s0(seed=11, n=1500)
+        p['means'][:, :2] *= 0.3
+        p['opacities'] -= 2.0
+        _run(sim_backend, oracle, p, v)
+    finally:
+        sim_backend.lib.fgs_debug_set_backward_variant(3)
+        sim_backend.lib.fgs_debug_set_option(14, 4096)
+
+
 def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
     """Scratch buffers pre-filled with 0xFF (NaN): checkpoints of finished pixels, records of invisible primitives etc. are
     never written by the forward pass and must never leak into a result (regression: 0 * NaN in the branch-free K11)."""
@@ -169,7 +186,7 @@ def test_uninitialised_scratch_is_harmless(sim_backend, oracle):
     p['opacities'] -= 2.5
     p['means'][:50, 2] = -10.0                      # invisible primitives: their records stay poisoned
     be = helpers.poisoned(sim_backend)
-    for variant in (2, 3, 4):                       # the default, round 1's main form and the matrix-core form (0 / 1: on hardware, test_gpu_parity.py)
+    for variant in (2, 3, 4, 5):                    # the default, round 1's main form, the matrix-core form, the chained form (0 / 1: on hardware, test_gpu_parity.py)
         be.lib.fgs_debug_set_backward_variant(variant)
         try:
             _run(be, oracle, p, v)
