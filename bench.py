@@ -287,6 +287,13 @@ def main():
                      'FGS_HIP_LIBRARY=$PWD/faster-gaussian-splatting_amd/libfgs_hip_dev.so python bench.py ...')
         be.lib.fgs_debug_set_backward_variant(int(os.environ['FGS_BACKWARD_VARIANT']))
 
+    if 'FGS_DEBUG_OPTIONS' in os.environ:         # "key=value,key=value" for fgs_debug_set_option (dev library only: A/B sweeps of tools/)
+        if not hasattr(be.lib, 'fgs_debug_set_option'):
+            sys.exit('FGS_DEBUG_OPTIONS needs the dev library: FGS_HIP_LIBRARY=$PWD/faster-gaussian-splatting_amd/libfgs_hip_dev.so')
+        for kv in os.environ['FGS_DEBUG_OPTIONS'].split(','):
+            k_, v_ = kv.split('=')
+            if be.lib.fgs_debug_set_option(int(k_), int(v_)) != 0:
+                sys.exit(f'fgs_debug_set_option({k_}, {v_}) failed: ' + be.lib.fgs_last_error().decode())
     g = T.Gaussians(params, device)
     g.training_setup(training_cameras_extent=5.0)
     n = g.means.shape[0]

@@ -698,12 +698,13 @@ namespace fgs {
 // LDS must not grow (12.5 KB per wave instead of 7.7 costs this kernel 10 %, same file), so the rings keep their 256 slots = the 64 positions in
 // flight + at most 192 staged ahead: the stream is staged in UNITS of one 64-pixel third of an item (its raw records prefetched into registers a
 // unit ahead) whenever fewer than 16 positions lie in front of lane 0, into the slots the tail has left.
-// MEASURED (profiles/r06_ab_k11_chained.txt): correct on the simulator and on the MI355X (all parity suites), and 12-18 % SLOWER than the kernel
-// above -- S2 0.354 vs 0.310 ms, layered scene 1.74 vs 1.47 ms. The steps are the same 46 vector instructions; what it loses is (a) the prefetch:
-// every register that a load inside the loop defines and a later iteration uses (the unit's raw records, the shadow set) is copied at the loop's
-// back edge by the register allocator, and the copy makes the compiler wait for ALL outstanding loads (`s_waitcnt vmcnt(0)` in front of every block
-// of eight steps) -- three exposed memory latencies per item instead of the kernel above's one; (b) occupancy: 110 registers = 16 waves per CU
-// against 20. Holding a whole item's raw records (one stall per item) needs 134 registers = 12 waves per CU, which costs this kernel 10 % by itself.
+// MEASURED (profiles/r06_ab_k11_chained.txt, r06_k11_variants_pmc.txt): correct on the simulator and on the MI355X (all parity suites), and never faster than
+// the kernel above. A first version defined its prefetch registers inside the loop that runs the steps: the register allocator copies such registers at
+// the loop's back edge and the copy waits for ALL outstanding loads (`s_waitcnt vmcnt(0)` in front of every block of eight steps): S2 0.354 vs 0.310 ms,
+// layered scene 1.74 vs 1.47. This version issues every load at the outer level of a loop nest (104 registers, no wait left in the step loop): it executes
+// 13 % fewer vector instructions than the kernel above and still takes 0.344 / 1.66 ms with 4096 waves -- on average 12 waves per CU are resident instead
+// of 19 (16 fit; static chains end at different times), the bookkeeping per block of eight steps adds 60 % scalar instructions, the group switches their
+// share. With 16 384 waves (shorter chains) it reaches the kernel above on the layered scene (1.46 ms) and stays behind it at S2 (0.342 vs 0.317).
 // Kept as an exhibit of the dev library (variant 5) with its tests; the product's K11 stays the kernel above.
 // Which items: wave w chains the items w, w + G, w + 2 G, ... of the live list, G = waves launched = g_k11_chain_waves (fgs_kernels.h: 4096 = 16 resident
 // waves x 256 CUs at 110 registers and 8.5 KB of LDS per wave, so every wave of the launch runs from the first cycle): no queue, no atomics, +-1 item of
@@ -712,7 +713,11 @@ namespace fgs {
 constexpr unsigned kChDesc = 32;                            // descriptor window: lane q mod 32 holds item q of the wave's chain, refilled 16 at a time
 constexpr unsigned kChRing = 256, kChXyBytes = kChRing * 8u, kChInjBase = kChXyBytes, kChPixBase = 2u * kChXyBytes, kChFlushBase = kChPixBase + kChRing * 16u;
 constexpr unsigned kChOffBase = kChFlushBase + 8u * kAccRecordWords * 4u, kChZeroBase = kChOffBase + 8u * 4u, kChBytes = kChZeroBase + 16u;
-__global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const BlendBackwardArgs a) {
+#ifndef FGS_K11_CHAIN_WAVES_PER_SIMD
+#define FGS_K11_CHAIN_WAVES_PER_SIMD 4      // register budget 128: without the cap the compiler takes 143 (3 waves per SIMD, 12 per CU: K11 loses 10 % there)
+#endif
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(FGS_K11_CHAIN_WAVES_PER_SIMD, FGS_K11_CHAIN_WAVES_PER_SIMD)))
+blend_backward_chained_kernel(const BlendBackwardArgs a) {
     __shared__ __attribute__((aligned(16))) char s_base[kChBytes];
     const unsigned lane = lane_id();
     const float lane_f = static_cast<float>(lane);
@@ -750,9 +755,13 @@ __global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const Ble
     bool have = false;
     float mx = 0.0f, my = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, op = 0.0f;           // op = 0: alpha = 0, nothing passes the test (no item yet / after the last)
     float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-    uint32_t sh_prim = 0, pf_prim = 0, sh_tile = 0;
-    bool sh_valid = false, pf_valid = false;
-    float4 sh_r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sh_r1 = sh_r0, sh_r2 = sh_r0;
+    // The SHADOW set: the next item's Gaussian, eleven registers per lane. All loads of this kernel are issued at the OUTER level of the loop nest below:
+    // a register that a load defines inside the loop that also runs the steps is copied at that loop's back edge, and the copy makes the compiler
+    // wait for every outstanding load in front of every block of steps (the first version of this kernel: profiles/r06_ab_k11_chained.txt).
+    struct Shadow { uint32_t prim, tile, hot; bool valid; float mx, my, ca, cb, cc, op, c0, c1, c2; };
+    Shadow sh{0u, 0u, 0u, false, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t pf_prim = 0;
+    bool pf_valid = false;
     auto prefetch_prim = [&](const unsigned j) {                                         // the primitive index of item j's Gaussian for this lane
         pf_valid = false; pf_prim = 0;
         if (j < n_items) {
@@ -762,11 +771,15 @@ __global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const Ble
             if (pf_valid) pf_prim = a.inst_prims[list_first + tp];
         }
     };
-    auto load_shadow = [&](const unsigned j) {                                           // item j's records -> shadow (j == n_items: the empty item behind the last)
-        sh_valid = pf_valid; sh_prim = pf_prim;
-        sh_tile = j < n_items ? wave_read(d_tile, slot_of(j)) : 0u;
-        sh_r0 = sh_r1 = sh_r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (sh_valid) { const float4* r = reinterpret_cast<const float4*>(a.rec + sh_prim); sh_r0 = r[0]; sh_r1 = r[1]; sh_r2 = r[2]; }
+    auto load_shadow = [&](const unsigned j) {                                           // item j's record (j == n_items: the empty item behind the last)
+        sh.valid = pf_valid; sh.prim = pf_prim;
+        sh.tile = j < n_items ? wave_read(d_tile, slot_of(j)) : 0u;
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+        if (sh.valid) { const float4* r = reinterpret_cast<const float4*>(a.rec + sh.prim); r0 = r[0]; r1 = r[1]; r2 = r[2]; }
+        sh.mx = r0.x; sh.my = r0.y; sh.ca = r0.z; sh.cb = r0.w; sh.cc = r1.x; sh.op = r1.y; sh.c0 = r1.z; sh.c1 = r1.w; sh.c2 = r2.x;
+        unsigned tx0, tx1, ty0, ty1;
+        tile_rect(__float_as_uint(r2.y), __float_as_uint(r2.z), tx0, tx1, ty0, ty1);
+        sh.hot = (sh.valid && (tx1 - tx0) * (ty1 - ty0) > kHotFootprint) ? __float_as_uint(r2.w) : 0u;
         prefetch_prim(j + 1u);
     };
 
@@ -802,14 +815,10 @@ __global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const Ble
             wave_lds_fence();
         }
         if (mine) {
-            prim = sh_prim; have = sh_valid; rep_tile = sh_tile;
-            mx = sh_r0.x; my = sh_r0.y; ca = sh_r0.z; cb = sh_r0.w; cc = sh_r1.x; op = sh_r1.y;
-            const float raw2 = sh_r2.x;
-            col0 = fmaxf(sh_r1.z, 0.0f); col1 = fmaxf(sh_r1.w, 0.0f); col2 = fmaxf(raw2, 0.0f);
-            f0 = sh_r1.z >= 0.0f ? 1.0f : 0.0f; f1 = sh_r1.w >= 0.0f ? 1.0f : 0.0f; f2 = raw2 >= 0.0f ? 1.0f : 0.0f;   // kb:313-318
-            unsigned tx0, tx1, ty0, ty1;
-            tile_rect(__float_as_uint(sh_r2.y), __float_as_uint(sh_r2.z), tx0, tx1, ty0, ty1);
-            hot_word = (have && (tx1 - tx0) * (ty1 - ty0) > kHotFootprint) ? __float_as_uint(sh_r2.w) : 0u;
+            prim = sh.prim; have = sh.valid; rep_tile = sh.tile; hot_word = sh.hot;
+            mx = sh.mx; my = sh.my; ca = sh.ca; cb = sh.cb; cc = sh.cc; op = sh.op;
+            col0 = fmaxf(sh.c0, 0.0f); col1 = fmaxf(sh.c1, 0.0f); col2 = fmaxf(sh.c2, 0.0f);
+            f0 = sh.c0 >= 0.0f ? 1.0f : 0.0f; f1 = sh.c1 >= 0.0f ? 1.0f : 0.0f; f2 = sh.c2 >= 0.0f ? 1.0f : 0.0f;   // kb:313-318
             a_c0 = a_c1 = a_c2 = a_h = a_x = a_y = a_xx = a_xy = a_yy = 0.0f;
         }
     };
@@ -903,42 +912,51 @@ __global__ void __launch_bounds__(kWave) blend_backward_chained_kernel(const Ble
     };
 
     prefetch_prim(0u);
-    load_shadow(0u);                                                                       // item 0's records (and item 1's primitive indices)
     fetch_unit();
-    unsigned next_shadow = 1;                                                              // the item the shadow set takes next
-    bool shadow_free = false;
+    unsigned next_shadow = 0;                                                              // items < next_shadow have their records in a shadow set
     unsigned sw_item = 0, sw_g = 0;                                                        // the next group switch: group sw_g enters item sw_item
+    unsigned s0 = 0;                                                                       // the next step (a multiple of 8)
+    unsigned desc_due = 0;                                                                 // first item of the half window to refill (0: none)
     float2 inj_a, inj_b;
     PixRead pix_a, pix_b;
     bool primed = false;
-    for (unsigned s0 = 0;; s0 += 8u) {                                                     // wave-uniform
+    for (;;) {                                                                             // OUTER level: everything that loads
         while (!st_done && st_pos < s0 + 16u) stage_unit();                                // lane 0 never runs into positions that are not there yet
         wave_lds_fence();
+        // the shadow set is free once every group has entered the item it holds: it then takes the next one, a whole item's length before its first use
+        if (desc_due != 0u) { load_descriptors(desc_due); desc_due = 0u; }
+        if (next_shadow <= n_items && next_shadow <= sw_item) { load_shadow(next_shadow); ++next_shadow; }
         if (!primed) { inj_a = read_inj(); pix_a = read_pix(); primed = true; }            // the reads of step 0
-        // the start of item sw_item is known as soon as everything in front of it is staged -- which the 16 positions of look-ahead guarantee
-        if (sw_item <= st_item) {                                                          // d_start of item j is written when item j - 1 completes (item 0: 0)
-            const unsigned start = wave_read(d_start, slot_of(sw_item));
-            if (s0 == start + 8u * sw_g) {                                                 // (the shadow set holds item sw_item since the boundary before)
-                switch_group(sw_g, sw_item > 0u);
-                if (++sw_g == 8u) {
-                    sw_g = 0; ++sw_item; shadow_free = true;
-                    // every group has entered item sw_item - 1, so item sw_item - 2 is staged to its end (an item's start is known only then) and
-                    // flushed: nothing refers to the descriptors of items <= sw_item - 2 any more, while staging may still be busy with the tail of
-                    // item sw_item - 1 and runs at most three items ahead (256 ring slots, items of >= 64 positions). One item into the other half
-                    // of the window, the half the chain has left takes the sixteen items after the next sixteen
-                    if ((sw_item & 15u) == 1u && sw_item > 1u) load_descriptors(sw_item + 15u);
+        bool finished = false;
+        for (;;) {                                                                         // INNER level: group switches and steps, no load is issued here
+            if (sw_item <= st_item) {                                                      // (d_start of item j is written when item j - 1 completes; item 0: 0)
+                const unsigned start = wave_read(d_start, slot_of(sw_item));
+                if (s0 == start + 8u * sw_g) {
+                    if (sw_item >= next_shadow) break;                                     // its record is not requested yet: outer level
+                    switch_group(sw_g, sw_item > 0u);
+                    if (++sw_g == 8u) {
+                        sw_g = 0; ++sw_item;
+                        // every group has entered item sw_item - 1, so item sw_item - 2 is staged to its end (an item's start is known only then) and
+                        // flushed: nothing refers to the descriptors of items <= sw_item - 2 any more, while staging may still be busy with the tail of
+                        // item sw_item - 1 and runs at most three items ahead (256 ring slots, items of >= 64 positions). One item into the other half
+                        // of the window, the half the chain has left takes the sixteen items after the next sixteen
+                        if (sw_item > n_items) { finished = true; break; }                  // every group has left the last item
+                        if ((sw_item & 15u) == 1u && sw_item > 1u) { desc_due = sw_item + 15u; break; }      // (a load: outer level)
+                    }
                 }
             }
-        }
-        if (sw_item > n_items) break;                                                      // every group has left the last item
-        if (shadow_free && next_shadow <= n_items) { load_shadow(next_shadow); ++next_shadow; shadow_free = false; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                                      // eight steps, the reads of a step issued one step ahead
-            inj_b = read_inj(); pix_b = read_pix();
-            step(inj_a, pix_a);
-            inj_a = read_inj(); pix_a = read_pix();
-            step(inj_b, pix_b);
+            for (int i = 0; i < 4; ++i) {                                                  // eight steps, the reads of a step issued one step ahead
+                inj_b = read_inj(); pix_b = read_pix();
+                step(inj_a, pix_a);
+                inj_a = read_inj(); pix_a = read_pix();
+                step(inj_b, pix_b);
+            }
+            s0 += 8u;
+            if (!st_done && st_pos < s0 + 16u) break;                                      // the stream runs low: outer level
+            if (next_shadow <= n_items && next_shadow <= sw_item) break;                   // the shadow set fell free: outer level
         }
+        if (finished) break;
     }
 }
 
