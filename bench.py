@@ -485,37 +485,40 @@ def main():
         dist.all_gather_object(idents, ident)
         if not (sim or shared) and len(set(idents)) != world:
             raise SystemExit(f'bench.py --gpus {world}: ranks share devices ({idents}); one process per GPU is required')
-        link_gbs = 76.8
+        try:      # (a measurement on the side: it must never take the scaling run down with it)
+            link_gbs = 76.8
 
-        def timed(fn, reps=3):
-            fn(); fence()                                   # warm-up (communicator set-up, first-touch)
-            t0_ = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            fence()
-            t_ = torch.tensor([(time.perf_counter() - t0_) / reps], dtype=torch.float64, device=device)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            return float(t_.item()) * 1e3
-        vis_t = torch.tensor([float(np.mean([s_['V'] for s_ in stats.values()]))], dtype=torch.float64, device=device)
-        dist.all_reduce(vis_t)                                  # every rank must name the same sizes: the mean over the ranks' own views
-        vis = float(vis_t.item()) / world
-        arena = torch.zeros(59 * n, dtype=torch.float32, device=device)
-        per_peer = int(vis / world)
-        rec_out, rec_in = torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device), torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device)
-        acc_out, acc_in = torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device), torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device)
-        ms_allreduce = timed(lambda: dist.all_reduce(arena))
-        ms_records = timed(lambda: dist.all_to_all_single(rec_in, rec_out))
-        ms_accs = timed(lambda: dist.all_to_all_single(acc_in, acc_out))
-        predict = lambda nbytes: nbytes / ((world - 1) * link_gbs * 1e9) * 1e3
-        dry = {'what': 'one dry exchange of each kind at the real sizes of this step (no rendering), MAX over ranks of the mean of 3 calls after 1 warm-up call',
-               'devices': idents, 'link_model_GBps_per_direction': link_gbs,
-               'allreduce_gradient_arena': {'bytes': 236.0 * n, 'wire_bytes_per_rank': wire_bytes('allreduce'), 'measured_ms': ms_allreduce, 'predicted_wire_ms': predict(wire_bytes('allreduce'))},
-               'sharded_all_to_all': {'records_bytes_per_rank': 56.0 * per_peer * (world - 1), 'accumulator_bytes_per_rank': 36.0 * per_peer * (world - 1),
-                                      'measured_ms_records': ms_records, 'measured_ms_accumulators': ms_accs,
-                                      'predicted_wire_ms': predict((56.0 + 36.0) * per_peer * (world - 1))},
-               'note': 'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6; gloo / shared-device runs measure host memory, not xGMI' if (sim or shared) else
-                       'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6'}
-        del arena, rec_out, rec_in, acc_out, acc_in
+            def timed(fn, reps=3):
+                fn(); fence()                                   # warm-up (communicator set-up, first-touch)
+                t0_ = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                fence()
+                t_ = torch.tensor([(time.perf_counter() - t0_) / reps], dtype=torch.float64, device=device)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return float(t_.item()) * 1e3
+            vis_t = torch.tensor([float(np.mean([s_['V'] for s_ in stats.values()]))], dtype=torch.float64, device=device)
+            dist.all_reduce(vis_t)                                  # every rank must name the same sizes: the mean over the ranks' own views
+            vis = float(vis_t.item()) / world
+            arena = torch.zeros(59 * n, dtype=torch.float32, device=device)
+            per_peer = int(vis / world)
+            rec_out, rec_in = torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device), torch.zeros(per_peer * world * 56, dtype=torch.uint8, device=device)
+            acc_out, acc_in = torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device), torch.zeros(per_peer * world * 9, dtype=torch.float32, device=device)
+            ms_allreduce = timed(lambda: dist.all_reduce(arena))
+            ms_records = timed(lambda: dist.all_to_all_single(rec_in, rec_out))
+            ms_accs = timed(lambda: dist.all_to_all_single(acc_in, acc_out))
+            predict = lambda nbytes: nbytes / ((world - 1) * link_gbs * 1e9) * 1e3
+            dry = {'what': 'one dry exchange of each kind at the real sizes of this step (no rendering), MAX over ranks of the mean of 3 calls after 1 warm-up call',
+                   'devices': idents, 'link_model_GBps_per_direction': link_gbs,
+                   'allreduce_gradient_arena': {'bytes': 236.0 * n, 'wire_bytes_per_rank': wire_bytes('allreduce'), 'measured_ms': ms_allreduce, 'predicted_wire_ms': predict(wire_bytes('allreduce'))},
+                   'sharded_all_to_all': {'records_bytes_per_rank': 56.0 * per_peer * (world - 1), 'accumulator_bytes_per_rank': 36.0 * per_peer * (world - 1),
+                                          'measured_ms_records': ms_records, 'measured_ms_accumulators': ms_accs,
+                                          'predicted_wire_ms': predict((56.0 + 36.0) * per_peer * (world - 1))},
+                   'note': 'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6; gloo / shared-device runs measure host memory, not xGMI' if (sim or shared) else
+                           'predicted = bytes a rank sends / ((G - 1) links x 76.8 GB/s), the model behind the table of DESIGN.md section 6'}
+            del arena, rec_out, rec_in, acc_out, acc_in
+        except Exception as exc:
+            dry = {'what': 'failed', 'error': f'{type(exc).__name__}: {exc}', 'devices': idents}
 
     # N > 1: the other exchange as well (north star: all-reduce of the per-Gaussian gradients; default: Gaussian-sharded records)
     other = None
