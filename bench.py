@@ -390,6 +390,30 @@ def main():
     # Setup, outside warm-up and timing: one iteration per view of this rank, so that the scratch blobs (sized per view through the resize
     # callback) and torch's caching allocator have reached their steady state whatever --warmup is. A view first met inside the timed region
     # costs a device allocation there (one 20-step block read 2.63 ms against 2.34-2.35 for the others, profiles/README.md round 3).
+    dp_fallback = None
+    if vp is not None and world > 1 and args.dp_mode != 'allreduce':
+        # First contact with the fabric: if the default exchange RAISES on its first two steps (an argument RCCL refuses, say), every rank falls back to
+        # north star's all-reduce of the gradient arena instead of ending the scaling run without a number -- the line then says so (`dp_fallback`).
+        # A rank that hangs in a collective is the watchdog's business, not this block's.
+        failure = ''
+        try:
+            if sim and os.environ.get('FGS_BENCH_SIM_FAIL_MODE') == args.dp_mode:      # tests/test_bench_multirank.py
+                raise RuntimeError(f'failure of --dp-mode {args.dp_mode} injected by FGS_BENCH_SIM_FAIL_MODE')
+            for i in range(2):
+                step(i)
+            if not sim:
+                torch.cuda.synchronize(device)
+        except Exception as exc:      # noqa: BLE001 -- whatever the exchange raised
+            failure = f'{type(exc).__name__}: {exc}'
+            print(f'bench.py rank {rank}: --dp-mode {args.dp_mode} failed on its first steps ({failure}); falling back to allreduce', file=sys.stderr)
+        bad = torch.tensor([1.0 if failure else 0.0], device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) > 0:
+            dp_fallback = {'from': args.dp_mode, 'to': 'allreduce', 'error_on_this_rank': failure or None}
+            args.dp_mode = 'allreduce'
+            vp = make_trainer('allreduce')
+            if hasattr(vp, 'time_comm'):
+                vp.time_comm = True
     for i in range(len(my_views) if vp is None else 2):
         step(i)
     fence()
@@ -522,21 +546,24 @@ def main():
 
     # N > 1: the other exchange as well (north star: all-reduce of the per-Gaussian gradients; default: Gaussian-sharded records)
     other = None
-    if vp is not None and world > 1 and not args.no_extras:
+    if vp is not None and world > 1 and not args.no_extras and dp_fallback is None:
         other_mode = 'allreduce' if args.dp_mode == 'sharded' else 'sharded'
-        vp2 = make_trainer(other_mode)
-        for i in range(2):
-            dp_step(vp2, other_mode, i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            dp_step(vp2, other_mode, 2 + i)
-        fence()
-        t_other = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        dist.all_reduce(t_other, op=dist.ReduceOp.MAX)
-        other = {'dp_mode': other_mode, 'iters_per_sec': args.steps * world / float(t_other.item()), 'ms_per_step': float(t_other.item()) / args.steps * 1e3,
-                 'wire_bytes_per_rank_per_step': wire_bytes(other_mode)}
-        del vp2
+        try:      # (a second measurement beside the headline: it must not take the line down with it)
+            vp2 = make_trainer(other_mode)
+            for i in range(2):
+                dp_step(vp2, other_mode, i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                dp_step(vp2, other_mode, 2 + i)
+            fence()
+            t_other = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(t_other, op=dist.ReduceOp.MAX)
+            other = {'dp_mode': other_mode, 'iters_per_sec': args.steps * world / float(t_other.item()), 'ms_per_step': float(t_other.item()) / args.steps * 1e3,
+                     'wire_bytes_per_rank_per_step': wire_bytes(other_mode)}
+            del vp2
+        except Exception as exc:      # noqa: BLE001
+            other = {'dp_mode': other_mode, 'error': f'{type(exc).__name__}: {exc}'}
 
     used = [my_views[(args.warmup + PROFILE_STEPS + i) % len(my_views)] for i in range(args.steps)]
     mean = lambda key: float(np.mean([stats[id(v)][key] for v in used]))
@@ -655,6 +682,8 @@ def main():
         'stage_algorithmic_GBps': {k: stage_bytes[k] / (per_launch[k] * 1e-3) / 1e9 for k in per_launch if k in stage_bytes and per_launch[k] > 0},
     }
 
+    if dp_fallback is not None:
+        out['dp_fallback'] = dp_fallback
     if other is not None:
         out['other_exchange'] = other
     if dry is not None:

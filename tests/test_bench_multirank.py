@@ -56,3 +56,15 @@ def test_bench_multirank_a_failing_rank_fails_the_job_and_its_stderr_is_relayed(
     assert r.returncode != 0
     assert r.stdout.strip() == ''                                           # no line at all rather than a wrong one
     assert 'failure injected by FGS_BENCH_SIM_FAIL_RANK' in r.stderr and 'stderr.log' in r.stderr     # the rank's own traceback, relayed by the launcher
+
+
+def test_bench_multirank_falls_back_to_allreduce_when_the_default_exchange_raises():
+    """First contact with the fabric must end with a number: an exchange that RAISES on its first steps is replaced by north star's all-reduce
+    on every rank, and the line says so."""
+    r = _run(['--gpus', '2', '--dp-mode', 'sharded'], env={'FGS_BENCH_SIM_FAIL_MODE': 'sharded'}, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d['dp_fallback']['from'] == 'sharded' and d['dp_fallback']['to'] == 'allreduce' and 'FGS_BENCH_SIM_FAIL_MODE' in d['dp_fallback']['error_on_this_rank']
+    assert d['config']['dp_mode'] == 'allreduce' and 'allreduce' in d['config']['parallelism'] and d['n_gpus'] == 2 and d['value'] > 0
+    assert all(x['n_gaussians_on_rank'] == 300 for x in d['config']['ranks'])      # replicated parameters: the all-reduce step ran
+    assert 'other_exchange' not in d                                              # the failed mode is not tried a second time
