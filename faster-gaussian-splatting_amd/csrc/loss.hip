@@ -183,19 +183,28 @@ __global__ void FGS_LOSS_FWD_BOUNDS ssim_forward_kernel(const LossArgs a, const 
     }
 }
 
-__global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, const unsigned n_blocks) {
-    __shared__ float s_red[2][4];
+// The forward kernel's per-workgroup partial sums -> means and the scalar loss, in a fixed order (one 256-thread workgroup; s_red: 8 floats of LDS).
+__device__ __forceinline__ void reduce_loss_partials(const LossArgs& a, const unsigned n_blocks, float* s_red) {
     const float2* __restrict__ part = reinterpret_cast<const float2*>(a.partials);
     float l1 = 0.0f, ss = 0.0f;
     for (unsigned b = threadIdx.x; b < n_blocks; b += 256u) { const float2 v = part[b]; l1 += v.x; ss += v.y; }
-    const float tl = block_sum_256(l1, s_red[0]);
-    const float ts = block_sum_256(ss, s_red[1]);
+    const float tl = block_sum_256(l1, s_red);
+    const float ts = block_sum_256(ss, s_red + 4);
     if (threadIdx.x == 255) {
         const float n_total = 3.0f * static_cast<float>(a.width) * static_cast<float>(a.height);
         const float l1 = tl / n_total, ssim = ts / n_total;
         a.sums[0] = l1; a.sums[1] = ssim;                                         // means, and the scalar loss itself:
         a.sums[2] = a.lambda_l1 * l1 + a.lambda_dssim * (1.0f - ssim);           // no framework-side arithmetic kernels
     }
+}
+
+#ifndef FGS_LOSS_SEPARATE_REDUCE
+#define FGS_LOSS_SEPARATE_REDUCE 0       // A/B knob: 1 = the reduction as a launch of its own between the two filter kernels (until round 6)
+#endif
+// Loss value only (no gradient asked for). With a gradient, workgroup 0 of the backward kernel does this on its way in (round 6: one launch less).
+__global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, const unsigned n_blocks) {
+    __shared__ float s_red[8];
+    reduce_loss_partials(a, n_blocks, s_red);
 }
 
 // The backward pass has its own tile (round 4): it stages three maps instead of two and keeps three filtered maps instead of five, so a 64 x 32 tile
@@ -211,12 +220,16 @@ constexpr int kBwdRows = (kBwdTileW * kBwdTileH) / 256;                         
 constexpr int kBwdHzGroups = kBwdTileW / 4;
 static_assert(kBwdTileW * (kBwdTileH / kBwdRows) == 256 && kBwdTileW % 4 == 0, "one (column, row strip) per thread");
 
-__global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, const GaussWindow gw) {
+__global__ void __launch_bounds__(256) ssim_backward_kernel(const LossArgs a, const GaussWindow gw, const unsigned n_reduce) {
     // The horizontally filtered maps go back into the memory of the staged region (dead once every thread has read its inputs into registers).
     constexpr int kMapFloats = kBwdRegionH * kBwdTileW;
     static_assert(3 * kBwdRegionH * kBwdRegionW >= 3 * kMapFloats, "the three filtered maps fit in the staged region");
     __shared__ float sd[3][kBwdRegionH][kBwdRegionW];
     float (*const hz)[kBwdRegionH][kBwdTileW] = reinterpret_cast<float (*)[kBwdRegionH][kBwdTileW]>(&sd[0][0][0]);
+    if (n_reduce != 0u && blockIdx.x == 0u) {        // the forward kernel's partial sums (complete: it is the launch in front) -> a.sums, by ONE workgroup
+        reduce_loss_partials(a, n_reduce, &sd[0][0][0]);
+        __syncthreads();                              // the scratch words are staged over below
+    }
     unsigned tile_x, tile_y, chan, logical;
     if (!loss_tile_of<FGS_LOSS_XCD_BANDS_BWD != 0>(blockIdx.x, (a.width + kBwdTileW - 1) / kBwdTileW, (a.height + kBwdTileH - 1) / kBwdTileH, tile_x, tile_y, chan, logical)) return;     // workgroup-uniform
     const int x0 = tile_x * kBwdTileW, y0 = tile_y * kBwdTileH, c = chan;
@@ -318,18 +331,21 @@ hipError_t launch_l1_dssim(const LossArgs& a, hipStream_t s) {
     const dim3 block(256);
     const unsigned tiles = static_cast<unsigned>((a.width + kLossTileW - 1) / kLossTileW) * static_cast<unsigned>((a.height + kLossTileH - 1) / kLossTileH) * 3u;
     hipLaunchKernelGGL(ssim_forward_kernel, loss_grid(tiles), block, 0, s, a, gw);
-    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), block, 0, s, a, tiles);
+    if (a.grad == nullptr || FGS_LOSS_SEPARATE_REDUCE) {
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(1), block, 0, s, a, tiles);
+        if (a.grad == nullptr) return hipGetLastError();
+    }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.grad == nullptr) return e;
+    if (e != hipSuccess) return e;
     const unsigned tiles_b = static_cast<unsigned>((a.width + kBwdTileW - 1) / kBwdTileW) * static_cast<unsigned>((a.height + kBwdTileH - 1) / kBwdTileH) * 3u;
-    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), block, 0, s, a, gw);
+    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), block, 0, s, a, gw, FGS_LOSS_SEPARATE_REDUCE ? 0u : tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_l1_dssim_backward(const LossArgs& a, hipStream_t s) {
     const GaussWindow gw = make_window();
     const unsigned tiles_b = static_cast<unsigned>((a.width + kBwdTileW - 1) / kBwdTileW) * static_cast<unsigned>((a.height + kBwdTileH - 1) / kBwdTileH) * 3u;
-    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), dim3(256), 0, s, a, gw);
+    hipLaunchKernelGGL(ssim_backward_kernel, loss_grid(tiles_b), dim3(256), 0, s, a, gw, 0u);
     return hipGetLastError();
 }
 
