@@ -217,7 +217,27 @@ __device__ __forceinline__ void preprocess_body(const PreprocessArgs& a) {
             }
             if (visible || huge) {
                 float col[3];
+#if defined(FGS_K1_SH_PROBE)
+                // TIMING PROBE, wrong colours (tools/build_variant.sh k1probe preprocess.hip -DFGS_K1_SH_PROBE): the lane's 45 coefficients are taken from the
+                // wave's 11.25 KB block with perfectly coalesced 16-byte loads (lane l takes float4 i*64 + l of the block) -- what staging the block through LDS
+                // could reach at most, without the LDS traffic. Measured: 0.198-0.201 -> 0.188-0.189 ms (profiles/r06_ab_k1_sh_probe.txt): the staging was not built.
+                float kk[48];
+                {
+                    const size_t wave_first = (size_t)(idx & ~63u) * 45u;
+                    const size_t total = (size_t)a.n * 45u;
+                    const float* blk = a.sh_rest + wave_first;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const size_t e = ((size_t)i * 64u + lane) * 4u;
+                        const bool in = i < 11 ? (wave_first + e + 3u < total) : (lane < 16u && wave_first + e + 3u < total);
+                        const float4 v = in ? *reinterpret_cast<const float4*>(blk + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        kk[4 * i] = v.x; kk[4 * i + 1] = v.y; kk[4 * i + 2] = v.z; kk[4 * i + 3] = v.w;
+                    }
+                }
+                const float* k = kk;
+#else
                 const float* k = a.sh_rest + (size_t)idx * cam.total_sh_rest * 3;
+#endif
                 sh_to_color(a.sh0 + 3 * (size_t)idx, k, m[0] - cam.pos[0], m[1] - cam.pos[1], m[2] - cam.pos[2],
                             (unsigned)cam.active_sh_bases, col);
                 if (INFERENCE) { col[0] = fmaxf(col[0], 0.0f); col[1] = fmaxf(col[1], 0.0f); col[2] = fmaxf(col[2], 0.0f); }  // ki:200
