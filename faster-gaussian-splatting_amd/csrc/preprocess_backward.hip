@@ -84,6 +84,9 @@ __device__ __forceinline__ bool gaussian_backward(const PreprocessBackwardArgs& 
             const float x = xr * inv, y = yr * inv, z = zr * inv;
             if (KEEP_DIR) { dir[0] = x; dir[1] = y; dir[2] = z; }
             else { V.view_dir[3 * (size_t)i] = x; V.view_dir[3 * (size_t)i + 1] = y; V.view_dir[3 * (size_t)i + 2] = z; }
+            // (round 6, measured and withdrawn: the wave's contiguous 11.25 KB coefficient block taken with coalesced 16-byte loads into the LDS slice the
+            // products go to afterwards, every lane reading its 45 words from there -- K12 0.282 vs 0.251 ms: the load -> LDS -> read chain in front of
+            // the arithmetic costs more at 3 waves per SIMD than the lane-strided loads do, profiles/r06_ab_k12_staged_coeffs.txt)
             const float* k = a.sh_rest + (size_t)i * cam.total_sh_rest * 3;
             float gdx[3], gdy[3], gdz[3];
 #pragma unroll
