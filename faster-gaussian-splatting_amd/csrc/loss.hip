@@ -201,7 +201,8 @@ __device__ __forceinline__ void reduce_loss_partials(const LossArgs& a, const un
 #ifndef FGS_LOSS_SEPARATE_REDUCE
 #define FGS_LOSS_SEPARATE_REDUCE 0       // A/B knob: 1 = the reduction as a launch of its own between the two filter kernels (until round 6)
 #endif
-// Loss value only (no gradient asked for). With a gradient, workgroup 0 of the backward kernel does this on its way in (round 6: one launch less).
+// Loss value only (no gradient asked for: the autograd form, whose forward call must leave a valid value). With a gradient in the same call, workgroup 0 of
+// the backward kernel does this on its way in (round 6: one launch less, -12 us per fused iteration, profiles/r06_ab_loss_reduce.txt).
 __global__ void __launch_bounds__(256) ssim_reduce_kernel(const LossArgs a, const unsigned n_blocks) {
     __shared__ float s_red[8];
     reduce_loss_partials(a, n_blocks, s_red);

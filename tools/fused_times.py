@@ -1,7 +1,7 @@
 """Fused iteration (BASELINE.json configs[3]) on S2, view 0, for the library named by FGS_HIP_LIBRARY: ms / iteration and the fused kernel's own
 time from HIP events (tools/ab_fused.sh alternates builds)."""
 import sys, time, torch
-sys.path[:0] = ['/root/repo', '/root/repo/faster-gaussian-splatting_amd']
+import os; ROOT = os.environ.get('ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [ROOT, ROOT + '/faster-gaussian-splatting_amd']
 import bench
 from FasterGSCudaBackend._backend import default_backend
 from FasterGSCudaBackend import FusedRasterizerOptimizer
