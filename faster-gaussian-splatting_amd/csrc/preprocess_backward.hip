@@ -781,6 +781,8 @@ hipError_t launch_sh_rest_backward(bool fused_adam, const ShRestArgs& a, hipStre
 // g_adam_unroll = 1: 16-byte pieces per thread (fgs_debug_set_option(1, u)); measured on MI355X: 1, 2 and 4 are within 2 %
 // g_adam_reverse = 1 (fgs_debug_set_option(8, 0|1) in the dev build): reversed workgroup order (measured 0.837 vs 0.855 ms at S2, tools/ab_adam_order.py)
 // g_adam_nontemporal = 1 (fgs_debug_set_option(2, 0|1) in the dev build): non-temporal loads / stores (state is streamed once per step: +2.3 % measured)
+// (round 6, measured and withdrawn: the updated PARAMETERS alone as ordinary stores, on the idea that the next forward pass reads them first -- K1 0.227 vs 0.201 ms,
+// Adam 0.797 vs 0.782: dirty lines in eight L2s are the last thing the next kernel's reads want to meet, profiles/r06_ab_adam_param_nt.txt)
 
 template <bool NT> __device__ __forceinline__ float4 load4(const float* p) { return NT ? load_float4_nt(p) : *reinterpret_cast<const float4*>(p); }
 template <bool NT> __device__ __forceinline__ void store4(float* p, const float4 v) {
