@@ -184,6 +184,10 @@ def preflight(args, world: int, local_rank) -> None:
     if args.sim or args.shared_device or args.cpu_baseline_only or world <= 1:
         return
     n_dev = torch.cuda.device_count()
+    if n_dev == 1 and local_rank is not None:
+        # a launcher that masks the devices per rank (every process sees exactly its own GPU as device 0): fine -- main() uses device 0 then, and the
+        # device-identity check behind the first collective stops the run if the ranks turn out to share one GPU after all
+        return
     if n_dev < world:
         raise SystemExit(f'bench.py --gpus {world}: only {n_dev} GPU(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = '
                          f'{os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "unset"))}). One process per GPU is required; '
@@ -258,7 +262,7 @@ def main():
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
     preflight(args, world=world, local_rank=local_rank)
     shared = args.shared_device and not sim
-    device = torch.device('cpu') if sim else torch.device('cuda', 0 if shared else local_rank)
+    device = torch.device('cpu') if sim else torch.device('cuda', 0 if (shared or torch.cuda.device_count() == 1) else local_rank)
     if not sim:
         torch.cuda.set_device(device)
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
