@@ -668,12 +668,17 @@ void orc_threshold_risk(const uint* ranges, const uint* inst_prims, const uint16
             const int sy0 = tyi * TILE_H + ((local / TILE_W) / SUBTILE_H) * SUBTILE_H;
             const int sx1 = sx0 + SUBTILE_W, sy1 = sy0 + SUBTILE_H;
             const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
-            const int last = (int)n_processed[pix];
+            /* The walk covers what the blend kernel walks: the tile's list until the transmittance test ends it -- NOT only the entries in front of the
+             * pixel's last contributor (n_processed): a pair that fails the alpha test by a hair BEHIND the last contributor is a flip like any other
+             * (the device then blends one entry more than this restatement; found by a 4000-seed fuzz sweep in round 6, seed 3316). */
+            const int n_total = (int)(ranges[2 * tile + 1] - r0);
+            (void)n_processed;
+            int n_scan = n_total;
             float Tr = 1.0f;
             int risky = 0;
             for (int pass = 0; pass < 2; pass++) {
                 if (pass == 1 && !risky) break;
-                for (int j = 0; j < last; j++) {
+                for (int j = 0; j < n_scan; j++) {
                     const uint p = inst_prims[r0 + j];
                     const float* co = conic_opacity + 4 * (size_t)p;
                     const float dx = mean2d[2 * (size_t)p] - pxf, dy = mean2d[2 * (size_t)p + 1] - pyf;
@@ -690,6 +695,7 @@ void orc_threshold_risk(const uint* ranges, const uint* inst_prims, const uint16
                     if (alpha < MIN_ALPHA_THRESHOLD) continue;
                     Tr *= 1.0f - alpha;
                     if (fabsf(Tr / TRANSMITTANCE_THRESHOLD - 1.0f) < eps_T) risky = 1;
+                    if (Tr < TRANSMITTANCE_THRESHOLD) { n_scan = j + 1; break; }                    /* kf:477: the pixel is done */
                 }
                 if (risky) risk_pixel[pix] = 1;
             }

@@ -302,6 +302,17 @@ def flip_masks(oracle, f, S, dec=None, eps=5e-6, eps_T=1e-5):
     S1 / S2 at 1080p): every pixel that differs by more than 1e-4 lies inside this mask, and outside it the image agrees to 5e-5 and
     all six gradients to 3e-5 of their max-abs value."""
     r = oracle.threshold_risk(f, S, eps, eps_T)
+    if dec is not None and dec.get('I') == f['I'] and 'conic_opacity' in dec and np.array_equal(dec['screen_bounds'], f['screen_bounds']):
+        # ... and the same walk over the DEVICE's records (round 6). The two sets of records are not bit-identical everywhere: a needle-shaped Gaussian's
+        # conic is cov / det with det a cancelling difference, and the one-ulp difference between the device's exp and glibc's in the variances reaches
+        # 7e-6 of the conic (seed 10436 of a 4000-seed sweep) -- a pair 1.5e-5 above the cut by the oracle's records can sit below it by the device's.
+        # A pair within the band by EITHER set of records is a legitimate flip.
+        vis = f['n_touched'] > 0
+        f_dev = dict(f)
+        f_dev['mean2d'] = np.ascontiguousarray(np.where(vis[:, None], dec['mean2d'], f['mean2d']).astype(np.float32))
+        f_dev['conic_opacity'] = np.ascontiguousarray(np.where(vis[:, None], dec['conic_opacity'], f['conic_opacity']).astype(np.float32))
+        r2 = oracle.threshold_risk(f_dev, S, eps, eps_T)
+        r = {k: r[k] | r2[k] for k in ('pixel', 'prim', 'near')}
     prim = r['prim'].copy()
     if dec is not None:
         vis = (f['n_touched'] > 0) | (dec['n_touched'] > 0)
@@ -386,7 +397,17 @@ def check_flip_aware(image, f_image, grads: dict, g_ref: dict, masks: dict, tol=
         a = np.asarray(a).reshape(ref.shape)
         report[k] = masked_rel_inf(a, ref, keep)
         report[k + '_masked'] = masked_rel_inf(a, ref, masks['prim'])
-        assert report[k] < tol, (label, k, report)
+        if report[k] >= tol and truth is not None and k in truth:
+            # A tensor whose LARGEST entry is itself an ill-conditioned sum (a one-Gaussian scene: its opacity gradient is a signed sum over the whole
+            # footprint; seeds 5645 / 5916 of a 4000-seed sweep, round 6) has no well-conditioned entry to set the scale: there the max-norm bar is
+            # applied three-way like the element-wise one -- the HIP value may be at most twice as far from the fp64 value as the fp32 oracle is.
+            t64 = np.asarray(truth[k]).reshape(ref.shape)
+            err_hip, err_o32 = masked_rel_inf(a, t64, keep), masked_rel_inf(ref, t64, keep)
+            report[k + '_vs_f64'] = (err_hip, err_o32)
+            log_note('max_norm_three_way', f'{err_hip:.3e}', label=label.replace(' ', '_'), tensor=k, oracle32=f'{err_o32:.3e}', hip_vs_oracle32=f'{report[k]:.3e}')
+            assert err_hip <= max(tol, 2.0 * err_o32), (label, k + ' (max-norm, three-way)', report)
+        else:
+            assert report[k] < tol, (label, k, report)
         assert report[k + '_masked'] < loose, (label, k + ' (masked Gaussians)', report)
         if truth is not None and k in truth:
             report[k + '_elem'] = elementwise_three_way(a, ref, np.asarray(truth[k]).reshape(ref.shape), keep, kind=k)
