@@ -314,10 +314,11 @@ def flip_masks(oracle, f, S, dec=None, eps=5e-6, eps_T=1e-5):
         r2 = oracle.threshold_risk(f_dev, S, eps, eps_T)
         r = {k: r[k] | r2[k] for k in ('pixel', 'prim', 'near')}
     prim = r['prim'].copy()
+    pixel, near = r['pixel'], r['near']
     if dec is not None:
         vis = (f['n_touched'] > 0) | (dec['n_touched'] > 0)
         prim |= vis & ((dec['n_touched'] != f['n_touched']) | (dec['screen_bounds'] != f['screen_bounds']).any(axis=1))
-    return {'pixel': r['pixel'], 'prim': prim, 'near': r['near'] & ~prim}
+    return {'pixel': pixel, 'prim': prim, 'near': near & ~prim}
 
 
 def masked_rel_inf(a, ref, keep):
