@@ -181,6 +181,31 @@ def forward(means, scales, rotations, opacities, sh0, sh_rest, settings: Setting
     return out
 
 
+def reblend(fwd: dict, settings: Settings, mean2d, conic_opacity, color) -> dict:
+    """Test support: K10 of `fwd` again on OTHER per-Gaussian records (the device's own, say) over the same discrete structure (instance lists, ranges,
+    buckets, screen bounds). Returns a copy of `fwd` with the records and every blend output replaced -- what `backward` and `threshold_risk`
+    need to follow. Isolates the two blend kernels from K1: a needle-shaped Gaussian's conic is cov / det with a cancelling det, and one ulp of
+    exp moves it by up to 2e-3 (profiles/r06_fuzz_sweeps.txt); with the same records on both sides only the blend arithmetic is compared."""
+    L = lib()
+    out = dict(fwd)
+    out['mean2d'] = np.ascontiguousarray(_f32(mean2d).reshape(-1, 2)); out['conic_opacity'] = np.ascontiguousarray(_f32(conic_opacity).reshape(-1, 4))
+    out['color'] = np.ascontiguousarray(_f32(color).reshape(-1, 3))
+    W, H, T, B, I = settings.width, settings.height, fwd['T'], fwd['B'], fwd['I']
+    inst_prims_c = np.ascontiguousarray(fwd['inst_prims']) if I > 0 else np.zeros(1, np.uint32)
+    image = np.zeros((3, H, W), np.float32)
+    final_T = np.ones(W * H, np.float32)
+    n_processed = np.zeros(W * H, np.uint32)
+    max_n_processed = np.zeros(T, np.uint32)
+    bucket_tile_index = np.zeros(max(B, 1), np.uint32)
+    bucket_ckpt = np.zeros((max(B, 1), BLOCK_BLEND, 4), np.float32)
+    L.orc_blend_forward(0, 1, 0, fwd['bucket_size'], _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims_c), _p(fwd['screen_bounds']),
+                        _p(out['mean2d']), _p(out['conic_opacity']), _p(out['color']), C.byref(fwd['_S']), _p(image), _p(final_T), _p(n_processed),
+                        _p(max_n_processed), _p(bucket_tile_index), _p(bucket_ckpt))
+    out.update(image=image, final_T=final_T, n_processed=n_processed, max_n_processed=max_n_processed,
+               bucket_tile_index=bucket_tile_index[:B], bucket_ckpt=bucket_ckpt[:B])
+    return out
+
+
 def backward(fwd: dict, settings: Settings, grad_image, densification_info: np.ndarray | None = None) -> dict:
     """K11 + K12 on the state returned by forward(); grads are zero-initialised as in rasterization_api.cu:127-134."""
     L = lib()
@@ -280,6 +305,38 @@ def forward_backward_f64(fwd: dict, settings: Settings, grad_image) -> dict:
                               _p(g['sh0']), _p(g['sh_rest']), None)
     g.update(image=image, final_T=final_T, n_processed=n_processed)
     return g
+
+
+def blend_sums_f64(fwd: dict, settings: Settings, grad_image) -> dict:
+    """Test support: the blend forward and K11's nine per-Gaussian sums in DOUBLE on the records held by `fwd` (reblend's output, say) over its discrete
+    structure -- the fp64 reference of helpers.check_blend_on_device_records' three-way bars. The per-pair decisions are re-taken in double, as in
+    forward_backward_f64. Returns {'image', 'final_T', 'sums' [N, 9] (mean2d.xy, conic.abc, opacity, colour.rgb)}."""
+    L = lib64()
+    f64 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+    N, B, T, bs = fwd['N'], fwd['B'], fwd['T'], fwd['bucket_size']
+    S32 = fwd['_S']
+    S = _Settings64()
+    for name, _ in _Settings64._fields_:
+        v = getattr(S32, name)
+        if hasattr(v, '__len__'):
+            getattr(S, name)[:] = [float(x) for x in v]
+        else:
+            setattr(S, name, v)
+    W, H = settings.width, settings.height
+    mean2d, conic, color = f64(fwd['mean2d']), f64(fwd['conic_opacity']), f64(fwd['color'])
+    inst_prims = np.ascontiguousarray(fwd['inst_prims']) if fwd['I'] > 0 else np.zeros(1, np.uint32)
+    image, final_T = np.zeros((3, H, W)), np.ones(W * H)
+    n_processed, max_n_processed = np.zeros(W * H, np.uint32), np.zeros(T, np.uint32)
+    bti = np.zeros(max(B, 1), np.uint32)
+    ckpt = np.zeros((max(B, 1), BLOCK_BLEND, 4))
+    L.orc_blend_forward(0, 1, 0, bs, _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims), _p(fwd['screen_bounds']), _p(mean2d),
+                        _p(conic), _p(color), C.byref(S), _p(image), _p(final_T), _p(n_processed), _p(max_n_processed), _p(bti), _p(ckpt))
+    gi = f64(grad_image).reshape(3, H, W)
+    grad_mean2d, grad_conic, g_op, g_col = np.zeros((N, 2)), np.zeros((3, N)), np.zeros((N, 1)), np.zeros((N, 1, 3))
+    L.orc_blend_backward(N, B, bs, _p(fwd['ranges']), _p(fwd['bucket_offsets']), _p(inst_prims), _p(mean2d), _p(conic), _p(color),
+                         C.byref(S), _p(gi), _p(image), _p(final_T), _p(max_n_processed), _p(n_processed), _p(bti), _p(ckpt),
+                         _p(grad_mean2d), _p(grad_conic), _p(g_op), _p(g_col))
+    return {'image': image, 'final_T': final_T, 'sums': np.concatenate([grad_mean2d, grad_conic.T, g_op.reshape(N, 1), g_col.reshape(N, 3)], axis=1)}
 
 
 def threshold_risk(fwd: dict, settings: Settings, eps: float = 1e-5, eps_T: float = 1e-4) -> dict:

@@ -584,3 +584,71 @@ def check_lists_up_to_ties(dec: dict, f: dict) -> None:
         mine = dec['inst_prims'][a:b]
         assert np.array_equal(np.sort(mine), np.sort(f['inst_prims'][a:b])), t
         assert np.all(np.diff(np.array([key_of[int(x)] for x in mine], np.int64)) >= 0), t
+
+
+# ---- the two blend kernels against the oracle ON THE DEVICE'S OWN RECORDS (round 6) --------------------------------------------------------------------------
+def check_blend_on_device_records(be, oracle, params, view, K=16, aa=False, device='cpu', label='', tol=1e-4, near_tol=1e-2, max_masked=3e-3):
+    """K10 and K11 isolated from K1: the backend's forward pass runs as usual; its per-Gaussian records (mean2d, conic, opacity, colour -- decoded from the
+    primitive blob) replace the oracle's in a second run of the oracle's blend (oracle.reblend) over the same instance lists, and the image, the final
+    transmittances, the last contributors and K11's nine per-Gaussian sums (read back from the blob behind fgs_backward) are held to `tol` outside the
+    threshold-risk masks of THAT run. What the end-to-end comparisons cannot separate -- a needle-shaped Gaussian whose conic differs by 2e-3 between two fp32
+    evaluations of kf:140-150 moves its pixels on both sides here."""
+    import torch
+    S, RS = settings_pair(view, K, aa, device=device)
+    dp = {k: v.to(device) for k, v in params.items()}
+    n = dp['means'].shape[0]
+    res = be.forward(*[dp[k] for k in NAMES], RS)
+    f = oracle.forward(*np_params(params), S, bucket_size=64)
+    dec = decode_forward(be, res, n, view.width, view.height)
+    # the DEVICE's discrete structure as well (tile counts, bounds, instance lists, ranges, buckets): equal depth keys keep K1's arrival order there and a
+    # cull / bound on its threshold may fall the other way -- neither is the blend kernels' business
+    T_ = f['T']
+    fdev = dict(f)
+    if 'B' not in dec:                                       # nothing visible: no bucket was laid out
+        dec = dict(dec, B=0, bucket_offsets=np.zeros(T_, np.uint32))
+    fdev.update(I=dec['I'], B=dec['B'], n_touched=np.ascontiguousarray(dec['n_touched']), screen_bounds=np.ascontiguousarray(dec['screen_bounds']),
+                inst_prims=np.ascontiguousarray(dec['inst_prims']), ranges=np.ascontiguousarray(dec['ranges'][:T_]),
+                bucket_offsets=np.ascontiguousarray(dec['bucket_offsets'][:T_]))
+    vis = dec['n_touched'] > 0
+    f2 = oracle.reblend(fdev, S, np.ascontiguousarray(dec['mean2d'], np.float32), np.ascontiguousarray(dec['conic_opacity'], np.float32), np.ascontiguousarray(dec['color'], np.float32))
+    masks = flip_masks(oracle, f2, S)
+    pm, prim, near = masks['pixel'], masks['prim'], masks['near']
+    report = {'masked_pixels': float(pm.mean()), 'masked_gaussians': float(prim.mean()), 'near_gaussians': float(near.mean())}
+    assert report['masked_pixels'] < max_masked and report['masked_gaussians'] < max_masked, (label, 'masked fraction', report)
+    img = res.image.cpu().numpy()
+    err = np.abs(img.astype(np.float64) - f2['image']).max(axis=0)
+    report['image'] = float(np.where(pm, 0.0, err).max() / max(1.0, float(np.abs(f2['image']).max())))
+    assert report['image'] < tol, (label, 'image on the device records', report)
+    fT = tiles_to_image(dec['final_T_tiles'], view.width, view.height, fill=1.0)
+    report['final_T'] = float(np.where(pm, 0.0, np.abs(fT - f2['final_T'].reshape(fT.shape))).max())
+    assert report['final_T'] < tol, (label, 'final transmittance', report)
+    npr = tiles_to_image(dec['n_processed_tiles'], view.width, view.height)
+    report['last_contributor_differs'] = float((npr != f2['n_processed'].reshape(npr.shape))[~pm].mean())
+    assert report['last_contributor_differs'] < 3e-4, (label, 'last contributor', report)
+    # backward: the nine sums of K11 per Gaussian, from the blob (they live behind the forward pass's records; hot Gaussians are folded by the backward pass)
+    gi = np.random.default_rng(3).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g2 = oracle.backward(f2, S, gi, np.zeros((2, n), np.float32))
+    be.backward(torch.zeros(2, n, device=device), torch.from_numpy(gi).to(device), res.image, dp['means'], dp['scales'], dp['rotations'], dp['opacities'],
+                dp['sh_coefficients_rest'], res.buffers, RS, res.state)
+    lp = be.blob_layout(0, n, view.width, view.height, res.state[1], res.state[2])
+    acc = be.view(res.buffers[0].cpu(), lp, 'acc', torch.float32).reshape(n, 9).numpy()
+    ref = np.concatenate([g2['_grad_mean2d'], g2['_grad_conic'].T, g2['_grad_opacity_acc'].reshape(n, 1), g2['_grad_color_acc'].reshape(n, 3)], axis=1)
+    keep = vis & ~prim & ~near
+    t64 = None
+    for c, name in enumerate(('mean2d.x', 'mean2d.y', 'conic.a', 'conic.b', 'conic.c', 'opacity', 'colour.r', 'colour.g', 'colour.b')):
+        scale = (float(np.abs(ref[vis, c]).max()) if vis.any() else 0.0) + 1e-30
+        report[name] = float(np.abs(acc[keep, c] - ref[keep, c]).max() / scale) if keep.any() else 0.0
+        report[name + '_near'] = float(np.abs(acc[vis & near & ~prim, c] - ref[vis & near & ~prim, c]).max() / scale) if (vis & near & ~prim).any() else 0.0
+        _log_tolerance('blend_on_device_records', report[name], acc[keep, c], ref[keep, c], tensor=name, label=label.replace(' ', '_'))
+        if report[name] >= tol:
+            # the largest entry of this sum over the scene is itself an ill-conditioned sum (a handful of visible Gaussians, or a screen-filling one whose
+            # dx^2 factors reach 1e5): three-way against the same sums in double -- the device may be at most twice as far from them as the fp32 oracle is
+            if t64 is None:
+                t64 = oracle.blend_sums_f64(f2, S, gi)['sums']
+            e_dev = float(np.abs(acc[keep, c] - t64[keep, c]).max() / (float(np.abs(t64[vis, c]).max()) + 1e-30))
+            e_o32 = float(np.abs(ref[keep, c] - t64[keep, c]).max() / (float(np.abs(t64[vis, c]).max()) + 1e-30))
+            report[name + '_vs_f64'] = (e_dev, e_o32)
+            log_note('blend_records_three_way', f'{e_dev:.3e}', label=label.replace(' ', '_'), tensor=name, oracle32=f'{e_o32:.3e}', device_vs_oracle32=f'{report[name]:.3e}')
+            assert e_dev <= max(tol, 2.0 * e_o32), (label, 'K11 sum ' + name + ' (three-way against fp64)', report)
+        assert report[name + '_near'] < near_tol, (label, 'K11 sum ' + name + ' (behind a borderline pair)', report)
+    return report

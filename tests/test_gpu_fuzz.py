@@ -66,3 +66,19 @@ def test_random_mid_scale_configuration_against_oracle(hip_backend, oracle, seed
     # the index of a pixel's last contributor may differ outside the mask on 3e-4 of the pixels: with opacities lowered by 3 most lists end in a
     # run of pairs near the 1/255 cut, and a flip of the very last one moves the image by less than the bar (seed 4 of a 24-seed sweep: 1.3e-4)
     _flip_aware_forward_backward(hip_backend, oracle, p, view, label, adam_steps=2, K=K, aa=aa, max_masked=3e-3, last_contributor_budget=3e-4, near_tol=1e-2)
+
+
+# Mid-scale seeds of a 600-seed sweep (round 6, profiles/r06_fuzz_sweeps.txt) whose END-TO-END comparison fails on a few dozen pixels because one needle-shaped
+# Gaussian's conic (cov / det, det a cancelling difference) differs by up to 2e-3 between the device's K1 and the oracle's: with the device's own records on both
+# sides the two blend kernels are held to the usual bars on exactly those scenes, next to the suite's own four.
+@pytest.mark.parametrize('seed', sorted(set(_MID_SEEDS) | {90, 201, 264, 351, 469}))
+def test_mid_scale_blend_kernels_on_the_device_records(hip_backend, oracle, seed):
+    p, view, K, aa, label = _mid_scale_configuration(seed)
+    helpers.check_blend_on_device_records(hip_backend, oracle, p, view, K, aa, device='cuda', label=label)
+
+
+@pytest.mark.parametrize('seed', _SEEDS[::2])
+def test_random_configuration_blend_kernels_on_the_device_records(hip_backend, oracle, seed):
+    p, view, K, aa, label = _configuration(seed)
+    n, pixels = p['means'].shape[0], view.width * view.height
+    helpers.check_blend_on_device_records(hip_backend, oracle, p, view, K, aa, device='cuda', label=label, max_masked=max(2e-2, 6.0 / min(n, pixels)))

@@ -517,6 +517,15 @@ def test_full_size_against_oracle(hip_backend, oracle, scene, n, view):
     _flip_aware_forward_backward(hip_backend, oracle, params, orbit_views(8)[view], scene, adam_steps=3)
 
 
+@pytest.mark.parametrize('scene,n,view,shift', [('S2', 3_000_000, 3, 0.0), ('S2 layered', 3_000_000, 3, -3.0)])
+def test_full_size_blend_kernels_on_the_device_records(hip_backend, oracle, scene, n, view, shift):
+    """K10 / K11 isolated from K1 at the headline size (round 6; helpers.check_blend_on_device_records): the oracle's blend re-run on the records the device's K1
+    produced, over the same instance lists -- image, final transmittance, last contributors and K11's nine per-Gaussian sums to 1e-4 outside the risk masks."""
+    params = make_garden_like(n)
+    params['opacities'] = params['opacities'] + shift
+    helpers.check_blend_on_device_records(hip_backend, oracle, params, orbit_views(8)[view], device=DEV, label=scene, max_masked=3e-3)
+
+
 def test_layered_scene_full_size_against_oracle(hip_backend, oracle):
     """bench.py's `layered_scene` at the size it is timed (missing #2): S2 with every opacity logit lowered by 3 -- ~11 of the
     ~13 buckets of a tile are blended instead of 2 of 21, the regime of a trained scene, where K10 / K11 are more than half of the step.

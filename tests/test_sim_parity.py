@@ -440,3 +440,12 @@ def test_depth_sort_pass_counts_through_the_forward_sim(sim_backend, oracle, nea
     dec = helpers.decode_forward(sim_backend, res, 800, v.width, v.height)
     assert f['V'] == 800 and dec['I'] == f['I'] and np.array_equal(dec['inst_keys'], f['inst_keys']) and np.array_equal(dec['inst_prims'], f['inst_prims'])
     assert np.array_equal(dec['offsets'], f['offsets']) and float(np.abs(res.image.numpy() - f['image']).max()) < 1e-6
+
+
+def test_blend_kernels_on_the_backends_own_records(sim_backend, oracle):
+    """K10 / K11 isolated from K1 (helpers.check_blend_on_device_records): the oracle's blend re-run on the records the backend's K1 produced."""
+    params, view = make_s0()
+    r = helpers.check_blend_on_device_records(sim_backend, oracle, params, view, label='S0')
+    assert r['image'] == 0.0
+    p, view, K, aa, label = helpers.fuzz_configuration(8)
+    helpers.check_blend_on_device_records(sim_backend, oracle, p, view, K, aa, label=label, max_masked=2e-2)
