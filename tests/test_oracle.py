@@ -339,3 +339,23 @@ def test_fp32_oracle_misses_elementwise_bar_by_conditioning(oracle):
         assert helpers.rel_inf(g[k], t[k]) < 1e-5, k                      # max-norm: fine
     assert all(frac[k] > 5e-3 for k in ('means', 'scales', 'rotations', 'opacities')), frac
     assert all(frac[k] < 1e-3 for k in ('sh0', 'sh_rest')), frac           # sums of same-signed terms times a gradient: well conditioned
+
+
+def test_reblend_and_fp64_blend_sums_follow_the_fp32_run(oracle):
+    """Test support of helpers.check_blend_on_device_records: reblend on the run's own records reproduces its blend outputs bit for bit, and the nine
+    K11 sums evaluated in double agree with the fp32 ones to fp32 rounding on a well-conditioned scene."""
+    params, view = make_s0()
+    S, _ = helpers.settings_pair(view)
+    f = oracle.forward(*helpers.np_params(params), S, bucket_size=64)
+    f2 = oracle.reblend(f, S, f['mean2d'], f['conic_opacity'], f['color'])
+    for k in ('image', 'final_T', 'n_processed', 'max_n_processed', 'bucket_ckpt', 'bucket_tile_index'):
+        assert np.array_equal(f2[k], f[k]), k
+    gi = np.random.default_rng(3).standard_normal(f['image'].shape).astype(np.float32) / f['image'].size
+    g = oracle.backward(f, S, gi, np.zeros((2, f['N']), np.float32))
+    ref = np.concatenate([g['_grad_mean2d'], g['_grad_conic'].T, g['_grad_opacity_acc'].reshape(-1, 1), g['_grad_color_acc'].reshape(-1, 3)], axis=1)
+    t = oracle.blend_sums_f64(f, S, gi)
+    assert np.abs(t['image'] - f['image']).max() < 1e-6
+    assert (np.abs(ref - t['sums']).max(axis=0) / np.abs(t['sums']).max(axis=0)).max() < 2e-6
+    # other records move the image: a colour scaled by two doubles every pixel's foreground
+    f3 = oracle.reblend(f, S, f['mean2d'], f['conic_opacity'], 2.0 * np.maximum(f['color'], 0.0))
+    assert np.abs(f3['final_T'] - f['final_T']).max() == 0.0 and not np.array_equal(f3['image'], f['image'])
