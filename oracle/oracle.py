@@ -307,6 +307,28 @@ def forward_backward_f64(fwd: dict, settings: Settings, grad_image) -> dict:
     return g
 
 
+def records_f64(fwd: dict, settings: Settings) -> dict:
+    """Test support: K1's per-Gaussian records (mean2d, conic + opacity, colour) evaluated in DOUBLE on the fp32 inputs, for the Gaussians the fp32 run found
+    visible (orc_preprocess_follow, as forward_backward_f64 uses it) -- the fp64 reference of a conditioning-aware comparison of two fp32 K1s."""
+    L = lib64()
+    f64 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float64)
+    means, scales, rotations, opacities, sh0, sh_rest = (f64(a) for a in fwd['_inputs'])
+    N = fwd['N']
+    S32 = fwd['_S']
+    S = _Settings64()
+    for name, _ in _Settings64._fields_:
+        v = getattr(S32, name)
+        if hasattr(v, '__len__'):
+            getattr(S, name)[:] = [float(x) for x in v]
+        else:
+            setattr(S, name, v)
+    S.total_sh_rest = int(sh_rest.shape[1] if sh_rest.ndim == 3 else 0)
+    mean2d, conic, color = np.zeros((N, 2)), np.zeros((N, 4)), np.zeros((N, 3))
+    L.orc_preprocess_follow(N, _p(means), _p(scales), _p(rotations), _p(opacities), _p(sh0), _p(sh_rest), C.byref(S),
+                            _p(fwd['n_touched']), _p(mean2d), _p(conic), _p(color))
+    return {'mean2d': mean2d, 'conic_opacity': conic, 'color': color}
+
+
 def blend_sums_f64(fwd: dict, settings: Settings, grad_image) -> dict:
     """Test support: the blend forward and K11's nine per-Gaussian sums in DOUBLE on the records held by `fwd` (reblend's output, say) over its discrete
     structure -- the fp64 reference of helpers.check_blend_on_device_records' three-way bars. The per-pair decisions are re-taken in double, as in

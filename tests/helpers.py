@@ -652,3 +652,37 @@ def check_blend_on_device_records(be, oracle, params, view, K=16, aa=False, devi
             assert e_dev <= max(tol, 2.0 * e_o32), (label, 'K11 sum ' + name + ' (three-way against fp64)', report)
         assert report[name + '_near'] < near_tol, (label, 'K11 sum ' + name + ' (behind a borderline pair)', report)
     return report
+
+
+def check_records_against_f64(be, oracle, params, view, K=16, aa=False, device='cpu', label='', thresholds=(1e-6, 1e-5, 1e-4, 1e-3, 1e-2)):
+    """K1 on its own, conditioning-aware (round 6; the complement of check_blend_on_device_records). Every record component of every Gaussian both runs find
+    visible -- mean2d, the three conic entries, opacity, colour -- is measured against its fp64 value (oracle.records_f64), on the device and in the fp32 oracle.
+    An entry-by-entry bar is meaningless here (two draws from the same rounding-error distribution differ by a factor of four in 15 % of the ill-conditioned
+    entries): the DISTRIBUTIONS are compared, as the element-wise three-way bar of the gradients does -- for every threshold t the device may have at most
+    1.25 x as many entries farther than t (relative) from the fp64 value as the fp32 oracle has, plus four standard deviations of that count, and its worst entry
+    may be at most 4 x the oracle's worst. A needle-shaped Gaussian's conic (cov / det, det a cancelling difference) is up to 0.2 of itself off the fp64 value in
+    BOTH fp32 runs at S1; 2e-3 apart between them is inside that. Returns the counts."""
+    S, RS = settings_pair(view, K, aa, device=device)
+    dp = {k: v.to(device) for k, v in params.items()}
+    n = dp['means'].shape[0]
+    res = be.forward(*[dp[k] for k in NAMES], RS)
+    f = oracle.forward(*np_params(params), S, bucket_size=64)
+    dec = decode_forward(be, res, n, view.width, view.height)
+    t = oracle.records_f64(f, S)
+    both = (f['n_touched'] > 0) & (dec['n_touched'] > 0)
+    report = {'visible': int(both.sum()), 'visible_to_one_side_only': int(((f['n_touched'] > 0) ^ (dec['n_touched'] > 0)).sum())}
+    assert report['visible_to_one_side_only'] <= max(2, n // 1000), (label, report)
+    for name in ('mean2d', 'conic_opacity', 'color'):
+        a, b, x = np.asarray(dec[name], np.float64)[both], np.asarray(f[name], np.float64)[both], t[name][both]
+        if not a.size:
+            continue
+        mag = np.maximum(np.abs(x), 1e-30)
+        e_dev, e_o32 = np.abs(a - x) / mag, np.abs(b - x) / mag
+        counts = {th: (int((e_dev > th).sum()), int((e_o32 > th).sum())) for th in thresholds}
+        report[name] = {'worst_device': float(e_dev.max()), 'worst_oracle32': float(e_o32.max()), 'beyond_threshold (device, oracle32)': counts, 'entries': int(a.size),
+                        'differ_between_the_fp32_runs': int((a != b).sum())}
+        log_note('records_vs_f64', f'{float(e_dev.max()):.3e}', label=label.replace(' ', '_'), record=name, oracle32=f'{float(e_o32.max()):.3e}', counts=str(counts).replace(' ', ''))
+        assert report[name]['worst_device'] <= 4.0 * report[name]['worst_oracle32'] + 2e-6, (label, name, 'worst entry', report)
+        for th, (n_dev, n_o32) in counts.items():
+            assert n_dev <= 1.25 * n_o32 + 4.0 * max(n_o32, 1) ** 0.5 + 2, (label, name, f'entries farther than {th:g} from the fp64 value', report)
+    return report

@@ -449,3 +449,10 @@ def test_blend_kernels_on_the_backends_own_records(sim_backend, oracle):
     assert r['image'] == 0.0
     p, view, K, aa, label = helpers.fuzz_configuration(8)
     helpers.check_blend_on_device_records(sim_backend, oracle, p, view, K, aa, label=label, max_masked=2e-2)
+
+
+def test_records_against_fp64_conditioning_aware(sim_backend, oracle):
+    """helpers.check_records_against_f64 on the simulation (bit-identical to the fp32 oracle here: the excess is the floor)."""
+    params, view = make_s0()
+    r = helpers.check_records_against_f64(sim_backend, oracle, params, view, label='S0')
+    assert r['visible'] == 1000 and all(r[k]['differ_between_the_fp32_runs'] == 0 for k in ('mean2d', 'conic_opacity', 'color'))
